@@ -1,0 +1,52 @@
+// Error plumbing + ABI query for libmla_hip.so (see include/mla_hip.h).
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void mla_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* mla_last_error(void) { return g_err; }
+
+// what: 0 = ABI version, 1 = compiled gfx arch number (950), 2 = wavefront size the kernels assume
+extern "C" int mla_query(int what) {
+  switch (what) {
+    case 0: return 1;
+    case 1: return 950;
+    case 2: return 64;
+    default: return -1;
+  }
+}
+
+// ---- hardware-assumption self tests (run by tests/test_hip_selftest.py on the GPU box) ----
+// out_tr[lane*4 + j] = element returned to `lane` as its j-th b16 by ds_read_b64_tr_b16 when LDS holds
+// lds[e] = e (u16) and lane l passes byte address l*8.  DESIGN.md states the mapping the kernels rely on:
+// out_tr[l*4+j] == (l>>4)*64 + j*16 + (l&15).
+// out_glds[i] = u32 word i of the LDS image after one global_load_lds_dwordx4 where lane l sourced src + l*16 bytes:
+// expected out_glds[i] == src_words[i] (lane-linear destination).
+__global__ void selftest_kernel(const uint32_t* __restrict__ src, int* __restrict__ out_tr, uint32_t* __restrict__ out_glds) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint16_t* l16 = (uint16_t*)smem;
+  const int lane = threadIdx.x;
+  for (int e = lane; e < 1024; e += 64) l16[e] = (uint16_t)e;
+  __syncthreads();
+  const short4_t v = lds_tr16_b64(smem + lane * 8);
+  for (int j = 0; j < 4; ++j) out_tr[lane * 4 + j] = (int)(uint16_t)v[j];
+  __syncthreads();
+  glds16((const char*)src + lane * 16, smem + 4096);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const uint32_t* l32 = (const uint32_t*)(smem + 4096);
+  for (int i = lane; i < 256; i += 64) out_glds[i] = l32[i];
+}
+
+extern "C" int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_1k, hipStream_t stream) {
+  MLA_CHECK_ARG(src_1k && out_tr_256 && out_glds_1k, "mla_selftest: null pointer");
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 8192, stream, (const uint32_t*)src_1k, out_tr_256, (uint32_t*)out_glds_1k);
+  MLA_LAUNCH_CHECK();
+}

@@ -1,0 +1,474 @@
+// Causal flash attention (forward, dQ, dK/dV) for head_dim 128, bf16 in / fp32 accumulate, gfx950 MFMA.
+//
+// Replaces flash_attn 2.5.5's varlen causal SDPA used by LlamaFlashAttention2
+// (reference: transformers/models/llama/modeling_llama.py:420-597; math = LlamaAttention.forward :371-380).
+// Semantics: softmax(Q K^T / sqrt(D) + causal) V per (batch, head); right-padded rows (q >= seqlen[b]) produce
+// zero output and zero gradients (the flash/varlen behaviour).
+//
+// Design (DESIGN.md "attention"): every product is computed *transposed* so that the softmax axis is lane-local:
+//   S^T = K Q^T        -> lane holds 16 scores of ONE query (q = lane&15), row max/sum = 2 xor-shuffles
+//   O^T = V^T P^T      -> P^T feeds the MFMA B operand straight from the score registers (no LDS round trip,
+//                         no permute): the MFMA k-slot <-> key mapping is permuted instead, and V^T fragments are
+//                         gathered with ds_read_b64_tr_b16 using the same permutation.
+// K/V (or Q/dO) tiles of 64 rows are staged with global_load_lds_dwordx4 into a double-buffered, source-swizzled
+// LDS image. One block = 4 waves x 16 rows.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int D = 128;
+constexpr int TROWS = 64;
+constexpr int TILE_BYTES = TROWS * D * 2;  // 16 KiB
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// swizzle of the 16-B chunk index inside a 256-B row: SW 0 = conflict-free ds_read_b128 row reads,
+// SW 1 = conflict-free ds_read_b64_tr_b16 over 8 consecutive rows.
+template <int SW>
+__device__ __forceinline__ int swz(int row, int c) { return SW == 0 ? (c ^ (row & 15)) : (c ^ ((row & 7) << 1)); }
+
+template <int SW>
+__device__ __forceinline__ void stage_rows64(const bf16_t* __restrict__ base, long long ld, int row0, int row_lim,
+                                             char* tile, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int instr = wave * 4 + it;
+    const int p = instr * 64 + lane;
+    const int row = p >> 4, cp = p & 15;
+    const int c = swz<SW>(row, cp);
+    int gr = row0 + row;
+    gr = gr < row_lim ? gr : row_lim - 1;
+    glds16(base + (long long)gr * ld + c * 8, tile + instr * 1024);
+  }
+}
+
+// A/B fragment of 16 tile rows (rb) x 32 d (ks): lane (i = lane&15 -> row, g = lane>>4 -> d group of 8)
+template <int SW>
+__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int rb, int ks, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int row = rb * 16 + i;
+  return *(const bf16x8_t*)(tile + (row * 16 + swz<SW>(row, ks * 4 + g)) * 16);
+}
+// transposed fragment: lane (i -> d = fd*16 + i, g) gets tile[row(g, j)][d], with the permuted reduction mapping
+// row(g, j) = ks2*32 + (j>>2)*16 + g*4 + (j&3)  -- identical to how the score registers enumerate their rows.
+template <int SW>
+__device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int fd, int ks2, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  union { bf16x8_t v; short4_t h[2]; } u;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = ks2 * 32 + jj * 16 + g * 4 + (i >> 2);
+    const int cp = swz<SW>(row, fd * 2 + ((i & 3) >> 1));
+    u.h[jj] = lds_tr16_b64(tile + (row * 16 + cp) * 16 + (i & 1) * 8);
+  }
+  return u.v;
+}
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t& lo, const f32x4_t& hi) {
+  union { bf16x8_t v; uint32_t w[4]; } u;
+  u.w[0] = pack2bf(lo[0], lo[1]); u.w[1] = pack2bf(lo[2], lo[3]);
+  u.w[2] = pack2bf(hi[0], hi[1]); u.w[3] = pack2bf(hi[2], hi[3]);
+  return u.v;
+}
+// direct global load of this lane's B-operand fragments of one row (4 k-steps of 32 d)
+__device__ __forceinline__ void load_row_frags(const bf16_t* __restrict__ rowptr, int lane, bf16x8_t* f) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8_t*)(rowptr + ks * 32 + g * 8);
+}
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;  // [B, S, *] token stride ld, head stride D
+  bf16_t* o;                                           // forward output [B, S, H*D] (ld_o)
+  float* lse;                                          // [B, H, S]
+  const int* seqlens;                                  // [B] or null
+  const bf16_t* dout;                                  // [B, S, H*D] (ld_o)
+  const float* delta;                                  // [B, H, S]
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;                  // same layout as q/k/v (ld)
+  int B, S, H;
+  long long ld, ld_o;
+  float scale;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqb = (p.S + 63) / 64;
+  const int qb = nqb - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
+  const int q0 = qb * 64;
+  const int myq = q0 + wave * 16 + (lane & 15);
+  const int g = lane >> 4;
+  const bf16_t* qb_ = p.q + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* vb_ = p.v + (long long)b * p.S * p.ld + h * D;
+  bf16_t* orow = p.o + ((long long)b * p.S + myq) * p.ld_o + h * D;
+  float* lse_p = p.lse + ((long long)b * p.H + h) * p.S;
+
+  int nkt = qb + 1;
+  const int kt_lim = (seqlen + 63) / 64;
+  if (nkt > kt_lim) nkt = kt_lim;
+  if (nkt <= 0) {  // whole block is padding
+    if (myq < p.S) {
+#pragma unroll
+      for (int fd = 0; fd < 8; ++fd) *(u32x2_t*)(orow + fd * 16 + g * 4) = u32x2_t{0u, 0u};
+      if (g == 0) lse_p[myq] = INFINITY;
+    }
+    return;
+  }
+
+  bf16x8_t qf[4];
+  load_row_frags(qb_ + (long long)(myq < p.S ? myq : p.S - 1) * p.ld, lane, qf);
+
+  f32x4_t ot[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ot[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const float sc2 = p.scale * LOG2E;
+
+  stage_rows64<0>(kb_, p.ld, 0, p.S, smem, wave, lane);
+  stage_rows64<1>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* kt_ = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* vt_ = kt_ + TILE_BYTES;
+    if (kt + 1 < nkt) {
+      char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+      stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
+      stage_rows64<1>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+    }
+    f32x4_t st[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      st[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        st[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<0>(kt_, f, ks, lane), qf[ks], st[f], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 64 + f * 16 + g * 4 + r;
+        const float s = (key <= myq) ? st[f][r] * sc2 : -INFINITY;
+        st[f][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = group_max(mx);
+    const float mnew = fmaxf(m, mx);
+    const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+    const float alpha = exp2f(m - msafe);
+    float rs = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = exp2f(st[f][r] - msafe);
+        st[f][r] = e;
+        rs += e;
+      }
+    rs = group_sum(rs);
+    l = l * alpha + rs;
+    m = mnew;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ot[i] *= alpha;
+    const bf16x8_t pf0 = pack_frag(st[0], st[1]), pf1 = pack_frag(st[2], st[3]);
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      ot[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<1>(vt_, fd, 0, lane), pf0, ot[fd], 0, 0, 0);
+      ot[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<1>(vt_, fd, 1, lane), pf1, ot[fd], 0, 0, 0);
+    }
+  }
+  if (myq < p.S) {
+    const bool pad = myq >= seqlen;
+    const float inv = (pad || l == 0.f) ? 0.f : 1.f / l;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2_t w;
+      w[0] = pack2bf(ot[fd][0] * inv, ot[fd][1] * inv);
+      w[1] = pack2bf(ot[fd][2] * inv, ot[fd][3] * inv);
+      *(u32x2_t*)(orow + fd * 16 + g * 4) = w;
+    }
+    if (g == 0) lse_p[myq] = pad ? INFINITY : (m * LN2 + logf(l));
+  }
+}
+
+// delta[b][h][q] = sum_d O[q][d] * dO[q][d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int S, int H, long long ld_o) {
+  const long long total = (long long)B * S * H * 16;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const bool ok = idx < total;
+    const long long id = ok ? idx : total - 1;
+    const int c = (int)(id & 15);
+    const long long r = id >> 4;
+    const int h = (int)(r % H);
+    const long long tok = r / H;
+    const u32x4_t a = *(const u32x4_t*)(o + tok * ld_o + h * D + c * 8);
+    const u32x4_t d = *(const u32x4_t*)(dout + tok * ld_o + h * D + c * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += bflo(a[j]) * bflo(d[j]) + bfhi(a[j]) * bfhi(d[j]);
+    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    if (ok && c == 0) {
+      const long long bb = tok / S, q = tok % S;
+      delta[(bb * H + h) * S + q] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqb = (p.S + 63) / 64;
+  const int qb = nqb - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
+  const int q0 = qb * 64;
+  const int myq = q0 + wave * 16 + (lane & 15);
+  const int g = lane >> 4;
+  const bf16_t* qb_ = p.q + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* vb_ = p.v + (long long)b * p.S * p.ld + h * D;
+  bf16_t* dqrow = p.dq + ((long long)b * p.S + myq) * p.ld + h * D;
+
+  int nkt = qb + 1;
+  const int kt_lim = (seqlen + 63) / 64;
+  if (nkt > kt_lim) nkt = kt_lim;
+  if (nkt <= 0) {
+    if (myq < p.S) {
+#pragma unroll
+      for (int fd = 0; fd < 8; ++fd) *(u32x2_t*)(dqrow + fd * 16 + g * 4) = u32x2_t{0u, 0u};
+    }
+    return;
+  }
+  const int qc = myq < p.S ? myq : p.S - 1;
+  bf16x8_t qf[4], dof[4];
+  load_row_frags(qb_ + (long long)qc * p.ld, lane, qf);
+  load_row_frags(p.dout + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, dof);
+  const bool padq = (myq >= seqlen) || (myq >= p.S);
+  const float lse2 = padq ? INFINITY : p.lse[((long long)b * p.H + h) * p.S + qc] * LOG2E;
+  const float dlt = p.delta[((long long)b * p.H + h) * p.S + qc];
+  const float sc2 = p.scale * LOG2E;
+
+  f32x4_t dqt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dqt[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage_rows64<0>(kb_, p.ld, 0, p.S, smem, wave, lane);
+  stage_rows64<0>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* kt_ = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* vt_ = kt_ + TILE_BYTES;
+    if (kt + 1 < nkt) {
+      char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+      stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
+      stage_rows64<0>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+    }
+    f32x4_t st[4], dp[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      st[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<0>(kt_, f, ks, lane), qf[ks], st[f], 0, 0, 0);
+        dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<0>(vt_, f, ks, lane), dof[ks], dp[f], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 64 + f * 16 + g * 4 + r;
+        const float pr = (key <= myq) ? exp2f(st[f][r] * sc2 - lse2) : 0.f;
+        st[f][r] = pr * (dp[f][r] - dlt);
+      }
+    const bf16x8_t ds0 = pack_frag(st[0], st[1]), ds1 = pack_frag(st[2], st[3]);
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      dqt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(kt_, fd, 0, lane), ds0, dqt[fd], 0, 0, 0);
+      dqt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(kt_, fd, 1, lane), ds1, dqt[fd], 0, 0, 0);
+    }
+  }
+  if (myq < p.S) {
+    const float sc = padq ? 0.f : p.scale;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2_t w;
+      w[0] = pack2bf(dqt[fd][0] * sc, dqt[fd][1] * sc);
+      w[1] = pack2bf(dqt[fd][2] * sc, dqt[fd][3] * sc);
+      *(u32x2_t*)(dqrow + fd * 16 + g * 4) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles + 2 x (64 lse + 64 delta) floats
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nkb = (p.S + 63) / 64;
+  const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
+  const int mykey = kb * 64 + wave * 16 + (lane & 15);
+  const int g = lane >> 4;
+  const bf16_t* qb_ = p.q + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* dob_ = p.dout + (long long)b * p.S * p.ld_o + h * D;
+  const float* lse_p = p.lse + ((long long)b * p.H + h) * p.S;
+  const float* dl_p = p.delta + ((long long)b * p.H + h) * p.S;
+  float* stats = (float*)(smem + 4 * TILE_BYTES);  // [2 buffers][lse 64 | delta 64]
+
+  const int kc = mykey < p.S ? mykey : p.S - 1;
+  bf16x8_t kf[4], vf[4];
+  load_row_frags(p.k + ((long long)b * p.S + kc) * p.ld + h * D, lane, kf);
+  load_row_frags(p.v + ((long long)b * p.S + kc) * p.ld + h * D, lane, vf);
+
+  f32x4_t dkt[8], dvt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { dkt[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  const float sc2 = p.scale * LOG2E;
+
+  // queries that can see this key block: q >= kb*64, q < min(S, seqlen)
+  int qend = seqlen < p.S ? seqlen : p.S;
+  const int nqt_end = (qend + 63) / 64;
+  const int qt0 = kb;
+  if (qt0 < nqt_end) {
+    stage_rows64<0>(qb_, p.ld, qt0 * 64, p.S, smem, wave, lane);
+    stage_rows64<0>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
+  }
+  for (int qt = qt0; qt < nqt_end; ++qt) {
+    const int bufi = (qt - qt0) & 1;
+    if (threadIdx.x < 128) {
+      const int qi = qt * 64 + (threadIdx.x & 63);
+      float val;
+      if (threadIdx.x < 64) val = (qi < qend) ? lse_p[qi] * LOG2E : INFINITY;
+      else val = (qi < qend) ? dl_p[qi] : 0.f;
+      stats[bufi * 128 + threadIdx.x] = val;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* qt_ = smem + bufi * 2 * TILE_BYTES;
+    const char* dot_ = qt_ + TILE_BYTES;
+    if (qt + 1 < nqt_end) {
+      char* nx = smem + (bufi ^ 1) * 2 * TILE_BYTES;
+      stage_rows64<0>(qb_, p.ld, (qt + 1) * 64, p.S, nx, wave, lane);
+      stage_rows64<0>(dob_, p.ld_o, (qt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+    }
+    f32x4_t s[4], dp[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      s[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<0>(qt_, f, ks, lane), kf[ks], s[f], 0, 0, 0);
+        dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<0>(dot_, f, ks, lane), vf[ks], dp[f], 0, 0, 0);
+      }
+    }
+    f32x4_t pr[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const f32x4_t l4 = *(const f32x4_t*)(stats + bufi * 128 + f * 16 + g * 4);
+      const f32x4_t d4 = *(const f32x4_t*)(stats + bufi * 128 + 64 + f * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qt * 64 + f * 16 + g * 4 + r;
+        const float pv = (mykey <= qi) ? exp2f(s[f][r] * sc2 - l4[r]) : 0.f;
+        pr[f][r] = pv;
+        s[f][r] = pv * (dp[f][r] - d4[r]);
+      }
+    }
+    const bf16x8_t p0 = pack_frag(pr[0], pr[1]), p1 = pack_frag(pr[2], pr[3]);
+    const bf16x8_t ds0 = pack_frag(s[0], s[1]), ds1 = pack_frag(s[2], s[3]);
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(dot_, fd, 0, lane), p0, dvt[fd], 0, 0, 0);
+      dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(dot_, fd, 1, lane), p1, dvt[fd], 0, 0, 0);
+      dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(qt_, fd, 0, lane), ds0, dkt[fd], 0, 0, 0);
+      dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(qt_, fd, 1, lane), ds1, dkt[fd], 0, 0, 0);
+    }
+  }
+  if (mykey < p.S) {
+    bf16_t* dkrow = p.dk + ((long long)b * p.S + mykey) * p.ld + h * D;
+    bf16_t* dvrow = p.dv + ((long long)b * p.S + mykey) * p.ld + h * D;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2_t w;
+      w[0] = pack2bf(dkt[fd][0] * p.scale, dkt[fd][1] * p.scale);
+      w[1] = pack2bf(dkt[fd][2] * p.scale, dkt[fd][3] * p.scale);
+      *(u32x2_t*)(dkrow + fd * 16 + g * 4) = w;
+      w[0] = pack2bf(dvt[fd][0], dvt[fd][1]);
+      w[1] = pack2bf(dvt[fd][2], dvt[fd][3]);
+      *(u32x2_t*)(dvrow + fd * 16 + g * 4) = w;
+    }
+  }
+  (void)nkb;
+}
+
+int check_common(const AttnArgs& p, const char* who) {
+  if (!(p.B > 0 && p.S > 0 && p.H > 0)) { mla_set_error("%s: bad shape", who); return -1; }
+  if ((p.ld % 8) || (p.ld_o % 8)) { mla_set_error("%s: strides must be multiples of 8 elements", who); return -1; }
+  return 0;
+}
+
+}  // namespace
+
+#define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
+                            int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, hipStream_t stream) {
+  MLA_CHECK_ARG(q && k && v && o && lse, "mla_attn_fwd: null pointer");
+  MLA_CHECK_ARG(head_dim == D, "mla_attn_fwd: head_dim must be 128 (got %d)", head_dim);
+  MLA_CHECK_ARG(AL16(q) && AL16(k) && AL16(v) && AL16(o), "mla_attn_fwd: 16-B alignment required");
+  AttnArgs p{};
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
+  p.seqlens = seqlens; p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
+  if (check_common(p, "mla_attn_fwd")) return -1;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); attr = true; }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, H, B), dim3(256), 4 * TILE_BYTES, stream, p);
+  MLA_LAUNCH_CHECK();
+}
+
+// delta: workspace [B,H,S] fp32 (caller-allocated)
+extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                            const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
+                            int head_dim, long long ld_qkv, long long ld_o, float scale, hipStream_t stream) {
+  MLA_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta, "mla_attn_bwd: null pointer");
+  MLA_CHECK_ARG(head_dim == D, "mla_attn_bwd: head_dim must be 128 (got %d)", head_dim);
+  MLA_CHECK_ARG(AL16(q) && AL16(k) && AL16(v) && AL16(o) && AL16(dout) && AL16(dq) && AL16(dk) && AL16(dv),
+                "mla_attn_bwd: 16-B alignment required");
+  AttnArgs p{};
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.lse = (float*)lse; p.seqlens = seqlens;
+  p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+  p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
+  if (check_common(p, "mla_attn_bwd")) return -1;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
+    attr = true;
+  }
+  const long long items = (long long)B * S * H * 16;
+  long long nb = (items + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((int)nb), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta, B, S, H, ld_o);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((S + 63) / 64, H, B), dim3(256), 4 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((S + 63) / 64, H, B), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
+  MLA_LAUNCH_CHECK();
+}

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libmla_hip.so for gfx950 (cross-compiles without a GPU). Usage: build.sh [outdir]
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="${1:-$HERE/..}"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result"
+mkdir -p "$HERE/build"
+pids=()
+for f in api gemm elementwise attention loss pointcloud vision; do
+  [ -f "$HERE/$f.hip" ] || continue
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmla_hip.so" "$HERE"/build/*.o
+echo "built $OUT/libmla_hip.so"

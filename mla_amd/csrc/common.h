@@ -1,0 +1,94 @@
+// Shared device/host helpers for libmla_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define MLA_GLOBAL_AS __attribute__((address_space(1)))
+#define MLA_LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16 cast)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// 64-lane wave reductions (xor butterflies; every lane ends with the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block reduction through LDS scratch (>= 16 floats). All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += scratch[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, scratch[i]);
+  return r;
+}
+
+// async global -> LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const MLA_GLOBAL_AS void*)gsrc, (MLA_LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS transpose read: 4 x b16 per lane (see DESIGN.md "tr16 semantics", verified by mla_selftest_tr16)
+__device__ __forceinline__ short4_t lds_tr16_b64(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((MLA_LDS_AS short4_t*)lds_addr);
+}
+
+// ---- host side error plumbing (see include/mla_hip.h) ----
+void mla_set_error(const char* fmt, ...);
+#define MLA_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      mla_set_error(__VA_ARGS__);                \
+      return -1;                                 \
+    }                                            \
+  } while (0)
+#define MLA_LAUNCH_CHECK()                                            \
+  do {                                                                \
+    hipError_t e__ = hipGetLastError();                               \
+    if (e__ != hipSuccess) {                                          \
+      mla_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return (int)e__;                                                \
+    }                                                                 \
+    return 0;                                                         \
+  } while (0)

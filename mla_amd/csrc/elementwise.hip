@@ -1,0 +1,620 @@
+// HBM-bound kernels of the decoder / heads: every kernel moves 16 B per lane per access (8 x bf16),
+// accumulates in fp32 and makes exactly one pass over its inputs (DESIGN.md "HBM-bound kernels").
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4_t& w, float* f) {
+  f[0] = bflo(w[0]); f[1] = bfhi(w[0]); f[2] = bflo(w[1]); f[3] = bfhi(w[1]);
+  f[4] = bflo(w[2]); f[5] = bfhi(w[2]); f[6] = bflo(w[3]); f[7] = bfhi(w[3]);
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  u32x4_t w;
+  w[0] = pack2bf(f[0], f[1]); w[1] = pack2bf(f[2], f[3]); w[2] = pack2bf(f[4], f[5]); w[3] = pack2bf(f[6], f[7]);
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RMSNorm  (reference: transformers/models/llama/modeling_llama.py:76-90; timm RmsNorm used by FinalLayer,
+// models/diffusion/models.py:177).  y = w * bf16(x * rsqrt(mean(x^2) + eps))  -- cast happens BEFORE the weight
+// multiply.  One 256-thread block per row, H <= 8192, H % 8 == 0.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int NORM_MAXC = 4;
+
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, float* __restrict__ rstd_out,
+                                                          int rows, int H, float eps) {
+  __shared__ float scratch[16];
+  const int row = blockIdx.x;
+  const int nchunk = H >> 3;
+  const bf16_t* xr = x + (size_t)row * H;
+  float xv[NORM_MAXC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      const u32x4_t v = *(const u32x4_t*)(xr + ch * 8);
+      unpack8(v, xv[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += xv[c][j] * xv[c][j];
+    }
+  }
+  ss = block_sum(ss, scratch);
+  const float rstd = 1.0f / sqrtf(ss / (float)H + eps);
+  if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      float wv[8], o[8];
+      unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = wv[j] * bf2f(f2bf(xv[c][j] * rstd));
+      *(u32x4_t*)(y + (size_t)row * H + ch * 8) = pack8(o);
+    }
+  }
+}
+
+// dx = dres + rstd * (dy*w - n * mean(dy*w*n)),  n = x*rstd ;  dw partial[blockIdx][h] = sum_rows dy*n
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w, const float* __restrict__ rstd,
+                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                          float* __restrict__ dw_partial, int rows, int H) {
+  __shared__ float scratch[16];
+  const int nchunk = H >> 3;
+  float wv[NORM_MAXC][8], dwacc[NORM_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwacc[c][j] = 0.f;
+    if (ch < nchunk) unpack8(*(const u32x4_t*)(w + ch * 8), wv[c]);
+  }
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float rs = rstd[row];
+    float nv[NORM_MAXC][8], dn[NORM_MAXC][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NORM_MAXC; ++c) {
+      const int ch = threadIdx.x + c * 256;
+      if (ch < nchunk) {
+        float xv[8], dyv[8];
+        unpack8(*(const u32x4_t*)(x + (size_t)row * H + ch * 8), xv);
+        unpack8(*(const u32x4_t*)(dy + (size_t)row * H + ch * 8), dyv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          nv[c][j] = xv[j] * rs;
+          dn[c][j] = dyv[j] * wv[c][j];
+          dot += dn[c][j] * nv[c][j];
+          dwacc[c][j] += dyv[j] * nv[c][j];
+        }
+      }
+    }
+    dot = block_sum(dot, scratch) / (float)H;
+#pragma unroll
+    for (int c = 0; c < NORM_MAXC; ++c) {
+      const int ch = threadIdx.x + c * 256;
+      if (ch < nchunk) {
+        float o[8];
+        if (dres) unpack8(*(const u32x4_t*)(dres + (size_t)row * H + ch * 8), o);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += rs * (dn[c][j] - nv[c][j] * dot);
+        *(u32x4_t*)(dx + (size_t)row * H + ch * 8) = pack8(o);
+      }
+    }
+  }
+  if (dw_partial) {
+#pragma unroll
+    for (int c = 0; c < NORM_MAXC; ++c) {
+      const int ch = threadIdx.x + c * 256;
+      if (ch < nchunk) {
+        float* o = dw_partial + (size_t)blockIdx.x * H + ch * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = dwacc[c][j];
+      }
+    }
+  }
+}
+
+// out[n] (+)= sum_p partial[p][n]   (deterministic second stage for dw / bias-grad reductions)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              int P, int N, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += partial[(size_t)p * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+// partial[blockIdx.y][n] = sum over this block's row slice of dy[r][n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ dy, float* __restrict__ partial,
+                                                             int rows, int N, int ld) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const int rs = gridDim.y;
+  const int per = (rows + rs - 1) / rs;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
+  float s = 0.f;
+  if (n < N)
+    for (int r = r0 + rl; r < r1; r += 4) s += bf2f(dy[(size_t)r * ld + n]);
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) partial[(size_t)blockIdx.y * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm forward (frozen vision tokenizer: models/mla/image/vision_tokenizer.py:21-24)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                            int rows, int H, float eps) {
+  __shared__ float scratch[16];
+  const int row = blockIdx.x;
+  const int nchunk = H >> 3;
+  float xv[NORM_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      unpack8(*(const u32x4_t*)(x + (size_t)row * H + ch * 8), xv[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xv[c][j];
+    }
+  }
+  const float mean = block_sum(s, scratch) / (float)H;
+  float vs = 0.f;
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xv[c][j] - mean; vs += d * d; }
+    }
+  }
+  const float var = block_sum(vs, scratch) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      float wv[8], bv[8], o[8];
+      unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+      unpack8(*(const u32x4_t*)(b + ch * 8), bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (xv[c][j] - mean) * rstd * wv[j] + bv[j];
+      *(u32x4_t*)(y + (size_t)row * H + ch * 8) = pack8(o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RoPE, half-split rotation, applied in place to the q and k slices of the packed qkv buffer
+// (reference: modeling_llama.py:96-145, 177-208; positions = arange(S) for every row, :985-990).
+// sign = +1 forward, -1 backward (the transpose of a rotation).  tab = [S][D/2] fp32 cos and sin.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ buf, const float* __restrict__ cos_t,
+                                                   const float* __restrict__ sin_t, long long tokens, int S, int nheads,
+                                                   int D, int ld, int q_off, int k_off, float sign) {
+  const int half = D >> 1, cpd = half >> 3;  // 16-B chunks per half head
+  const long long total = tokens * 2 * nheads * cpd;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int dc = (int)(idx % cpd);
+    long long r = idx / cpd;
+    const int h = (int)(r % nheads);
+    r /= nheads;
+    const int which = (int)(r & 1);
+    const long long t = r >> 1;
+    const int pos = (int)(t % S);
+    bf16_t* p = buf + t * ld + (which ? k_off : q_off) + h * D + dc * 8;
+    float a[8], b[8], c[8], s[8], oa[8], ob[8];
+    unpack8(*(const u32x4_t*)p, a);
+    unpack8(*(const u32x4_t*)(p + half), b);
+    const f32x4_t c0 = *(const f32x4_t*)(cos_t + (size_t)pos * half + dc * 8);
+    const f32x4_t c1 = *(const f32x4_t*)(cos_t + (size_t)pos * half + dc * 8 + 4);
+    const f32x4_t s0 = *(const f32x4_t*)(sin_t + (size_t)pos * half + dc * 8);
+    const f32x4_t s1 = *(const f32x4_t*)(sin_t + (size_t)pos * half + dc * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = c0[j]; c[j + 4] = c1[j]; s[j] = s0[j] * sign; s[j + 4] = s1[j] * sign; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      oa[j] = a[j] * c[j] - b[j] * s[j];
+      ob[j] = b[j] * c[j] + a[j] * s[j];
+    }
+    *(u32x4_t*)p = pack8(oa);
+    *(u32x4_t*)(p + half) = pack8(ob);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SwiGLU (reference: modeling_llama.py:211-242): act = silu(gate) * up, gate = gu[:, :I], up = gu[:, I:]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
+                                                         long long rows, int I) {
+  const int cpr = I >> 3;
+  const long long total = rows * cpr;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long r = idx / cpr;
+    const int c = (int)(idx % cpr);
+    float g[8], u[8], o[8];
+    unpack8(*(const u32x4_t*)(gu + r * 2 * I + c * 8), g);
+    unpack8(*(const u32x4_t*)(gu + r * 2 * I + I + c * 8), u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+    *(u32x4_t*)(act + r * I + c * 8) = pack8(o);
+  }
+}
+
+// dgu[:, :I] = dact * up * silu'(gate); dgu[:, I:] = dact * silu(gate); optionally re-materialises act.
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* __restrict__ gu,
+                                                         bf16_t* __restrict__ dgu, bf16_t* __restrict__ act_out,
+                                                         long long rows, int I) {
+  const int cpr = I >> 3;
+  const long long total = rows * cpr;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long r = idx / cpr;
+    const int c = (int)(idx % cpr);
+    float g[8], u[8], d[8], dg[8], du[8], a[8];
+    unpack8(*(const u32x4_t*)(gu + r * 2 * I + c * 8), g);
+    unpack8(*(const u32x4_t*)(gu + r * 2 * I + I + c * 8), u);
+    unpack8(*(const u32x4_t*)(dact + r * I + c * 8), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = 1.f / (1.f + __expf(-g[j]));
+      const float sl = g[j] * s;
+      dg[j] = d[j] * u[j] * (s + sl * (1.f - s));
+      du[j] = d[j] * sl;
+      a[j] = sl * u[j];
+    }
+    *(u32x4_t*)(dgu + r * 2 * I + c * 8) = pack8(dg);
+    *(u32x4_t*)(dgu + r * 2 * I + I + c * 8) = pack8(du);
+    if (act_out) *(u32x4_t*)(act_out + r * I + c * 8) = pack8(a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Activations of the small heads: 0 GELU(erf) (MLPProjector util/nn_utils.py:21-34, MLP_GELU), 1 GELU(tanh)
+// (timm Mlp in ActionEmbedder/FinalLayer, models/diffusion/models.py:112-123,173-189), 2 ReLU (contrastive heads,
+// models/mla/fuser/contrastive.py:173-183), 3 SiLU (TimestepEmbedder, models/diffusion/models.py:34-38).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_f(int kind, float x) {
+  switch (kind) {
+    case 0: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case 1: { const float t = tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)); return 0.5f * x * (1.f + t); }
+    case 2: return x > 0.f ? x : 0.f;
+    default: return x / (1.f + __expf(-x));
+  }
+}
+__device__ __forceinline__ float act_df(int kind, float x) {
+  switch (kind) {
+    case 0: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    case 1: {
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      const float t = tanhf(u);
+      return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
+    }
+    case 2: return x > 0.f ? 1.f : 0.f;
+    default: { const float s = 1.f / (1.f + __expf(-x)); return s + x * s * (1.f - s); }
+  }
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long n,
+                                                      int kind) {
+  const long long nch = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long long)gridDim.x * 256) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + i * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_f(kind, v[j]);
+    *(u32x4_t*)(y + i * 8) = pack8(v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long long i = (nch << 3) + threadIdx.x;
+    y[i] = f2bf(act_f(kind, bf2f(x[i])));
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                      bf16_t* __restrict__ dx, long long n, int kind) {
+  const long long nch = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long long)gridDim.x * 256) {
+    float v[8], d[8];
+    unpack8(*(const u32x4_t*)(x + i * 8), v);
+    unpack8(*(const u32x4_t*)(dy + i * 8), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] *= act_df(kind, v[j]);
+    *(u32x4_t*)(dx + i * 8) = pack8(d);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long long i = (nch << 3) + threadIdx.x;
+    dx[i] = f2bf(bf2f(dy[i]) * act_df(kind, bf2f(x[i])));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// casts, adds, embedding
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  const long long nch = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long long)gridDim.x * 256) {
+    const f32x4_t a = *(const f32x4_t*)(x + i * 8), b = *(const f32x4_t*)(x + i * 8 + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    *(u32x4_t*)(y + i * 8) = pack8(v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[(nch << 3) + threadIdx.x] = f2bf(x[(nch << 3) + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long nch = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long long)gridDim.x * 256) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + i * 8), v);
+    *(f32x4_t*)(y + i * 8) = f32x4_t{v[0], v[1], v[2], v[3]};
+    *(f32x4_t*)(y + i * 8 + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[(nch << 3) + threadIdx.x] = bf2f(x[(nch << 3) + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ y, long long n) {
+  const long long nch = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nch; i += (long long)gridDim.x * 256) {
+    float u[8], v[8];
+    unpack8(*(const u32x4_t*)(a + i * 8), u);
+    unpack8(*(const u32x4_t*)(b + i * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] += v[j];
+    *(u32x4_t*)(y + i * 8) = pack8(u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long long i = (nch << 3) + threadIdx.x;
+    y[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+  }
+}
+
+// out[t][:] = table[ids[t]][:]   (LlamaModel.embed_tokens, modeling_llama.py:975-976)
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ ids, const bf16_t* __restrict__ table,
+                                                            bf16_t* __restrict__ out, long long tokens, int H, int vocab) {
+  const int cpr = H >> 3;
+  const long long total = tokens * cpr;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long t = idx / cpr;
+    const int c = (int)(idx % cpr);
+    long long id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    *(u32x4_t*)(out + t * H + c * 8) = *(const u32x4_t*)(table + id * H + c * 8);
+  }
+}
+// grad[ids[t]][h] += dy[t][h], sequential over t for a fixed column -> deterministic without atomics
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const bf16_t* __restrict__ dy,
+                                                            float* __restrict__ grad, long long tokens, int H, int vocab) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  for (long long t = 0; t < tokens; ++t) {
+    const long long id = ids[t];
+    if (id < 0 || id >= vocab) continue;
+    grad[id * H + h] += bf2f(dy[t * H + h]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Optimizer: fused AdamW over the local fp32 shard, also refreshes the bf16 compute copy
+// (reference: torch.optim.AdamW built at training/strategies/fsdp.py:257; clip at :308-310)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p16, long long n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                                    const float* __restrict__ grad_scale) {
+  const float gs = grad_scale ? *grad_scale : 1.f;
+  const float step = lr / bc1, isq = 1.f / sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gg = g[i] * gs;
+    float pp = p[i] * (1.f - lr * wd);
+    const float mm = beta1 * m[i] + (1.f - beta1) * gg;
+    const float vv = beta2 * v[i] + (1.f - beta2) * gg * gg;
+    pp -= step * mm / (sqrtf(vv) * isq + eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (p16) p16[i] = f2bf(pp);
+  }
+}
+
+// partial[blockIdx] = sum of squares of this block's slice (deterministic two-stage grad-norm)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, long long n) {
+  __shared__ float scratch[16];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// out[0] (+)= sum(partial[0..P))
+__global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int P,
+                                                        int accumulate) {
+  __shared__ float scratch[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < P; i += 256) s += partial[i];
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+// coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); norm_out[0] = sqrt(sumsq[0])   (torch clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef,
+                                 float* __restrict__ norm_out) {
+  const float nrm = sqrtf(sumsq[0]);
+  const float c = max_norm / (nrm + 1e-6f);
+  coef[0] = c < 1.f ? c : 1.f;
+  if (norm_out) norm_out[0] = nrm;
+}
+
+// x_t = sqrt_ac[t]*x0 + sqrt_1mac[t]*noise   (GaussianDiffusion.q_sample, models/diffusion/gaussian_diffusion.py:214-229)
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const long long* __restrict__ t, const float* __restrict__ sqrt_ac,
+                                                       const float* __restrict__ sqrt_1mac, float* __restrict__ out,
+                                                       int batch, int per, int nsteps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= batch * per) return;
+  long long tt = t[i / per];
+  tt = tt < 0 ? 0 : (tt >= nsteps ? nsteps - 1 : tt);
+  out[i] = sqrt_ac[tt] * x0[i] + sqrt_1mac[tt] * noise[i];
+}
+
+inline int grid_for(long long work_items, int cap = 4096) {
+  long long b = (work_items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+#define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+extern "C" int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int H, float eps,
+                               hipStream_t stream) {
+  MLA_CHECK_ARG(x && w && y, "mla_rmsnorm_fwd: null pointer");
+  MLA_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 8192, "mla_rmsnorm_fwd: need H%%8==0, H<=8192 (H=%d)", H);
+  MLA_CHECK_ARG(AL16(x) && AL16(w) && AL16(y), "mla_rmsnorm_fwd: pointers must be 16-B aligned");
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
+                     rstd, rows, H, eps);
+  MLA_LAUNCH_CHECK();
+}
+
+// workspace: nblocks*H floats (nblocks = mla_rmsnorm_bwd_blocks(rows)); dw may be null (frozen weight)
+extern "C" int mla_rmsnorm_bwd_blocks(int rows) { return rows < 512 ? rows : 512; }
+extern "C" int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                               float* dw, int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes,
+                               hipStream_t stream) {
+  MLA_CHECK_ARG(dy && x && w && rstd && dx, "mla_rmsnorm_bwd: null pointer");
+  MLA_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 8192, "mla_rmsnorm_bwd: need H%%8==0, H<=8192 (H=%d)", H);
+  const int nb = mla_rmsnorm_bwd_blocks(rows);
+  MLA_CHECK_ARG(!dw || (workspace && workspace_bytes >= (size_t)nb * H * sizeof(float)), "mla_rmsnorm_bwd: workspace too small");
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
+  if (dw)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_colsum_blocks(int rows) { int r = rows / 256; return r < 1 ? 1 : (r > 64 ? 64 : r); }
+// out[n] (+)= sum_r dy[r][n];  workspace: mla_colsum_blocks(rows)*N floats
+extern "C" int mla_colsum_bf16(const void* dy, float* out, int accumulate, int rows, int N, int ld, float* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
+  MLA_CHECK_ARG(dy && out && workspace, "mla_colsum_bf16: null pointer");
+  const int rs = mla_colsum_blocks(rows);
+  MLA_CHECK_ARG(workspace_bytes >= (size_t)rs * N * sizeof(float), "mla_colsum_bf16: workspace too small");
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, (const bf16_t*)dy, workspace, rows, N, ld);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, workspace, out, rs, N, accumulate);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int H, float eps,
+                                 hipStream_t stream) {
+  MLA_CHECK_ARG(x && w && b && y, "mla_layernorm_fwd: null pointer");
+  MLA_CHECK_ARG(rows > 0 && H % 8 == 0 && H <= 8192, "mla_layernorm_fwd: need H%%8==0, H<=8192");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)w,
+                     (const bf16_t*)b, (bf16_t*)y, rows, H, eps);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_rope_inplace(void* buf, const float* cos_t, const float* sin_t, long long tokens, int S, int nheads,
+                                int D, int ld, int q_off, int k_off, int backward, hipStream_t stream) {
+  MLA_CHECK_ARG(buf && cos_t && sin_t, "mla_rope_inplace: null pointer");
+  MLA_CHECK_ARG(D % 16 == 0 && ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && S > 0, "mla_rope_inplace: bad layout");
+  MLA_CHECK_ARG(AL16(buf) && AL16(cos_t) && AL16(sin_t), "mla_rope_inplace: alignment");
+  const long long total = tokens * 2 * nheads * (D / 16);
+  hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, stream, (bf16_t*)buf, cos_t, sin_t, tokens, S,
+                     nheads, D, ld, q_off, k_off, backward ? -1.f : 1.f);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_swiglu_fwd(const void* gu, void* act, long long rows, int I, hipStream_t stream) {
+  MLA_CHECK_ARG(gu && act && I % 8 == 0, "mla_swiglu_fwd: bad args");
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (I / 8), 8192)), dim3(256), 0, stream, (const bf16_t*)gu,
+                     (bf16_t*)act, rows, I);
+  MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_swiglu_bwd(const void* dact, const void* gu, void* dgu, void* act_out, long long rows, int I,
+                              hipStream_t stream) {
+  MLA_CHECK_ARG(dact && gu && dgu && I % 8 == 0, "mla_swiglu_bwd: bad args");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (I / 8), 8192)), dim3(256), 0, stream, (const bf16_t*)dact,
+                     (const bf16_t*)gu, (bf16_t*)dgu, (bf16_t*)act_out, rows, I);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_act_fwd(const void* x, void* y, long long n, int kind, hipStream_t stream) {
+  MLA_CHECK_ARG(x && y && kind >= 0 && kind <= 3 && AL16(x) && AL16(y), "mla_act_fwd: bad args");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n, kind);
+  MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_act_bwd(const void* dy, const void* x, void* dx, long long n, int kind, hipStream_t stream) {
+  MLA_CHECK_ARG(dy && x && dx && kind >= 0 && kind <= 3 && AL16(x) && AL16(dy) && AL16(dx), "mla_act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
+                     (bf16_t*)dx, n, kind);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_cast_f32_to_bf16(const float* x, void* y, long long n, hipStream_t stream) {
+  MLA_CHECK_ARG(x && y && AL16(x) && AL16(y), "mla_cast_f32_to_bf16: bad args");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, x, (bf16_t*)y, n);
+  MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_cast_bf16_to_f32(const void* x, float* y, long long n, hipStream_t stream) {
+  MLA_CHECK_ARG(x && y && AL16(x) && AL16(y), "mla_cast_bf16_to_f32: bad args");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16_t*)x, y, n);
+  MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_add_bf16(const void* a, const void* b, void* y, long long n, hipStream_t stream) {
+  MLA_CHECK_ARG(a && b && y && AL16(a) && AL16(b) && AL16(y), "mla_add_bf16: bad args");
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b,
+                     (bf16_t*)y, n);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_embedding_fwd(const long long* ids, const void* table, void* out, long long tokens, int H, int vocab,
+                                 hipStream_t stream) {
+  MLA_CHECK_ARG(ids && table && out && H % 8 == 0, "mla_embedding_fwd: bad args");
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(tokens * (H / 8))), dim3(256), 0, stream, ids, (const bf16_t*)table,
+                     (bf16_t*)out, tokens, H, vocab);
+  MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_embedding_bwd(const long long* ids, const void* dy, float* grad, long long tokens, int H, int vocab,
+                                 hipStream_t stream) {
+  MLA_CHECK_ARG(ids && dy && grad, "mla_embedding_bwd: bad args");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, ids, (const bf16_t*)dy, grad, tokens, H, vocab);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long long n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, const float* grad_scale,
+                              hipStream_t stream) {
+  MLA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "mla_adamw_step: bad args");
+  if (n == 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p16, n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2, grad_scale);
+  MLA_LAUNCH_CHECK();
+}
+
+// out[0] (+)= sum(x^2); workspace >= 1024 floats
+extern "C" int mla_sumsq_f32(const float* x, long long n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
+  MLA_CHECK_ARG(x && out && workspace && workspace_bytes >= 1024 * sizeof(float), "mla_sumsq_f32: bad args");
+  const int nb = grid_for(n, 1024);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, x, workspace, n);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, stream, workspace, out, nb, accumulate);
+  MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, hipStream_t stream) {
+  MLA_CHECK_ARG(sumsq && coef, "mla_clip_coef: bad args");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, max_norm, coef, norm_out);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
+                            const float* sqrt_1mac, float* out, int batch, int per, int nsteps, hipStream_t stream) {
+  MLA_CHECK_ARG(x0 && noise && t && sqrt_ac && sqrt_1mac && out, "mla_q_sample: null pointer");
+  hipLaunchKernelGGL(q_sample_kernel, dim3((batch * per + 255) / 256), dim3(256), 0, stream, x0, noise, t, sqrt_ac, sqrt_1mac,
+                     out, batch, per, nsteps);
+  MLA_LAUNCH_CHECK();
+}

@@ -1,0 +1,365 @@
+"""ctypes binding of libmla_hip.so (C-ABI declared in include/mla_hip.h).
+
+Every wrapper launches on torch's current HIP stream, never synchronises, and raises RuntimeError on a
+non-zero return code. There is deliberately NO fallback: if the shared library is missing or a kernel rejects its
+arguments the product path fails loudly (oracle/ is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmla_hip.so")
+_lib = None
+
+ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_SILU = 0, 1, 2, 3
+
+# name -> argtypes (restype is always int unless noted) -- mirrors include/mla_hip.h
+_SIGNATURES = {
+    "mla_query": [c_int],
+    "mla_selftest": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "mla_gemm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                      c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
+    "mla_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "mla_rmsnorm_bwd_blocks": [c_int],
+    "mla_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                        c_size_t, c_void_p],
+    "mla_colsum_blocks": [c_int],
+    "mla_colsum_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    "mla_layernorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "mla_rope_inplace": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mla_swiglu_fwd": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "mla_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "mla_act_fwd": [c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "mla_act_bwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p],
+    "mla_cast_f32_to_bf16": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "mla_cast_bf16_to_f32": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "mla_add_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
+    "mla_embedding_fwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+    "mla_embedding_bwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+    "mla_adamw_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
+                       c_float, c_int, c_void_p, c_void_p],
+    "mla_sumsq_f32": [c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
+    "mla_clip_coef": [c_void_p, c_float, c_void_p, c_void_p, c_void_p],
+    "mla_q_sample": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mla_attn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong,
+                     c_longlong, c_float, c_void_p],
+    "mla_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                     c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p],
+    "mla_ce_fwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p],
+    "mla_ce_bwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong, c_int, c_int,
+                   c_longlong, c_void_p],
+    "mla_infonce_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mla_l2norm_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "mla_l2norm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+}
+
+
+def exported_symbols():
+    """Names every build of libmla_hip.so must export (checked by the CPU test-suite)."""
+    return sorted(list(_SIGNATURES.keys()) + ["mla_last_error"] + list(_EXTRA_SIGNATURES.keys()))
+
+
+_EXTRA_SIGNATURES = {}  # filled by optional kernel groups (pointcloud / vision) below
+
+
+def register_signatures(sigs):
+    _EXTRA_SIGNATURES.update(sigs)
+    global _lib
+    if _lib is not None:
+        for name, argt in sigs.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argt
+            fn.restype = c_int
+
+
+def lib():
+    """Load the shared library (once). Raises if it is absent -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(mla_amd has no CPU fallback)")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.mla_last_error.restype = ctypes.c_char_p
+        L.mla_last_error.argtypes = []
+        for name, argt in {**_SIGNATURES, **_EXTRA_SIGNATURES}.items():
+            fn = getattr(L, name)
+            fn.argtypes = argt
+            fn.restype = c_int
+        _lib = L
+    return _lib
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib().mla_last_error().decode()}")
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must live on the GPU (mla_amd has no CPU path)")
+
+
+def call(name: str, *args):
+    """Raw call helper: appends the current stream and checks the return code."""
+    rc = getattr(lib(), name)(*args, _stream())
+    _check(rc, name)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Per-(device, stream) scratch buffer owned by torch (kernels never allocate)."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 24), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, a_mode: int = 0, b_mode: int = 0,
+         M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None, lda: Optional[int] = None,
+         ldb: Optional[int] = None, ldc: Optional[int] = None, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None, out_dtype=torch.bfloat16,
+         accumulate: bool = False, alpha: float = 1.0, force_generic: bool = False) -> torch.Tensor:
+    """C[M,N] = alpha * sum_k Aop(m,k) Bop(n,k) (+bias[n]) (+residual[m,n]) (+C if accumulate).
+
+    a_mode/b_mode 0: operand stored [rows, K] (k contiguous); 1: stored [K, rows] (reduction-major).
+    2-D tensors with unit inner stride; leading dimension taken from stride(0).
+    """
+    _req(a, torch.bfloat16, "gemm a")
+    _req(b, torch.bfloat16, "gemm b")
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    if M is None:
+        M = a.shape[0] if a_mode == 0 else a.shape[1]
+    if K is None:
+        K = a.shape[1] if a_mode == 0 else a.shape[0]
+    if N is None:
+        N = b.shape[0] if b_mode == 0 else b.shape[1]
+    kb = b.shape[1] if b_mode == 0 else b.shape[0]
+    if kb != K:
+        raise ValueError(f"gemm: reduction mismatch {K} vs {kb}")
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(-1) == 1
+    out_fp32 = 1 if out.dtype == torch.float32 else 0
+    if not out_fp32:
+        _req(out, torch.bfloat16, "gemm out")
+    ldc = out.stride(0) if ldc is None else ldc
+    if residual is not None:
+        _req(residual, torch.bfloat16, "gemm residual")
+        ldr = residual.stride(0) if ldr is None else ldr
+    if bias is not None:
+        _req(bias, torch.bfloat16, "gemm bias")
+    call("mla_gemm_bf16", _p(a), _p(b), _p(out), _p(residual), _p(bias), M, N, K, lda, ldb, ldc, ldr or 0, a_mode, b_mode,
+         out_fp32, 1 if accumulate else 0, float(alpha), 1 if force_generic else 0)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- norms
+def rmsnorm_fwd(x2d, w, eps):
+    _req(x2d, torch.bfloat16, "rmsnorm x")
+    _req(w, torch.bfloat16, "rmsnorm w")
+    rows, H = x2d.shape
+    y = torch.empty_like(x2d)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    call("mla_rmsnorm_fwd", _p(x2d), _p(w), _p(y), _p(rstd), rows, H, float(eps))
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x2d, w, rstd, dres=None, dw_out=None, dw_accumulate=False):
+    rows, H = x2d.shape
+    dx = torch.empty_like(x2d)
+    nb = lib().mla_rmsnorm_bwd_blocks(rows)
+    ws = workspace(nb * H * 4, x2d.device) if dw_out is not None else None
+    call("mla_rmsnorm_bwd", _p(dy), _p(x2d), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw_out), 1 if dw_accumulate else 0, rows, H,
+         _p(ws), ws.numel() if ws is not None else 0)
+    return dx
+
+
+def colsum(dy2d, out_f32, accumulate):
+    rows, N = dy2d.shape
+    rs = lib().mla_colsum_blocks(rows)
+    ws = workspace(rs * N * 4, dy2d.device)
+    call("mla_colsum_bf16", _p(dy2d), _p(out_f32), 1 if accumulate else 0, rows, N, dy2d.stride(0), _p(ws), ws.numel())
+
+
+def layernorm_fwd(x2d, w, b, eps):
+    rows, H = x2d.shape
+    y = torch.empty_like(x2d)
+    call("mla_layernorm_fwd", _p(x2d), _p(w), _p(b), _p(y), rows, H, float(eps))
+    return y
+
+
+def rope_inplace(buf2d, cos, sin, S, nheads, D, q_off, k_off, backward=False):
+    tokens = buf2d.shape[0]
+    call("mla_rope_inplace", _p(buf2d), _p(cos), _p(sin), tokens, S, nheads, D, buf2d.stride(0), q_off, k_off,
+         1 if backward else 0)
+
+
+def swiglu_fwd(gu2d):
+    rows, two_i = gu2d.shape
+    act = torch.empty((rows, two_i // 2), dtype=torch.bfloat16, device=gu2d.device)
+    call("mla_swiglu_fwd", _p(gu2d), _p(act), rows, two_i // 2)
+    return act
+
+
+def swiglu_bwd(dact, gu2d, want_act=False):
+    rows, two_i = gu2d.shape
+    dgu = torch.empty_like(gu2d)
+    act = torch.empty_like(dact) if want_act else None
+    call("mla_swiglu_bwd", _p(dact), _p(gu2d), _p(dgu), _p(act), rows, two_i // 2)
+    return dgu, act
+
+
+def act_fwd(x, kind):
+    y = torch.empty_like(x)
+    call("mla_act_fwd", _p(x), _p(y), x.numel(), kind)
+    return y
+
+
+def act_bwd(dy, x, kind):
+    dx = torch.empty_like(x)
+    call("mla_act_bwd", _p(dy), _p(x), _p(dx), x.numel(), kind)
+    return dx
+
+
+def cast_f32_to_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("mla_cast_f32_to_bf16", _p(x), _p(out), x.numel())
+    return out
+
+
+def cast_bf16_to_f32(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("mla_cast_bf16_to_f32", _p(x), _p(out), x.numel())
+    return out
+
+
+def add_bf16(a, b):
+    y = torch.empty_like(a)
+    call("mla_add_bf16", _p(a), _p(b), _p(y), a.numel())
+    return y
+
+
+def embedding_fwd(ids, table):
+    tokens = ids.numel()
+    vocab, H = table.shape
+    out = torch.empty((tokens, H), dtype=torch.bfloat16, device=table.device)
+    call("mla_embedding_fwd", _p(ids), _p(table), _p(out), tokens, H, vocab)
+    return out
+
+
+def embedding_bwd(ids, dy2d, grad_f32):
+    vocab, H = grad_f32.shape
+    call("mla_embedding_bwd", _p(ids), _p(dy2d), _p(grad_f32), ids.numel(), H, vocab)
+
+
+def adamw_step(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    call("mla_adamw_step", _p(p32), _p(g32), _p(m), _p(v), _p(p16), p32.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), float(wd), int(step), _p(grad_scale))
+
+
+def sumsq(x32, out1, accumulate):
+    ws = workspace(4096, x32.device)
+    call("mla_sumsq_f32", _p(x32), x32.numel(), _p(out1), 1 if accumulate else 0, _p(ws), ws.numel())
+
+
+def clip_coef(sumsq1, max_norm, coef1, norm1=None):
+    call("mla_clip_coef", _p(sumsq1), float(max_norm), _p(coef1), _p(norm1))
+
+
+def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
+    out = torch.empty_like(x0)
+    batch = x0.shape[0]
+    call("mla_q_sample", _p(x0), _p(noise), _p(t), _p(sqrt_ac), _p(sqrt_1mac), _p(out), batch, x0.numel() // batch,
+         sqrt_ac.numel())
+    return out
+
+
+# --------------------------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale):
+    """q/k/v: views into the packed [B*S, 3*H*D] buffer (first element of each slice)."""
+    o = torch.empty((B * S, H * D), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    call("mla_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale))
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale):
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    call("mla_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
+         H, D, ld_qkv, H * D, float(scale))
+
+
+# --------------------------------------------------------------------------------------------- losses
+def ce_fwd(logits2d, labels, ncols=None, ignore_index=-100, want_loss=True):
+    rows = logits2d.shape[0]
+    ncols = logits2d.shape[1] if ncols is None else ncols
+    loss = torch.empty(rows, dtype=torch.float32, device=logits2d.device) if want_loss else None
+    lse = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+    call("mla_ce_fwd", _p(logits2d), 1 if logits2d.dtype == torch.float32 else 0, logits2d.stride(0), _p(labels), _p(loss),
+         _p(lse), rows, ncols, ignore_index)
+    return loss, lse
+
+
+def ce_bwd(logits2d, labels, lse, gscale1, inv_count, ncols=None, ignore_index=-100):
+    rows = logits2d.shape[0]
+    ncols = logits2d.shape[1] if ncols is None else ncols
+    d = torch.zeros(logits2d.shape, dtype=torch.bfloat16, device=logits2d.device)
+    call("mla_ce_bwd", _p(logits2d), 1 if logits2d.dtype == torch.float32 else 0, logits2d.stride(0), _p(labels), _p(lse),
+         _p(gscale1), float(inv_count), _p(d), d.stride(0), rows, ncols, ignore_index)
+    return d
+
+
+def infonce_bwd(L, rlse, clse, gscale1, M):
+    Mp = L.shape[0]
+    dL = torch.empty((Mp, Mp), dtype=torch.bfloat16, device=L.device)
+    call("mla_infonce_bwd", _p(L), _p(rlse), _p(clse), _p(gscale1), _p(dL), M, Mp)
+    return dL
+
+
+def l2norm_fwd(x2d, eps=1e-12):
+    rows, n = x2d.shape
+    y = torch.empty_like(x2d)
+    norms = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    call("mla_l2norm_fwd", _p(x2d), _p(y), _p(norms), rows, n, float(eps))
+    return y, norms
+
+
+def l2norm_bwd(dy, y, norms):
+    rows, n = y.shape
+    dx = torch.empty_like(y)
+    call("mla_l2norm_bwd", _p(dy), _p(y), _p(norms), _p(dx), rows, n)
+    return dx
+
+
+def selftest(device="cuda"):
+    src = torch.arange(256, dtype=torch.int32, device=device) * 7 + 3
+    out_tr = torch.zeros(256, dtype=torch.int32, device=device)
+    out_g = torch.zeros(256, dtype=torch.int32, device=device)
+    call("mla_selftest", _p(src), _p(out_tr), _p(out_g))
+    return src, out_tr, out_g

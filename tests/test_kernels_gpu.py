@@ -1,0 +1,261 @@
+"""GPU parity: every HIP kernel vs the CPU oracle (oracle/torch_oracle.py) on the same seeded, bf16-rounded inputs.
+Tolerances: bf16 outputs -> Frobenius-relative <= 4e-3 (one bf16 rounding = 2^-9) and max-relative <= 2e-2;
+fp32 outputs -> <= 2e-4. Integer outputs exact."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import fro_rel, max_rel
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def bfr(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def test_selftest_hw_assumptions(dev):
+    from mla_amd import hip
+    src, out_tr, out_g = hip.selftest(dev)
+    out_tr = out_tr.cpu().view(64, 4)
+    exp = torch.tensor([[(l >> 4) * 64 + j * 16 + (l & 15) for j in range(4)] for l in range(64)], dtype=torch.int32)
+    assert torch.equal(out_tr, exp), f"ds_read_b64_tr_b16 mapping differs:\n{out_tr.tolist()}"
+    assert torch.equal(out_g.cpu(), src.cpu()), "global_load_lds destination is not lane-linear"
+
+
+@pytest.mark.parametrize("am,bm", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 136, 96), (1000, 520, 1056), (16, 4096, 256)])
+def test_gemm_modes(dev, am, bm, M, N, K):
+    from mla_amd import hip
+    a = bfr(M, K, seed=1) if am == 0 else bfr(K, M, seed=1)
+    b = bfr(N, K, seed=2) if bm == 0 else bfr(K, N, seed=2)
+    A = a.float() if am == 0 else a.float().t()
+    B = b.float() if bm == 0 else b.float().t()
+    ref = A @ B.t()
+    out = hip.gemm(a.to(dev), b.to(dev), a_mode=am, b_mode=bm)
+    assert fro_rel(out, ref) < 4e-3 and max_rel(out, ref) < 2e-2
+    out32 = hip.gemm(a.to(dev), b.to(dev), a_mode=am, b_mode=bm, out_dtype=torch.float32)
+    assert fro_rel(out32, ref) < 2e-4
+
+
+def test_gemm_epilogues(dev):
+    from mla_amd import hip
+    M, N, K = 300, 264, 160
+    a, b = bfr(M, K, seed=3), bfr(N, K, seed=4)
+    bias, res = bfr(N, seed=5), bfr(M, N, seed=6)
+    ref = 0.5 * (a.float() @ b.float().t()) + bias.float() + res.float()
+    out = hip.gemm(a.to(dev), b.to(dev), bias=bias.to(dev), residual=res.to(dev), alpha=0.5)
+    assert fro_rel(out, ref) < 4e-3
+    acc = torch.full((M, N), 2.0, dtype=torch.float32, device=dev)
+    hip.gemm(a.to(dev), b.to(dev), out=acc, accumulate=True)
+    assert fro_rel(acc, a.float() @ b.float().t() + 2.0) < 2e-4
+    # strided output slice (fused qkv style): write into columns [N:2N] of a wider buffer
+    wide = torch.zeros((M, 3 * N), dtype=BF, device=dev)
+    hip.gemm(a.to(dev), b.to(dev), out=wide[:, N:2 * N])
+    assert fro_rel(wide[:, N:2 * N], a.float() @ b.float().t()) < 4e-3
+    assert float(wide[:, :N].float().abs().max()) == 0.0 and float(wide[:, 2 * N:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,am,bm", [(32, 7, 4096, 0, 0), (32, 4096, 7, 0, 0), (32, 4096, 7, 0, 1), (7, 4096, 32, 1, 1),
+                                          (50, 30, 20, 1, 0)])
+def test_gemm_generic_fallback(dev, M, N, K, am, bm):
+    from mla_amd import hip
+    a = bfr(M, K, seed=1) if am == 0 else bfr(K, M, seed=1)
+    b = bfr(N, K, seed=2) if bm == 0 else bfr(K, N, seed=2)
+    A = a.float() if am == 0 else a.float().t()
+    B = b.float() if bm == 0 else b.float().t()
+    bias = bfr(N, seed=9)
+    ref = A @ B.t() + bias.float()
+    out = hip.gemm(a.to(dev), b.to(dev), a_mode=am, b_mode=bm, bias=bias.to(dev), out_dtype=torch.float32)
+    assert fro_rel(out, ref) < 2e-4
+    out2 = hip.gemm(a.to(dev), b.to(dev), a_mode=am, b_mode=bm, bias=bias.to(dev), force_generic=True)
+    assert fro_rel(out2, ref) < 4e-3
+
+
+@pytest.mark.parametrize("rows,H", [(37, 4096), (5, 128), (64, 1024)])
+def test_rmsnorm(dev, rows, H):
+    from mla_amd import hip
+    x, w = bfr(rows, H, seed=1), (1 + 0.1 * torch.randn(H, generator=torch.Generator().manual_seed(2))).to(BF)
+    y, rstd = hip.rmsnorm_fwd(x.to(dev), w.to(dev), 1e-5)
+    ref = O.rmsnorm(x, w, 1e-5)  # bf16 semantics of the reference
+    assert max_rel(y, ref) < 1e-2 and fro_rel(y, ref) < 3e-3
+    # backward vs fp32 autograd of the same function
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    dy, dres = bfr(rows, H, seed=3), bfr(rows, H, seed=4)
+    O.rmsnorm(xf, wf, 1e-5).backward(dy.float())
+    dw = torch.zeros(H, dtype=torch.float32, device=dev)
+    dx = hip.rmsnorm_bwd(dy.to(dev), x.to(dev), w.to(dev), rstd, dres=dres.to(dev), dw_out=dw)
+    assert fro_rel(dx, xf.grad + dres.float()) < 4e-3
+    assert fro_rel(dw, wf.grad) < 1e-3
+
+
+def test_rope_roundtrip_and_oracle(dev):
+    from mla_amd import hip
+    B, S, H, D = 2, 37, 4, 128
+    qkv = bfr(B * S, 3 * H * D, seed=1)
+    cos, sin = O.rope_tables(S, D)
+    buf = qkv.clone().to(dev)
+    hip.rope_inplace(buf, cos.to(dev), sin.to(dev), S, H, D, 0, H * D)
+    q = qkv[:, :H * D].float().view(B, S, H, D).transpose(1, 2)
+    k = qkv[:, H * D:2 * H * D].float().view(B, S, H, D).transpose(1, 2)
+    qr, kr = O.apply_rope(q, k, cos, sin)
+    got_q = buf[:, :H * D].float().cpu().view(B, S, H, D).transpose(1, 2)
+    got_k = buf[:, H * D:2 * H * D].float().cpu().view(B, S, H, D).transpose(1, 2)
+    assert fro_rel(got_q, qr) < 4e-3 and fro_rel(got_k, kr) < 4e-3
+    assert torch.equal(buf[:, 2 * H * D:].cpu(), qkv[:, 2 * H * D:])  # v untouched
+    hip.rope_inplace(buf, cos.to(dev), sin.to(dev), S, H, D, 0, H * D, backward=True)
+    assert fro_rel(buf, qkv) < 6e-3  # rotation followed by its transpose
+
+
+def test_swiglu_and_acts(dev):
+    from mla_amd import hip
+    rows, I = 33, 11008
+    gu = bfr(rows, 2 * I, seed=1)
+    act = hip.swiglu_fwd(gu.to(dev))
+    g, u = gu[:, :I].float().requires_grad_(True), gu[:, I:].float().requires_grad_(True)
+    ref = F.silu(g) * u
+    assert fro_rel(act, ref) < 4e-3
+    d = bfr(rows, I, seed=2)
+    ref.backward(d.float())
+    dgu, act2 = hip.swiglu_bwd(d.to(dev), gu.to(dev), want_act=True)
+    assert fro_rel(dgu[:, :I], g.grad) < 4e-3 and fro_rel(dgu[:, I:], u.grad) < 4e-3
+    assert torch.equal(act2.cpu(), act.cpu())
+    x = bfr(1000, 7, seed=5, scale=2.0).contiguous()
+    fns = {0: lambda t: F.gelu(t), 1: lambda t: F.gelu(t, approximate="tanh"), 2: F.relu, 3: F.silu}
+    for kind, fn in fns.items():
+        xf = x.float().requires_grad_(True)
+        yr = fn(xf)
+        yr.backward(torch.ones_like(yr))
+        y = hip.act_fwd(x.to(dev), kind)
+        dx = hip.act_bwd(torch.ones_like(x).to(dev), x.to(dev), kind)
+        assert fro_rel(y, yr) < 4e-3, kind
+        assert fro_rel(dx, xf.grad) < 5e-3, kind
+
+
+@pytest.mark.parametrize("B,S,H,lens", [(2, 64, 2, None), (2, 100, 2, None), (2, 100, 3, [70, 100]), (1, 548, 2, None),
+                                         (3, 200, 1, [1, 129, 64])])
+def test_attention_fwd_bwd(dev, B, S, H, lens):
+    from mla_amd import hip
+    D = 128
+    qkv = bfr(B * S, 3 * H * D, seed=11, scale=0.7)
+    do = bfr(B * S, H * D, seed=12)
+    seqlens = torch.tensor(lens, dtype=torch.int32) if lens else None
+    dq = qkv.to(dev)
+    q, k, v = dq[:, :H * D], dq[:, H * D:2 * H * D], dq[:, 2 * H * D:]
+    sl_dev = seqlens.to(dev) if seqlens is not None else None
+    o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, sl_dev, 1 / math.sqrt(D))
+    qf = qkv[:, :H * D].float().view(B, S, H, D).transpose(1, 2).requires_grad_(True)
+    kf = qkv[:, H * D:2 * H * D].float().view(B, S, H, D).transpose(1, 2).requires_grad_(True)
+    vf = qkv[:, 2 * H * D:].float().view(B, S, H, D).transpose(1, 2).requires_grad_(True)
+    ref = O.causal_attention(qf, kf, vf, seqlens.long() if seqlens is not None else None)
+    ref2d = ref.transpose(1, 2).reshape(B * S, H * D)
+    assert fro_rel(o, ref2d) < 5e-3 and max_rel(o, ref2d) < 3e-2
+    ref2d.backward(do.float())
+    dqkv = torch.full_like(dq, float("nan"))
+    hip.attn_bwd(q, k, v, o, do.to(dev), lse, sl_dev, dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:], B, S, H, D,
+                 3 * H * D, 1 / math.sqrt(D))
+    gq = qf.grad.transpose(1, 2).reshape(B * S, H * D)
+    gk = kf.grad.transpose(1, 2).reshape(B * S, H * D)
+    gv = vf.grad.transpose(1, 2).reshape(B * S, H * D)
+    assert torch.isfinite(dqkv.float()).all()
+    assert fro_rel(dqkv[:, :H * D], gq) < 1e-2
+    assert fro_rel(dqkv[:, H * D:2 * H * D], gk) < 1e-2
+    assert fro_rel(dqkv[:, 2 * H * D:], gv) < 1e-2
+    if seqlens is not None:  # pad rows: zero output and zero dq (flash/varlen semantics)
+        for b_ in range(B):
+            rows = slice(b_ * S + int(seqlens[b_]), (b_ + 1) * S)
+            assert float(o[rows].float().abs().max() if int(seqlens[b_]) < S else 0.0) == 0.0
+            assert float(dqkv[rows].float().abs().max() if int(seqlens[b_]) < S else 0.0) == 0.0
+
+
+def test_ce_and_l2norm_and_infonce(dev):
+    from mla_amd import hip
+    rows, V = 50, 32064
+    logits = bfr(rows, V, seed=1, scale=3.0)
+    labels = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(2))
+    labels[::7] = -100
+    loss, lse = hip.ce_fwd(logits.to(dev), labels.to(dev))
+    ref = F.cross_entropy(logits.float(), labels, ignore_index=-100, reduction="none")
+    assert fro_rel(loss, ref) < 1e-5
+    x = bfr(100, 256, seed=3)
+    y, nrm = hip.l2norm_fwd(x.to(dev))
+    xf = x.float().requires_grad_(True)
+    yr = F.normalize(xf, p=2, dim=-1)
+    assert fro_rel(y, yr) < 4e-3
+    dy = bfr(100, 256, seed=4)
+    yr.backward(dy.float())
+    dx = hip.l2norm_bwd(dy.to(dev), y, nrm)
+    assert fro_rel(dx, xf.grad) < 1e-2
+    # InfoNCE gradient on a padded logits matrix
+    M, Mp = 100, 128
+    L = torch.zeros(Mp, Mp)
+    L[:M, :M] = torch.randn(M, M, generator=torch.Generator().manual_seed(5)) * 4
+    Lr = L[:M, :M].clone().requires_grad_(True)
+    lab = torch.arange(M)
+    lr = (F.cross_entropy(Lr, lab) + F.cross_entropy(Lr.t(), lab)) / 2
+    lr.backward()
+    Ld = L.to(dev)
+    _, rl = hip.ce_fwd(Ld[:M], None, ncols=M, want_loss=False)
+    _, cl = hip.ce_fwd(Ld.t().contiguous()[:M], None, ncols=M, want_loss=False)
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dL = hip.infonce_bwd(Ld, rl, cl, one, M)
+    assert fro_rel(dL[:M, :M], Lr.grad) < 5e-3
+    assert float(dL[M:].float().abs().max()) == 0.0 and float(dL[:, M:].float().abs().max()) == 0.0
+
+
+def test_adamw_embedding_misc(dev):
+    from mla_amd import hip
+    n = 100003
+    g = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    pd, md, vd = p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    p16 = torch.zeros(n, dtype=BF, device=dev)
+    for step in range(1, 4):
+        ref_p.grad = gr * step
+        opt.step()
+        hip.adamw_step(pd, (gr * step).to(dev), md, vd, p16, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+    assert fro_rel(pd, ref_p) < 1e-5
+    assert torch.equal(p16.cpu(), pd.cpu().to(BF))
+    s = torch.zeros(1, device=dev)
+    hip.sumsq(pd, s, False)
+    assert abs(float(s) - float((pd.cpu().double() ** 2).sum())) / float((pd.cpu().double() ** 2).sum()) < 1e-5
+    coef, nrm = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    hip.clip_coef(s, 1.0, coef, nrm)
+    assert abs(float(coef) - min(1.0, 1.0 / (math.sqrt(float(s)) + 1e-6))) < 1e-6
+    # embedding fwd / deterministic bwd
+    vocab, H = 1000, 256
+    table = bfr(vocab, H, seed=3)
+    ids = torch.randint(0, vocab, (77,), generator=g)
+    ids[5] = ids[6]
+    out = hip.embedding_fwd(ids.to(dev), table.to(dev))
+    assert torch.equal(out.cpu(), table[ids])
+    dy = bfr(77, H, seed=4)
+    grad = torch.zeros(vocab, H, device=dev)
+    hip.embedding_bwd(ids.to(dev), dy.to(dev), grad)
+    ref = torch.zeros(vocab, H).index_add_(0, ids, dy.float())
+    assert fro_rel(grad, ref) < 1e-6
+    # casts / add / colsum / layernorm / q_sample
+    x32 = torch.randn(1003, generator=g)
+    assert torch.equal(hip.cast_f32_to_bf16(x32.to(dev)).cpu(), x32.to(BF))
+    xb = bfr(513, 40, seed=6)
+    cs = torch.zeros(40, device=dev)
+    hip.colsum(xb.to(dev), cs, False)
+    assert fro_rel(cs, xb.float().sum(0)) < 1e-5
+    xl, wl, bl = bfr(10, 1024, seed=7), bfr(1024, seed=8), bfr(1024, seed=9)
+    yl = hip.layernorm_fwd(xl.to(dev), wl.to(dev), bl.to(dev), 1e-5)
+    assert fro_rel(yl, F.layer_norm(xl.float(), (1024,), wl.float(), bl.float(), 1e-5)) < 4e-3
+    x0, nz = torch.randn(8, 1, 7, generator=g), torch.randn(8, 1, 7, generator=g)
+    t = torch.randint(0, 100, (8,), generator=g)
+    sa, s1 = O.diffusion_tables(100)
+    xt = hip.q_sample(x0.to(dev), nz.to(dev), t.to(dev), torch.from_numpy(sa).float().to(dev), torch.from_numpy(s1).float().to(dev))
+    assert fro_rel(xt, O.q_sample(x0, t, nz)) < 1e-6

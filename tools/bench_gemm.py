@@ -1,0 +1,41 @@
+"""Micro-benchmark of the hand-written MFMA GEMM on the Llama-2-7B shapes (random data), next to torch.matmul
+(hipBLASLt) as an on-box reference ceiling. Usage: python tools/bench_gemm.py [tokens]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mla_amd import hip
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 17536
+dev = torch.device("cuda:0")
+H, I = 4096, 11008
+shapes = [  # name, M, N, K, a_mode, b_mode
+    ("qkv fwd  NT", T, 3 * H, H, 0, 0), ("o    fwd  NT", T, H, H, 0, 0), ("gu   fwd  NT", T, 2 * I, H, 0, 0),
+    ("down fwd  NT", T, H, I, 0, 0), ("qkv dgrad NN", T, H, 3 * H, 0, 1), ("gu  dgrad NN", T, H, 2 * I, 0, 1),
+    ("down dgrad NN", T, I, H, 0, 1), ("qkv wgrad TN", 3 * H, H, T, 1, 1), ("gu  wgrad TN", 2 * I, H, T, 1, 1),
+    ("down wgrad TN", H, I, T, 1, 1),
+]
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+for name, M, N, K, am, bm in shapes:
+    a = torch.randn((M, K) if am == 0 else (K, M), device=dev).to(torch.bfloat16)
+    b = torch.randn((N, K) if bm == 0 else (K, N), device=dev).to(torch.bfloat16)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ms = timeit(lambda: hip.gemm(a, b, out=out, a_mode=am, b_mode=bm))
+    A = a if am == 0 else a.t()
+    Bt = b.t() if bm == 0 else b
+    ms_ref = timeit(lambda: torch.matmul(A, Bt))
+    fl = 2.0 * M * N * K
+    print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d}  mla_hip {ms:8.3f} ms {fl/ms/1e9:8.1f} TF/s | hipBLASLt {ms_ref:8.3f} ms {fl/ms_ref/1e9:8.1f} TF/s", flush=True)
