@@ -1,0 +1,137 @@
+/* mla_hip.h -- C ABI of libmla_hip.so: the MI355X (gfx950) kernels behind the MLA-Llama2-7B training hot path.
+ *
+ * There is no FFI in the reference (ZhuoyangLiu2005/MLA is pure PyTorch + the flash_attn wheel); each entry point
+ * replaces the PyTorch / flash-attn call sites cited next to it (paths relative to the reference root). The Python
+ * binding a maintainer would add is shown in INTEGRATION.md and implemented in mla_amd/hip.py (ctypes).
+ *
+ * Contract
+ *  - plain pointers + sizes only; every buffer (inputs, outputs, workspace) is allocated and owned by the caller
+ *    (PyTorch); kernels never allocate, free or retain pointers past the call;
+ *  - launch-only on `stream`, never synchronise, never touch the default stream; re-entrant, no global mutable state
+ *    (forward runs on the main thread, backward on autograd worker threads);
+ *  - return 0 on success, a negative value for argument / shape / alignment violations (checked on the host before
+ *    launch), a positive hipError_t if the launch failed; mla_last_error() returns a thread-local message;
+ *  - bf16 tensors are raw uint16 bit patterns, row-major, unit inner stride; statistics, losses and master gradients
+ *    are fp32; indices are int64 as torch provides them (int32 where noted).
+ */
+#ifndef MLA_HIP_H
+#define MLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mla_stream_t; /* == hipStream_t */
+
+/* ---- library ---- */
+const char* mla_last_error(void);
+int mla_query(int what); /* 0: ABI version, 1: compiled gfx arch (950), 2: wavefront size (64) */
+/* hardware-assumption self test (ds_read_b64_tr_b16 lane map, global_load_lds destination order) */
+int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_1k, mla_stream_t stream);
+
+/* ---- GEMM: every nn.Linear forward / dgrad / wgrad on the path --------------------------------------------------
+ * transformers/models/llama/modeling_llama.py:240 (gate/up/down), :351-353 (q/k/v), :390 (o_proj), :1254 (lm_head);
+ * util/nn_utils.py:21-34; models/diffusion/models.py:112-123,173-189; models/mla/fuser/contrastive.py:173-183,208.
+ * C[M,N] = alpha * sum_k Aop(m,k) Bop(n,k) (+ bias[n]) (+ R[m,n]) (+ C when accumulate).
+ * a_mode/b_mode: 0 = operand stored [rows][K] (k contiguous), 1 = stored [K][rows] (reduction-major).
+ * forward y = x W^T: (0,0); dgrad dx = dy W: (0,1); wgrad dW = dy^T x: (1,1). out_fp32: C is float (else bf16). */
+int mla_gemm_bf16(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N, int K, int lda, int ldb,
+                  int ldc, int ldr, int a_mode, int b_mode, int out_fp32, int accumulate, float alpha, int force_generic,
+                  mla_stream_t stream);
+
+/* ---- RMSNorm: LlamaRMSNorm.forward modeling_llama.py:76-90; timm RmsNorm in FinalLayer (models/diffusion/models.py:177) */
+int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int H, float eps, mla_stream_t stream);
+int mla_rmsnorm_bwd_blocks(int rows);
+/* dx = dres + d(rmsnorm)/dx ; dw (+)= sum_rows dy * x_hat ; workspace >= mla_rmsnorm_bwd_blocks(rows)*H floats */
+int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx, float* dw,
+                    int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes, mla_stream_t stream);
+/* bias gradients: out[n] (+)= sum_r dy[r][n]; workspace >= mla_colsum_blocks(rows)*N floats */
+int mla_colsum_blocks(int rows);
+int mla_colsum_bf16(const void* dy, float* out, int accumulate, int rows, int N, int ld, float* workspace, size_t workspace_bytes,
+                    mla_stream_t stream);
+/* nn.LayerNorm forward in the frozen vision tokenizer: models/mla/image/vision_tokenizer.py:21-24 */
+int mla_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int H, float eps, mla_stream_t stream);
+
+/* ---- RoPE in place on the q and k slices of a packed qkv buffer: apply_rotary_pos_emb modeling_llama.py:184-208 */
+int mla_rope_inplace(void* buf, const float* cos_t, const float* sin_t, long long tokens, int S, int nheads, int D, int ld,
+                     int q_off, int k_off, int backward, mla_stream_t stream);
+
+/* ---- SwiGLU: LlamaMLP.forward modeling_llama.py:240; gu = [gate | up] per row */
+int mla_swiglu_fwd(const void* gu, void* act, long long rows, int I, mla_stream_t stream);
+int mla_swiglu_bwd(const void* dact, const void* gu, void* dgu, void* act_out, long long rows, int I, mla_stream_t stream);
+/* ---- activations: kind 0 GELU(erf), 1 GELU(tanh), 2 ReLU, 3 SiLU */
+int mla_act_fwd(const void* x, void* y, long long n, int kind, mla_stream_t stream);
+int mla_act_bwd(const void* dy, const void* x, void* dx, long long n, int kind, mla_stream_t stream);
+
+/* ---- casts / adds / row gathers (sequence assembly of PrismaticVLM.forward models/vlm/prismatic.py:981-1038) */
+int mla_cast_f32_to_bf16(const float* x, void* y, long long n, mla_stream_t stream);
+int mla_cast_bf16_to_f32(const void* x, float* y, long long n, mla_stream_t stream);
+int mla_add_bf16(const void* a, const void* b, void* y, long long n, mla_stream_t stream);
+int mla_gather_rows_bf16(const void* src, const long long* idx, void* out, long long rows, int H, int scatter, mla_stream_t stream);
+
+/* ---- embedding: LlamaModel.embed_tokens modeling_llama.py:975-976 (deterministic, atomics-free backward) */
+int mla_embedding_fwd(const long long* ids, const void* table, void* out, long long tokens, int H, int vocab, mla_stream_t stream);
+int mla_embedding_bwd(const long long* ids, const void* dy, float* grad, long long tokens, int H, int vocab, mla_stream_t stream);
+
+/* ---- optimizer: AdamW (training/strategies/fsdp.py:257) over the local fp32 shard + bf16 compute copy; clip (:308-310) */
+int mla_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, const float* grad_scale, mla_stream_t stream);
+int mla_sumsq_f32(const float* x, long long n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
+                  mla_stream_t stream);
+int mla_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, mla_stream_t stream);
+
+/* ---- diffusion: GaussianDiffusion.q_sample models/diffusion/gaussian_diffusion.py:214-229 */
+int mla_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac, const float* sqrt_1mac, float* out,
+                 int batch, int per, int nsteps, mla_stream_t stream);
+
+/* ---- causal attention (replaces flash_attn 2.5.5: modeling_llama.py:420-597; math :371-380). head_dim 128.
+ * q/k/v: first element of each slice of the packed [B*S, ld_qkv] buffer; o / dout: [B*S, ld_o]; lse, delta: [B,H,S].
+ * seqlens (int32 [B] or NULL): right-padded rows q >= seqlens[b] give zero output / zero gradients. */
+int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B, int S, int H,
+                 int head_dim, long long ld_qkv, long long ld_o, float scale, mla_stream_t stream);
+int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
+                 void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
+                 float scale, mla_stream_t stream);
+
+/* ---- losses: CrossEntropyLoss modeling_llama.py:1258-1269; InfoNCE models/mla/fuser/contrastive.py:208-215 */
+int mla_ce_fwd(const void* logits, int logits_fp32, long long ld, const long long* labels, float* loss, float* lse, int rows,
+               int ncols, long long ignore_index, mla_stream_t stream);
+int mla_ce_bwd(const void* logits, int logits_fp32, long long ld, const long long* labels, const float* lse, const float* gscale,
+               float inv_count, void* dlogits, long long ldd, int rows, int ncols, long long ignore_index, mla_stream_t stream);
+int mla_infonce_bwd(const float* L, const float* rlse, const float* clse, const float* gscale, void* dL, int M, int Mp,
+                    mla_stream_t stream);
+int mla_l2norm_fwd(const void* x, void* y, float* norms, int rows, int ncols, float eps, mla_stream_t stream);
+int mla_l2norm_bwd(const void* dy, const void* y, const float* norms, void* dx, int rows, int ncols, mla_stream_t stream);
+
+/* ---- point-cloud tokenizer (forward): models/mla/pointcloud/backbone/Point_PN.py
+ * furthest_point_sample :6-21 (start index = explicit input), knn_point :62-73, LGA :115-158 + PosE_Geo :231-249,
+ * BatchNorm in train mode :179,209,215, Pooling :166-169; projection models/mla/fuser/contrastive.py:5-45 */
+int mla_project_points(const float* xyz, const float* consts21, long long* idx, unsigned char* valid, int n, float W, float Hh,
+                       float stride, int ph, int pw, mla_stream_t stream);
+int mla_fps(const float* xyz, const long long* start, long long* out, int B, int N, int npoint, mla_stream_t stream);
+int mla_knn(const float* xyz, const float* centers, int* out, int B, int N, int G, int k, mla_stream_t stream);
+int mla_gather_rows_f32(const float* src, const long long* idx, float* out, int B, int N, int G, int W, mla_stream_t stream);
+int mla_lga_prep(const float* xyz, const void* feats, const long long* fps_idx, const int* knn, void* rows, float* lc_xyz, int B,
+                 int N, int G, int K, int C, float alpha, float beta, mla_stream_t stream);
+int mla_colstats_blocks(long long rows);
+int mla_colstats_bf16(const void* x, float* mean, float* var, long long rows, int C, int ld, float* workspace, size_t workspace_bytes,
+                      mla_stream_t stream);
+int mla_bn_apply(const void* x, const float* mean, const float* var, const void* w, const void* b, const void* res, void* y,
+                 long long rows, int C, float eps, int relu, mla_stream_t stream);
+int mla_maxpool_k(const void* x, void* out, long long groups, int K, int C, mla_stream_t stream);
+
+/* ---- vision tokenizer (forward): models/mla/image/vision_tokenizer.py  Conv2d patchify :110,122 (im2col + GEMM),
+ * LocalAttention :26-47 (avg-pool, 3x3 window attention) */
+int mla_im2col_patch(const void* pix, int pix_fp32, void* rows, int B, int CT, int Himg, int Wimg, int P, int Kpad,
+                     mla_stream_t stream);
+int mla_avgpool_tokens(const void* x, void* y, int B, int gh, int gw, int C, int cs, mla_stream_t stream);
+int mla_local_attn(const void* q, const void* kv, void* out, int B, int gh, int gw, int C, int cs, int heads, float scale,
+                   mla_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLA_HIP_H */

@@ -1,0 +1,109 @@
+"""LLM backbone wrapper with the reference's surface (models/backbones/llm/base_llm.py:37-241, llama2.py:55-104).
+
+The reference downloads meta-llama/Llama-2-7b-hf; there is no network here, so the backbone is built from a config with
+random-init weights (checkpoint layout / loading is SURVEY 8f rank 1). A minimal tokenizer stand-in provides the few
+attributes the model code reads (vocab size incl. <PAD>, pad id, single-id encode for the trigger strings).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Type
+
+import torch
+import torch.nn as nn
+
+from .llama import LlamaConfig, LlamaDecoderLayer, LlamaForCausalLM
+from .modeling_outputs import CausalLMOutputWithPast
+
+
+class SyntheticLlamaTokenizer:
+    """Stand-in for LlamaTokenizerFast: ids only (no text). vocab 32000 + <PAD> (llama2.py:75-77)."""
+
+    def __init__(self, vocab_size: int = 32000):
+        self.base_vocab = vocab_size
+        self.added = ["<PAD>"]
+        self.pad_token_id = vocab_size
+        self.bos_token_id, self.eos_token_id = 1, 2
+        self.padding_side = "right"
+        self.model_max_length = 2048
+
+    def __len__(self):
+        return self.base_vocab + len(self.added)
+
+    @property
+    def vocab_size(self):
+        return self.base_vocab
+
+    def add_special_tokens(self, d):
+        toks = d.get("additional_special_tokens", []) + ([d["pad_token"]] if "pad_token" in d else [])
+        new = [t for t in toks if t not in self.added]
+        self.added += new
+        return len(new)
+
+    def encode(self, s, add_special_tokens=False):
+        return [3 + (sum(map(ord, s)) % 1000)]
+
+
+class LLMBackbone(nn.Module):
+    def __init__(self, llm_backbone_id: str) -> None:
+        super().__init__()
+        self.identifier = llm_backbone_id
+        self.llm = None
+        self.tokenizer = None
+
+    def get_tokenizer(self):
+        return self.tokenizer
+
+
+class LLaMa2LLMBackbone(LLMBackbone):
+    def __init__(self, llm_backbone_id: str = "llama2-7b-pure", llm_max_length: int = 2048, hf_token: Optional[str] = None,
+                 inference_mode: bool = False, use_flash_attention_2: bool = True, llm_vision_layers: int = 1,
+                 config: Optional[LlamaConfig] = None, pad_to_multiple_of: int = 64, **kwargs) -> None:
+        super().__init__(llm_backbone_id)
+        self.llm_max_length, self.inference_mode = llm_max_length, inference_mode
+        cfg = config or LlamaConfig()
+        self.tokenizer = SyntheticLlamaTokenizer(cfg.vocab_size)
+        self.llm = LlamaForCausalLM(cfg)
+        # llama2.py:75-77: add <PAD>, resize embeddings padded to a multiple of 64 (32001 -> 32064)
+        self.llm.resize_token_embeddings(len(self.tokenizer), pad_to_multiple_of=pad_to_multiple_of)
+        self.llm.config.pad_token_id = self.tokenizer.pad_token_id
+        self.llm.config.use_cache = False
+
+    @property
+    def transformer_layer_cls(self) -> Type[nn.Module]:
+        return LlamaDecoderLayer
+
+    @property
+    def half_precision_dtype(self) -> torch.dtype:
+        return torch.bfloat16
+
+    @property
+    def embed_dim(self) -> int:
+        return self.llm.config.hidden_size
+
+    @property
+    def pad_token_id(self) -> int:
+        return self.tokenizer.pad_token_id
+
+    @property
+    def prompt_builder_fn(self):
+        raise NotImplementedError("prompt construction belongs to the data pipeline (SURVEY 8f rank 4)")
+
+    def get_fsdp_wrapping_policy(self) -> Callable:
+        cls = self.transformer_layer_cls
+        return lambda module: isinstance(module, cls)
+
+    def enable_gradient_checkpointing(self) -> None:
+        """base_llm.py: gradient checkpointing on the HF model == full recompute inside each decoder layer here."""
+        self.llm.config.activation_save_level = 0
+
+    def embed_input_ids(self, input_ids: torch.LongTensor) -> torch.Tensor:
+        return self.llm.model.embed(input_ids)
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **contrastive_kwargs
+                ) -> CausalLMOutputWithPast:
+        """base_llm.py:198-241: passes the 9 extra contrastive kwargs through to LlamaForCausalLM.forward."""
+        return self.llm(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                        past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels, use_cache=use_cache,
+                        output_attentions=output_attentions, output_hidden_states=output_hidden_states, return_dict=return_dict,
+                        **contrastive_kwargs)

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
     unpack8(*(const u32x4_t*)(gu + r * 2 * I + c * 8), g);
     unpack8(*(const u32x4_t*)(gu + r * 2 * I + I + c * 8), u);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+    for (int j = 0; j < 8; ++j) { const float s = 1.f / (1.f + __expf(-g[j])); o[j] = (g[j] * s) * u[j]; }
     *(u32x4_t*)(act + r * I + c * 8) = pack8(o);
   }
 }
@@ -459,6 +459,20 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
   out[i] = sqrt_ac[tt] * x0[i] + sqrt_1mac[tt] * noise[i];
 }
 
+// out[r][:] = src[idx[r]][:]  /  dst[idx[r]][:] = src[r][:]   (sequence assembly; idx is injective for the scatter)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, const long long* __restrict__ idx,
+                                                          bf16_t* __restrict__ out, long long rows, int H, int scatter) {
+  const int cpr = H >> 3;
+  const long long total = rows * cpr;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long r = e / cpr;
+    const int c = (int)(e % cpr);
+    const long long s = idx[r];
+    if (scatter) *(u32x4_t*)(out + s * H + c * 8) = *(const u32x4_t*)(src + r * H + c * 8);
+    else *(u32x4_t*)(out + r * H + c * 8) = *(const u32x4_t*)(src + s * H + c * 8);
+  }
+}
+
 inline int grid_for(long long work_items, int cap = 4096) {
   long long b = (work_items + 255) / 256;
   if (b < 1) b = 1;
@@ -616,5 +630,13 @@ extern "C" int mla_q_sample(const float* x0, const float* noise, const long long
   MLA_CHECK_ARG(x0 && noise && t && sqrt_ac && sqrt_1mac && out, "mla_q_sample: null pointer");
   hipLaunchKernelGGL(q_sample_kernel, dim3((batch * per + 255) / 256), dim3(256), 0, stream, x0, noise, t, sqrt_ac, sqrt_1mac,
                      out, batch, per, nsteps);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_gather_rows_bf16(const void* src, const long long* idx, void* out, long long rows, int H, int scatter,
+                                    hipStream_t stream) {
+  MLA_CHECK_ARG(src && idx && out && H % 8 == 0 && AL16(src) && AL16(out), "mla_gather_rows_bf16: bad args");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (H / 8))), dim3(256), 0, stream, (const bf16_t*)src, idx, (bf16_t*)out,
+                     rows, H, scatter);
   MLA_LAUNCH_CHECK();
 }

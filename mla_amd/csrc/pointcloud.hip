@@ -1,0 +1,331 @@
+// Point-cloud tokenizer kernels (forward only: the 3-D tower is frozen on the SFT / post-training path,
+// models/vlm/prismatic.py:463-467) + camera projection of the point centres.
+// Reference: models/mla/pointcloud/backbone/Point_PN.py (furthest_point_sample :6-21, knn_point :62-73, LGA :115-158,
+// PosE_Geo :231-249, Linear1Layer/Linear2Layer :173-219, Pooling :166-169), models/mla/fuser/contrastive.py:5-45.
+// The reference's FPS is a 512/256-iteration Python loop with a host sync per iteration; here one workgroup per cloud
+// keeps the cloud and the running distances on chip for the whole selection.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ projection
+__global__ __launch_bounds__(256) void project_points_kernel(const float* __restrict__ xyz, const float* __restrict__ c,
+                                                             long long* __restrict__ idx, unsigned char* __restrict__ valid,
+                                                             int n, float W, float Hh, float stride, int ph, int pw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = xyz[i * 3], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+  float cam[3], uvw[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float a = __fmul_rn(x, c[r * 3]);
+    a = fmaf(y, c[r * 3 + 1], a);
+    a = fmaf(z, c[r * 3 + 2], a);
+    cam[r] = __fadd_rn(a, c[9 + r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float a = __fmul_rn(cam[0], c[12 + r * 3]);
+    a = fmaf(cam[1], c[12 + r * 3 + 1], a);
+    uvw[r] = fmaf(cam[2], c[12 + r * 3 + 2], a);
+  }
+  const float zz = uvw[2];
+  const float den = __fadd_rn(zz, 1e-6f);
+  const float px = __fdiv_rn(uvw[0], den), py = __fdiv_rn(uvw[1], den);
+  long long row = (long long)floorf(__fdiv_rn(py, stride));
+  long long col = (long long)floorf(__fdiv_rn(px, stride));
+  const bool v = (zz > 0.f) && (px >= 0.f) && (px < W) && (py >= 0.f) && (py < Hh);
+  row = row < 0 ? 0 : (row > ph - 1 ? ph - 1 : row);
+  col = col < 0 ? 0 : (col > pw - 1 ? pw - 1 : col);
+  idx[i * 2] = row;
+  idx[i * 2 + 1] = col;
+  valid[i] = v ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ FPS
+constexpr int FPS_MAXP = 8;  // points per thread (N <= 2048)
+__global__ __launch_bounds__(256) void fps_kernel(const float* __restrict__ xyz, const long long* __restrict__ start,
+                                                  long long* __restrict__ out, int N, int npoint) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* pts = (float*)smem;                 // [N][3]
+  float* rv = pts + N * 3;                   // [4] per-wave best value
+  int* ri = (int*)(rv + 4);                  // [4] per-wave best index
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* src = xyz + (size_t)b * N * 3;
+  for (int e = tid; e < N * 3; e += 256) pts[e] = src[e];
+  float dist[FPS_MAXP];
+#pragma unroll
+  for (int i = 0; i < FPS_MAXP; ++i) dist[i] = 1e10f;
+  __syncthreads();
+  int far = (int)start[b];
+  for (int it = 0; it < npoint; ++it) {
+    if (tid == 0) out[(size_t)b * npoint + it] = far;
+    const float cx = pts[far * 3], cy = pts[far * 3 + 1], cz = pts[far * 3 + 2];
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < FPS_MAXP; ++i) {
+      const int p = tid + i * 256;
+      if (p < N) {
+        const float dx = __fsub_rn(pts[p * 3], cx), dy = __fsub_rn(pts[p * 3 + 1], cy), dz = __fsub_rn(pts[p * 3 + 2], cz);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        if (d < dist[i]) dist[i] = d;
+        if (dist[i] > bv) { bv = dist[i]; bi = p; }  // ascending p: first (lowest) index wins ties
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    __syncthreads();  // previous iteration's rv/ri fully consumed
+    if (lane == 0) { rv[wid] = bv; ri[wid] = bi; }
+    __syncthreads();
+    bv = rv[0]; bi = ri[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+    far = bi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ kNN
+// One block per centre: distances to all N (<= 1024) points with the reference's expansion
+// (-2 <c,p> + |c|^2 + |p|^2, square_distance Point_PN.py:23-42), bitonic sort of (dist, index), first k indices.
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz, const float* __restrict__ centers,
+                                                  int* __restrict__ out, int N, int G, int k) {
+  __shared__ float key[1024];
+  __shared__ int val[1024];
+  const int bg = blockIdx.x, b = bg / G, tid = threadIdx.x;
+  const float* c = centers + (size_t)bg * 3;
+  const float cx = c[0], cy = c[1], cz = c[2];
+  const float cs = __fadd_rn(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)), __fmul_rn(cz, cz));
+  const float* pts = xyz + (size_t)b * N * 3;
+  for (int p = tid; p < 1024; p += 256) {
+    float d = INFINITY;
+    if (p < N) {
+      const float x = pts[p * 3], y = pts[p * 3 + 1], z = pts[p * 3 + 2];
+      float dot = __fmul_rn(cx, x);
+      dot = fmaf(cy, y, dot);
+      dot = fmaf(cz, z, dot);
+      const float ps = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+      d = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), cs), ps);
+    }
+    key[p] = d;
+    val[p] = p;
+  }
+  __syncthreads();
+  for (int size = 2; size <= 1024; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < 512; t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool asc = ((lo & size) == 0);
+        const float a = key[lo], bb = key[hi];
+        const int ia = val[lo], ib = val[hi];
+        const bool gt = (a > bb) || (a == bb && ia > ib);
+        if (gt == asc) { key[lo] = bb; key[hi] = a; val[lo] = ib; val[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = tid; j < k; j += 256) out[(size_t)bg * k + j] = val[j];
+}
+
+// ------------------------------------------------------------------------------------------------ LGA prep
+// rows[(b,g,k)][0:C] = feats[knn] ; rows[..][C:2C] = feats[centre] ; + sin/cos positional embedding of the
+// centre-subtracted, per-group max-abs normalised neighbour offset (type 'scan', alpha 1000, beta 100).
+__global__ __launch_bounds__(256) void lga_prep_kernel(const float* __restrict__ xyz, const bf16_t* __restrict__ feats,
+                                                       const long long* __restrict__ fps_idx, const int* __restrict__ knn,
+                                                       bf16_t* __restrict__ rows, float* __restrict__ lc_xyz, int N, int G,
+                                                       int K, int C, float alpha, float beta) {
+  __shared__ float rel[128][3];
+  __shared__ int nb[128];
+  __shared__ float mx[3];
+  const int bg = blockIdx.x, b = bg / G, tid = threadIdx.x;
+  const int ci = (int)fps_idx[bg];
+  const float* pts = xyz + (size_t)b * N * 3;
+  const float cx = pts[ci * 3], cy = pts[ci * 3 + 1], cz = pts[ci * 3 + 2];
+  if (tid < 3) lc_xyz[(size_t)bg * 3 + tid] = pts[ci * 3 + tid];
+  for (int kk = tid; kk < K; kk += 256) {
+    const int j = knn[(size_t)bg * K + kk];
+    nb[kk] = j;
+    rel[kk][0] = pts[j * 3] - cx;
+    rel[kk][1] = pts[j * 3 + 1] - cy;
+    rel[kk][2] = pts[j * 3 + 2] - cz;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float m = 0.f;
+    for (int kk = 0; kk < K; ++kk) m = fmaxf(m, fabsf(rel[kk][tid]));
+    mx[tid] = fmaxf(m, 1e-6f);
+  }
+  __syncthreads();
+  const int OD = 2 * C, fd = OD / 6;
+  const bf16_t* fb = feats + (size_t)b * N * C;
+  for (int e = tid; e < K * OD; e += 256) {
+    const int kk = e / OD, ch = e % OD;
+    const float f = ch < C ? bf2f(fb[(size_t)nb[kk] * C + ch]) : bf2f(fb[(size_t)ci * C + (ch - C)]);
+    const int coord = ch / (2 * fd), r = ch % (2 * fd);
+    const int fi = r < fd ? r : r - fd;
+    const float de = powf(alpha, (float)fi / (float)fd);
+    const float arg = (beta * (rel[kk][coord] / mx[coord])) / de;
+    const float pe = r < fd ? sinf(arg) : cosf(arg);
+    rows[((size_t)bg * K + kk) * OD + ch] = f2bf(f + pe);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm (train)
+// partial[(blockIdx.y*2 + {0,1}) * C + c] = sum / sum of squares over this block's row slice
+__global__ __launch_bounds__(256) void colstats_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+                                                               long long rows, int C, int ld) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + c;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = blockIdx.y * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
+  float a = 0.f, q = 0.f;
+  if (ch < C)
+    for (long long r = r0 + rl; r < r1; r += 4) { const float v = bf2f(x[r * ld + ch]); a += v; q += v * v; }
+  s1[rl][c] = a; s2[rl][c] = q;
+  __syncthreads();
+  if (rl == 0 && ch < C) {
+    partial[((size_t)blockIdx.y * 2) * C + ch] = s1[0][c] + s1[1][c] + s1[2][c] + s1[3][c];
+    partial[((size_t)blockIdx.y * 2 + 1) * C + ch] = s2[0][c] + s2[1][c] + s2[2][c] + s2[3][c];
+  }
+}
+__global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
+                                                             float* __restrict__ var, int P, int C, long long rows) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= C) return;
+  double a = 0.0, q = 0.0;
+  for (int p = 0; p < P; ++p) { a += (double)partial[((size_t)p * 2) * C + ch]; q += (double)partial[((size_t)p * 2 + 1) * C + ch]; }
+  const double m = a / (double)rows;
+  double v = q / (double)rows - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[ch] = (float)m;
+  var[ch] = (float)v;  // biased (what BatchNorm normalises with)
+}
+// y = (x - mean) * rsqrt(var + eps) * w + b (+ residual) (relu)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, const bf16_t* __restrict__ w,
+                                                       const bf16_t* __restrict__ b, const bf16_t* __restrict__ res,
+                                                       bf16_t* __restrict__ y, long long rows, int C, float eps, int relu) {
+  const int cpr = C >> 3;
+  const long long total = rows * cpr;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long r = idx / cpr;
+    const int c0 = (int)(idx % cpr) * 8;
+    const u32x4_t xv = *(const u32x4_t*)(x + r * C + c0);
+    u32x4_t rv = {0u, 0u, 0u, 0u};
+    if (res) rv = *(const u32x4_t*)(res + r * C + c0);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t wd = xv[j >> 1], rd = rv[j >> 1];
+      const float v = (j & 1) ? bfhi(wd) : bflo(wd);
+      const float rr = (j & 1) ? bfhi(rd) : bflo(rd);
+      const int c = c0 + j;
+      float t = (v - mean[c]) * (1.0f / sqrtf(var[c] + eps)) * bf2f(w[c]) + bf2f(b[c]) + rr;
+      if (relu) t = t > 0.f ? t : 0.f;
+      o[j] = t;
+    }
+    u32x4_t ov;
+    ov[0] = pack2bf(o[0], o[1]); ov[1] = pack2bf(o[2], o[3]); ov[2] = pack2bf(o[4], o[5]); ov[3] = pack2bf(o[6], o[7]);
+    *(u32x4_t*)(y + r * C + c0) = ov;
+  }
+}
+// out[g][c] = max_k x[g][k][c]
+__global__ __launch_bounds__(256) void maxpool_k_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long groups,
+                                                        int K, int C) {
+  const long long total = groups * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long g = idx / C;
+    const int c = (int)(idx % C);
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, bf2f(x[(g * K + k) * C + c]));
+    out[idx] = f2bf(m);
+  }
+}
+// gather rows: out[i][:] = src[idx[i]][:] (fp32, 3 wide or any width)
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, const long long* __restrict__ idx,
+                                                              float* __restrict__ out, int B, int N, int G, int W) {
+  const long long total = (long long)B * G * W;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int w = (int)(e % W);
+    const long long bg = e / W;
+    const int b = (int)(bg / G);
+    out[e] = src[((size_t)b * N + idx[bg]) * W + w];
+  }
+}
+
+inline int gridn(long long items, int cap = 8192) {
+  long long b = (items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int mla_project_points(const float* xyz, const float* consts21, long long* idx, unsigned char* valid, int n,
+                                  float W, float Hh, float stride, int ph, int pw, hipStream_t stream) {
+  MLA_CHECK_ARG(xyz && consts21 && idx && valid && n > 0, "mla_project_points: bad args");
+  hipLaunchKernelGGL(project_points_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xyz, consts21, idx, valid, n, W, Hh,
+                     stride, ph, pw);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_fps(const float* xyz, const long long* start, long long* out, int B, int N, int npoint, hipStream_t stream) {
+  MLA_CHECK_ARG(xyz && start && out && B > 0 && N > 0 && N <= 2048 && npoint > 0 && npoint <= N, "mla_fps: need N <= 2048");
+  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(256), N * 3 * sizeof(float) + 64, stream, xyz, start, out, N, npoint);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_knn(const float* xyz, const float* centers, int* out, int B, int N, int G, int k, hipStream_t stream) {
+  MLA_CHECK_ARG(xyz && centers && out && N > 0 && N <= 1024 && k > 0 && k <= N, "mla_knn: need N <= 1024, k <= N");
+  hipLaunchKernelGGL(knn_kernel, dim3(B * G), dim3(256), 0, stream, xyz, centers, out, N, G, k);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_lga_prep(const float* xyz, const void* feats, const long long* fps_idx, const int* knn, void* rows,
+                            float* lc_xyz, int B, int N, int G, int K, int C, float alpha, float beta, hipStream_t stream) {
+  MLA_CHECK_ARG(xyz && feats && fps_idx && knn && rows && lc_xyz, "mla_lga_prep: null pointer");
+  MLA_CHECK_ARG(K <= 128 && (2 * C) % 6 == 0, "mla_lga_prep: need K <= 128 and 2C divisible by 6");
+  hipLaunchKernelGGL(lga_prep_kernel, dim3(B * G), dim3(256), 0, stream, xyz, (const bf16_t*)feats, fps_idx, knn, (bf16_t*)rows,
+                     lc_xyz, N, G, K, C, alpha, beta);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_colstats_blocks(long long rows) { long long r = rows / 2048; return (int)(r < 1 ? 1 : (r > 256 ? 256 : r)); }
+// workspace: mla_colstats_blocks(rows) * 2 * C floats
+extern "C" int mla_colstats_bf16(const void* x, float* mean, float* var, long long rows, int C, int ld, float* workspace,
+                                 size_t workspace_bytes, hipStream_t stream) {
+  MLA_CHECK_ARG(x && mean && var && workspace && rows > 0, "mla_colstats_bf16: bad args");
+  const int P = mla_colstats_blocks(rows);
+  MLA_CHECK_ARG(workspace_bytes >= (size_t)P * 2 * C * sizeof(float), "mla_colstats_bf16: workspace too small");
+  hipLaunchKernelGGL(colstats_partial_kernel, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const bf16_t*)x, workspace, rows, C, ld);
+  hipLaunchKernelGGL(colstats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, mean, var, P, C, rows);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_bn_apply(const void* x, const float* mean, const float* var, const void* w, const void* b, const void* res,
+                            void* y, long long rows, int C, float eps, int relu, hipStream_t stream) {
+  MLA_CHECK_ARG(x && mean && var && w && b && y && C % 8 == 0, "mla_bn_apply: bad args (C %% 8)");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(gridn(rows * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, mean, var,
+                     (const bf16_t*)w, (const bf16_t*)b, (const bf16_t*)res, (bf16_t*)y, rows, C, eps, relu);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_maxpool_k(const void* x, void* out, long long groups, int K, int C, hipStream_t stream) {
+  MLA_CHECK_ARG(x && out, "mla_maxpool_k: null pointer");
+  hipLaunchKernelGGL(maxpool_k_kernel, dim3(gridn(groups * C)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, groups, K, C);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_gather_rows_f32(const float* src, const long long* idx, float* out, int B, int N, int G, int W,
+                                   hipStream_t stream) {
+  MLA_CHECK_ARG(src && idx && out, "mla_gather_rows_f32: null pointer");
+  hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(gridn((long long)B * G * W)), dim3(256), 0, stream, src, idx, out, B, N, G, W);
+  MLA_LAUNCH_CHECK();
+}

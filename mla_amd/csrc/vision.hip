@@ -1,0 +1,124 @@
+// Encoder-free vision tokenizer kernels (forward only: vision_tower_2d is frozen on the SFT / post-training path).
+// Reference: models/mla/image/vision_tokenizer.py -- Conv2d(3->C, k = s = 14) patchify :110,122 (here: im2col +
+// the MFMA GEMM), LocalAttention :14-47 (3x3 window attention, scale = C^-0.5).  The reference loops over samples in
+// Python with a host sync each; here the whole batch is one launch per stage.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldp(const T* p);
+template <> __device__ __forceinline__ float ldp<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldp<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+// rows[(b, py, px)][k = c*P*P + ky*P + kx] = pix[b][c][py*P + ky][px*P + kx], zero padded to Kpad columns.
+// pix has CT channels per image (RGB + mask) of which the first 3 are used.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ pix, bf16_t* __restrict__ rows, int B, int CT, int Himg,
+                                                     int Wimg, int P, int Kpad) {
+  const int gh = Himg / P, gw = Wimg / P;
+  const long long total = (long long)B * gh * gw * Kpad;
+  const int Kreal = 3 * P * P;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int k = (int)(e % Kpad);
+    const long long r = e / Kpad;
+    float v = 0.f;
+    if (k < Kreal) {
+      const int px = (int)(r % gw), py = (int)((r / gw) % gh), b = (int)(r / ((long long)gw * gh));
+      const int c = k / (P * P), rem = k % (P * P), ky = rem / P, kx = rem % P;
+      v = ldp<T>(pix + (((size_t)b * CT + c) * Himg + (py * P + ky)) * Wimg + (px * P + kx));
+    }
+    rows[e] = f2bf(v);
+  }
+}
+
+// tokens [B, gh, gw, C] (channel-last rows) -> pooled [B, gh/cs, gw/cs, C], mean over the cs x cs window
+__global__ __launch_bounds__(256) void avgpool_tokens_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int gh,
+                                                             int gw, int C, int cs) {
+  const int oh = gh / cs, ow = gw / cs;
+  const long long total = (long long)B * oh * ow * C;
+  const float inv = 1.f / (float)(cs * cs);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    long long r = e / C;
+    const int j = (int)(r % ow), i = (int)((r / ow) % oh), b = (int)(r / ((long long)ow * oh));
+    float s = 0.f;
+    for (int dy = 0; dy < cs; ++dy)
+      for (int dx = 0; dx < cs; ++dx) s += bf2f(x[(((size_t)b * gh + i * cs + dy) * gw + j * cs + dx) * C + c]);
+    y[e] = f2bf(s * inv);
+  }
+}
+
+// One block per window. q [B*oh*ow, C]; kv [B*gh*gw, 2C] (k = [:, :C], v = [:, C:]); heads x 128... generic head dim
+// hd = C / heads (hd % 32 == 0 handled: 32 lanes per head, hd/32 channels per lane; heads*32 == blockDim.x = 256).
+__global__ __launch_bounds__(256) void local_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                         bf16_t* __restrict__ out, int B, int gh, int gw, int C, int cs, float scale) {
+  const int oh = gh / cs, ow = gw / cs;
+  const int win = blockIdx.x;
+  const int j = win % ow, i = (win / ow) % oh, b = win / (ow * oh);
+  const int head = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int hd = C / 8, per = hd / 32;
+  const int c0 = head * hd + l * per;
+  float qv[8];
+  for (int t = 0; t < per; ++t) qv[t] = bf2f(q[(size_t)win * C + c0 + t]) * scale;
+  const int N = cs * cs;
+  float sc[16];
+  float m = -INFINITY;
+  for (int n = 0; n < N; ++n) {
+    const int dy = n / cs, dx = n % cs;
+    const size_t row = ((size_t)b * gh + i * cs + dy) * gw + j * cs + dx;
+    float s = 0.f;
+    for (int t = 0; t < per; ++t) s += qv[t] * bf2f(kv[row * 2 * C + c0 + t]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    sc[n] = s;
+    m = fmaxf(m, s);
+  }
+  float den = 0.f;
+  for (int n = 0; n < N; ++n) { sc[n] = __expf(sc[n] - m); den += sc[n]; }
+  const float inv = 1.f / den;
+  float acc[8];
+  for (int t = 0; t < per; ++t) acc[t] = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int dy = n / cs, dx = n % cs;
+    const size_t row = ((size_t)b * gh + i * cs + dy) * gw + j * cs + dx;
+    const float p = sc[n] * inv;
+    for (int t = 0; t < per; ++t) acc[t] += p * bf2f(kv[row * 2 * C + C + c0 + t]);
+  }
+  for (int t = 0; t < per; ++t) out[(size_t)win * C + c0 + t] = f2bf(acc[t]);
+}
+
+inline int gridn(long long items, int cap = 16384) {
+  long long b = (items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int mla_im2col_patch(const void* pix, int pix_fp32, void* rows, int B, int CT, int Himg, int Wimg, int P, int Kpad,
+                                hipStream_t stream) {
+  MLA_CHECK_ARG(pix && rows && CT >= 3 && Himg % P == 0 && Wimg % P == 0 && Kpad >= 3 * P * P, "mla_im2col_patch: bad args");
+  const long long total = (long long)B * (Himg / P) * (Wimg / P) * Kpad;
+  if (pix_fp32)
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(gridn(total)), dim3(256), 0, stream, (const float*)pix, (bf16_t*)rows, B, CT, Himg, Wimg, P, Kpad);
+  else
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(gridn(total)), dim3(256), 0, stream, (const bf16_t*)pix, (bf16_t*)rows, B, CT, Himg, Wimg, P, Kpad);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_avgpool_tokens(const void* x, void* y, int B, int gh, int gw, int C, int cs, hipStream_t stream) {
+  MLA_CHECK_ARG(x && y && gh % cs == 0 && gw % cs == 0, "mla_avgpool_tokens: bad args");
+  hipLaunchKernelGGL(avgpool_tokens_kernel, dim3(gridn((long long)B * (gh / cs) * (gw / cs) * C)), dim3(256), 0, stream,
+                     (const bf16_t*)x, (bf16_t*)y, B, gh, gw, C, cs);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_local_attn(const void* q, const void* kv, void* out, int B, int gh, int gw, int C, int cs, int heads,
+                              float scale, hipStream_t stream) {
+  MLA_CHECK_ARG(q && kv && out, "mla_local_attn: null pointer");
+  MLA_CHECK_ARG(heads == 8 && C % 256 == 0 && C / 8 / 32 <= 8 && cs * cs <= 16 && gh % cs == 0 && gw % cs == 0,
+                "mla_local_attn: need 8 heads, C %% 256 == 0, window <= 16");
+  hipLaunchKernelGGL(local_attn_kernel, dim3(B * (gh / cs) * (gw / cs)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)kv,
+                     (bf16_t*)out, B, gh, gw, C, cs, scale);
+  MLA_LAUNCH_CHECK();
+}

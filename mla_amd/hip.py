@@ -363,3 +363,118 @@ def selftest(device="cuda"):
     out_g = torch.zeros(256, dtype=torch.int32, device=device)
     call("mla_selftest", _p(src), _p(out_tr), _p(out_g))
     return src, out_tr, out_g
+
+
+# --------------------------------------------------------------------------------------------- point cloud / vision
+register_signatures({
+    "mla_project_points": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p],
+    "mla_fps": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mla_knn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "mla_lga_prep": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                     c_float, c_void_p],
+    "mla_colstats_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    "mla_bn_apply": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_float, c_int,
+                     c_void_p],
+    "mla_maxpool_k": [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+    "mla_gather_rows_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "mla_im2col_patch": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mla_avgpool_tokens": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mla_local_attn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mla_colstats_blocks": [c_longlong],
+    "mla_gather_rows_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+})
+
+
+def gather_rows(src2d, idx, out_rows=None, scatter=False):
+    """gather: out[r] = src[idx[r]] (out has len(idx) rows); scatter: out[idx[r]] = src[r] (out has out_rows rows, zero-filled)."""
+    H = src2d.shape[1]
+    n = idx.numel()
+    if scatter:
+        out = torch.zeros((out_rows, H), dtype=torch.bfloat16, device=src2d.device)
+    else:
+        out = torch.empty((n, H), dtype=torch.bfloat16, device=src2d.device)
+    call("mla_gather_rows_bf16", _p(src2d), _p(idx), _p(out), n, H, 1 if scatter else 0)
+    return out
+
+
+def project_points(xyz_n3, consts21, idx_out, valid_out, W, Hh, stride, ph, pw):
+    call("mla_project_points", _p(xyz_n3), _p(consts21), _p(idx_out), _p(valid_out), xyz_n3.shape[0], W, Hh, stride, ph, pw)
+
+
+def fps(xyz, start, npoint):
+    B, N, _ = xyz.shape
+    out = torch.empty((B, npoint), dtype=torch.int64, device=xyz.device)
+    call("mla_fps", _p(xyz), _p(start), _p(out), B, N, npoint)
+    return out
+
+
+def knn(xyz, centers, k):
+    B, N, _ = xyz.shape
+    G = centers.shape[1]
+    out = torch.empty((B, G, k), dtype=torch.int32, device=xyz.device)
+    call("mla_knn", _p(xyz), _p(centers), _p(out), B, N, G, k)
+    return out
+
+
+def gather_rows_f32(src_bnw, idx_bg):
+    B, N, W = src_bnw.shape
+    G = idx_bg.shape[1]
+    out = torch.empty((B, G, W), dtype=torch.float32, device=src_bnw.device)
+    call("mla_gather_rows_f32", _p(src_bnw), _p(idx_bg), _p(out), B, N, G, W)
+    return out
+
+
+def lga_prep(xyz, feats_bnc, fps_idx, knn_idx, alpha, beta):
+    B, N, _ = xyz.shape
+    C = feats_bnc.shape[2]
+    G, K = knn_idx.shape[1], knn_idx.shape[2]
+    rows = torch.empty((B * G * K, 2 * C), dtype=torch.bfloat16, device=xyz.device)
+    lc = torch.empty((B, G, 3), dtype=torch.float32, device=xyz.device)
+    call("mla_lga_prep", _p(xyz), _p(feats_bnc), _p(fps_idx), _p(knn_idx), _p(rows), _p(lc), B, N, G, K, C, float(alpha),
+         float(beta))
+    return rows, lc
+
+
+def colstats(x2d):
+    rows, C = x2d.shape
+    mean = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    var = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    P = lib().mla_colstats_blocks(rows)
+    ws = workspace(P * 2 * C * 4, x2d.device)
+    call("mla_colstats_bf16", _p(x2d), _p(mean), _p(var), rows, C, x2d.stride(0), _p(ws), ws.numel())
+    return mean, var
+
+
+def bn_apply(x2d, mean, var, w, b, eps, residual=None, relu=False):
+    rows, C = x2d.shape
+    y = torch.empty_like(x2d)
+    call("mla_bn_apply", _p(x2d), _p(mean), _p(var), _p(w), _p(b), _p(residual), _p(y), rows, C, float(eps), 1 if relu else 0)
+    return y
+
+
+def maxpool_k(x2d, groups, K):
+    C = x2d.shape[1]
+    out = torch.empty((groups, C), dtype=torch.bfloat16, device=x2d.device)
+    call("mla_maxpool_k", _p(x2d), _p(out), groups, K, C)
+    return out
+
+
+def im2col_patch(pix, P, Kpad):
+    B, CT, Himg, Wimg = pix.shape
+    rows = torch.empty((B * (Himg // P) * (Wimg // P), Kpad), dtype=torch.bfloat16, device=pix.device)
+    call("mla_im2col_patch", _p(pix), 1 if pix.dtype == torch.float32 else 0, _p(rows), B, CT, Himg, Wimg, P, Kpad)
+    return rows
+
+
+def avgpool_tokens(x, B, gh, gw, cs):
+    C = x.shape[-1]
+    y = torch.empty((B * (gh // cs) * (gw // cs), C), dtype=torch.bfloat16, device=x.device)
+    call("mla_avgpool_tokens", _p(x), _p(y), B, gh, gw, C, cs)
+    return y
+
+
+def local_attn(q, kv, B, gh, gw, cs, heads, scale):
+    C = q.shape[-1]
+    out = torch.empty_like(q)
+    call("mla_local_attn", _p(q), _p(kv), _p(out), B, gh, gw, C, cs, heads, float(scale))
+    return out

@@ -1,0 +1,112 @@
+"""MLA wrapper (reference: models/mla/model_mla.py:47-309): diffusion branch of forward + wrap policy + freeze."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .action_tokenizer import ActionTokenizer
+from .diffusion import create_diffusion
+from .prismatic import PrismaticVLM
+
+IGNORE_INDEX = -100
+
+
+class MLA(nn.Module):
+    def __init__(self, vlm: PrismaticVLM, action_tokenizer: Optional[ActionTokenizer] = None, token_size: int = 4096,
+                 action_dim: int = 7, future_action_window_size: int = 15, past_action_window_size: int = 0, use_ema: bool = False,
+                 norm_stats=None, use_diff: bool = False, use_pointcloud: bool = False, use_tactile: bool = False,
+                 use_contrastive: bool = False, use_generation: bool = False, gen_image: bool = False, use_roi: bool = False,
+                 gen_pointcloud: bool = False, gen_tactile: bool = False, **kwargs) -> None:
+        super().__init__()
+        self.action_tokenizer = action_tokenizer
+        self.use_diff, self.use_pointcloud, self.use_tactile = use_diff, use_pointcloud, use_tactile
+        self.use_contrastive, self.use_generation = use_contrastive, use_generation
+        self.gen_image, self.use_roi, self.gen_pointcloud, self.gen_tactile = gen_image, use_roi, gen_pointcloud, gen_tactile
+        self.vlm = vlm
+        self.future_action_window_size = future_action_window_size
+        self.vlm.future_action_window_size = future_action_window_size
+        self.past_action_window_size = past_action_window_size
+        self.all_module_keys = ["vlm." + k for k in self.vlm.all_module_keys]
+        if use_ema:
+            raise NotImplementedError("use_ema is non-functional in the reference (no ema_diffusion is ever built, "
+                                      "model_mla.py:47-97, 305-309); keep it False")
+        self.use_ema = use_ema
+        self.norm_stats = norm_stats
+        self._trainable_module_keys: List[str] = []
+        self.last_diff_mse = None
+        if self.use_diff:
+            self.ddim_diffusion = None
+            self.diffusion_steps = 100
+            self.diffusion = create_diffusion(timestep_respacing="", noise_schedule="squaredcos_cap_v2", diffusion_steps=100,
+                                              sigma_small=True, learn_sigma=False)
+
+    @property
+    def trainable_module_keys(self) -> List[str]:
+        return ["vlm." + k for k in self.vlm.trainable_module_keys] + self._trainable_module_keys
+
+    @property
+    def llm_backbone(self):
+        return self.vlm.llm_backbone
+
+    def freeze_backbones(self, stage):
+        self.vlm.freeze_backbones(stage)
+
+    def get_fsdp_wrapping_policy(self) -> Callable:
+        """model_mla.py:279-303 (same class sets as the VLM's policy)."""
+        return self.vlm.get_fsdp_wrapping_policy()
+
+    def forward(self, input_ids=None, attention_mask=None, images=None, next_images=None, camera_name=None, point_cloud=None,
+                next_point_cloud=None, tactile=None, next_tactile=None, labels=None, actions=None, proprio=None, gripper_xyz=None,
+                inputs_embeds=None, past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, repeated_diffusion_steps: int = 4, action_masks=None, use_diff: Optional[bool] = None,
+                noise: Optional[torch.Tensor] = None, timestep: Optional[torch.Tensor] = None) -> Tuple[Dict, object]:
+        """model_mla.py:118-234. ``noise`` / ``timestep`` (not in the reference signature) let tests inject the random
+        draws; when omitted they are drawn in the reference's order: randn_like(actions_future) then randint (:178-179)."""
+        if use_diff is not None:
+            self.use_diff = use_diff
+        if not self.use_diff:
+            raise NotImplementedError("the autoregressive branch is dead code in the reference (SURVEY Appendix A #15)")
+        R = repeated_diffusion_steps
+        rep = lambda v: v.repeat(R, *([1] * (v.ndimension() - 1)))  # noqa: E731
+        proprio = rep(proprio)
+        actions = rep(actions)
+        actions_future = actions[:, -(self.future_action_window_size + 1):, :]
+        input_ids, attention_mask, labels = rep(input_ids), rep(attention_mask), rep(labels)
+        if action_masks is not None:
+            action_masks = rep(action_masks)
+        images = {k_: rep(v) for k_, v in images.items()} if isinstance(images, dict) else rep(images)
+        if self.use_pointcloud:
+            point_cloud = rep(point_cloud)
+        if noise is None:
+            noise = torch.randn_like(actions_future)
+        if timestep is None:
+            timestep = torch.randint(0, self.diffusion.num_timesteps, (actions_future.size(0),), device=actions.device)
+        x = self.diffusion.q_sample(actions_future, timestep, noise)
+
+        self.vlm.image_repeat_hint = R
+        try:
+            output, noise_pred, generation_outputs, generation_losses = self.vlm(
+                input_ids=input_ids, attention_mask=attention_mask, images=images, next_images=next_images,
+                camera_name=camera_name, point_cloud=point_cloud if self.use_pointcloud else None,
+                next_point_cloud=next_point_cloud, tactile=tactile, next_tactile=next_tactile, labels=labels, x=x, t=timestep,
+                proprio=proprio, gripper_xyz=gripper_xyz, use_cache=use_cache, output_attentions=output_attentions,
+                output_hidden_states=output_hidden_states, return_dict=return_dict, use_diff=self.use_diff)
+        finally:
+            self.vlm.image_repeat_hint = 1
+        assert noise_pred.shape == noise.shape == actions_future.shape
+        zero = lambda: torch.tensor(0, dtype=torch.float32)  # noqa: E731
+        loss_dict = {"total_loss": zero(), "img_pc_contrastive_loss": zero(), "tactile_contrastive_loss": zero(),
+                     "diff_loss": zero(), "image_gen_loss": zero(), "point_cloud_gen_loss": zero(), "tactile_gen_loss": zero()}
+        diff_loss = ((noise_pred.float() - noise.float()) ** 2).mean()
+        self.last_diff_mse = diff_loss.detach().clone()
+        total = diff_loss
+        if self.use_contrastive:
+            loss_dict["img_pc_contrastive_loss"] = output.img_pc_contrastive_loss
+            total = total + output.img_pc_contrastive_loss.float()
+        # the reference's `total_loss` and `diff_loss` are one tensor mutated in place (model_mla.py:215-229), so the
+        # reported diff_loss equals total_loss; the true diffusion MSE is kept in self.last_diff_mse
+        loss_dict["total_loss"] = total
+        loss_dict["diff_loss"] = total
+        return loss_dict, output

@@ -1,0 +1,267 @@
+"""PrismaticVLM drop-in (reference: models/vlm/prismatic.py:149-287 constructor, :415-536 freeze_backbones,
+:598-769 get_fused_tokens, :840-1144 forward) for the diffusion training path.
+
+Differences from the reference that do not change results:
+* the per-sample Python splice loop with .item() syncs (:981-1038) is a single vectorised index computation on the GPU
+  followed by one HIP row gather;
+* FinalLayer runs on the T action rows only (the reference runs it on all S positions and then slices, :1115-1126;
+  RmsNorm + Mlp are row-wise, so the selected rows are identical);
+* visualize_generation_simple / print side effects (:1129-1135) are not reproduced.
+Post-training generation heads (use_generation, BASELINE config[3]) are not built yet.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbones import LLMBackbone
+from .diffusion import ActionEmbedder, FinalLayer, LabelEmbedder, TimestepEmbedder
+from .fuser import get_camera_params, get_projection_func
+from .modeling_outputs import CausalLMOutputWithPast
+from .nn_utils import MLPProjector
+from .point_tokenizer import PointTokenizer
+from .vision_tokenizer import MLP_GELU, VisionTokenizer
+
+IGNORE_INDEX = -100
+
+
+def build_splice_plan(input_ids, attention_mask, labels, n_fused: int, ins: int, tag_0: int = 2):
+    """Index arithmetic of the splice loop prismatic.py:981-1038, vectorised (no host sync).
+
+    Final sequence per row = [BOS | fused (n_fused) | text[1:pos] | proprio, t, x.. (ins rows) | text[pos:]] where pos is
+    the LAST index of ``tag_0`` in input_ids (the reference's `last_true_indice` is k = pos + n_fused).
+    Source rows live in a per-sample pool laid out [text (L) | fused (n_fused) | inserted (ins)].
+    Returns (flat_pool_row_index [B*S], k [B,1], spliced attention mask [B,S] bool, spliced labels [B,S])."""
+    B, L = input_ids.shape
+    dev = input_ids.device
+    ar_l = torch.arange(L, device=dev)
+    pos = torch.where(input_ids == tag_0, ar_l[None], -1).max(dim=1).values
+    k = (pos + n_fused)[:, None]
+    S = L + n_fused + ins
+    s = torch.arange(S, device=dev)[None]
+    text_j = torch.where(s < k, s - n_fused, s - n_fused - ins)
+    text_j = torch.where(s == 0, torch.zeros_like(text_j), text_j)
+    is_text = (s == 0) | ((s > n_fused) & (s < k)) | (s >= k + ins)
+    src = torch.where(is_text, text_j, torch.where(s <= n_fused, L + s - 1, L + n_fused + (s - k)))
+    flat = (src + torch.arange(B, device=dev)[:, None] * S).reshape(-1)
+    tj = text_j.clamp(0, L - 1).expand(B, S)
+    mask = None
+    if attention_mask is not None:
+        mask = torch.where(is_text, attention_mask.gather(1, tj).bool(), torch.ones_like(is_text))
+    labs = None
+    if labels is not None:
+        labs = torch.where(is_text, labels.gather(1, tj), torch.full_like(tj, IGNORE_INDEX))
+    return flat, k, mask, labs
+
+
+class PrismaticVLM(nn.Module):
+    def __init__(self, model_id: str, llm_backbone: LLMBackbone, enable_mixed_precision_training: bool = True, action_dim=7,
+                 token_size=4096, future_action_window_size=0, past_action_window_size=0, class_dropout_prob=0.0,
+                 norm_stats=None, use_diff=False, use_pointcloud: bool = False, use_tactile: bool = False,
+                 use_contrastive: bool = False, llm_vision_layers: int = 1, use_generation: bool = True, gen_image: bool = False,
+                 use_roi: bool = False, gen_pointcloud: bool = True, gen_tactile: bool = True, **kwargs) -> None:
+        super().__init__()
+        self.model_family, self.model_id = "prismatic", model_id
+        self.llm_backbone = llm_backbone
+        self.enable_mixed_precision_training = enable_mixed_precision_training
+        self.token_size, self.use_diff = token_size, use_diff
+        self.use_pointcloud, self.use_tactile, self.use_contrastive = use_pointcloud, use_tactile, use_contrastive
+        self.llm_vision_layers = llm_vision_layers
+        self.use_generation = use_generation
+        self.gen_image = gen_image and use_generation
+        self.use_roi = use_roi
+        self.gen_pointcloud = gen_pointcloud and use_generation
+        self.gen_tactile = gen_tactile and use_generation
+        if use_generation:
+            raise NotImplementedError("post-training generation heads (models/mla/generation, BASELINE config[3]) are not "
+                                      "built yet; construct with use_generation=False")
+        if use_tactile:
+            raise NotImplementedError("tactile inputs are outside BASELINE configs 0-4")
+        self.string2idx = {}
+        for trigger in ["True", "False", "Yes", "No"] + [chr(ord("A") + i) for i in range(26)]:
+            ids = self.llm_backbone.tokenizer.encode(trigger, add_special_tokens=False)
+            assert len(ids) == 1, f'String "{trigger}" is tokenized as more than one token!'
+            self.string2idx[trigger] = ids[0]
+        self.norm_stats, self.class_dropout_prob = norm_stats, class_dropout_prob
+        self.future_action_window_size, self.action_dim = future_action_window_size, action_dim
+        self.tactile_dim = 12 if action_dim == 7 else 24    # defined unconditionally
+
+        self.image_hidden_dim = 1024
+        self.vision_tower_2d = VisionTokenizer(input_size=self.image_hidden_dim)
+        self.projector_2d = MLP_GELU(self.image_hidden_dim, token_size, 2)
+        if self.use_pointcloud:
+            self.vision_tower_3d = PointTokenizer(in_channels=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True)
+            self.projector_3d = MLPProjector(self.vision_tower_3d.embed_dim, token_size)
+        self.proprio_embedder = ActionEmbedder(action_size=action_dim, hidden_size=token_size)
+        if self.use_diff:
+            self.x_embedder = ActionEmbedder(action_size=action_dim, hidden_size=token_size)
+            self.t_embedder = TimestepEmbedder(token_size)
+            self.z_embedder = LabelEmbedder(in_size=token_size, hidden_size=token_size, dropout_prob=self.class_dropout_prob)
+            self.final_layer = FinalLayer(token_size, action_dim)
+
+        self.all_module_keys = ["vision_tower_2d", "projector_2d", "llm_backbone", "proprio_embedder"]
+        if self.use_diff:
+            self.all_module_keys.extend(["x_embedder", "t_embedder", "final_layer"])
+        if self.use_pointcloud:
+            self.all_module_keys.extend(["vision_tower_3d", "projector_3d"])
+        self.trainable_module_keys: List[str] = []
+        self.vision_backbone_requires_grad = False
+        self.image_repeat_hint = 1   # set by MLA.forward: inputs are R tiled copies (model_mla.py:159-176)
+
+        self.initialize_weights()
+        if self.use_pointcloud:
+            self.vision_tower_3d.initialize_weights()
+
+    # ------------------------------------------------------------------------------------------ init / freeze
+    def initialize_weights(self):
+        """prismatic.py:299-321: Xavier on EVERY nn.Linear / LayerNorm in the tree (including the LLM, Appendix A #16),
+        then normal(0.02) on the embedders and zeros on final_layer.mlp.fc2."""
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+            elif isinstance(module, nn.LayerNorm):
+                nn.init.constant_(module.weight, 1.0)
+                nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        if self.use_diff:
+            for lin in (self.x_embedder.mlp.fc1, self.x_embedder.mlp.fc2, self.proprio_embedder.mlp.fc1,
+                        self.proprio_embedder.mlp.fc2, self.t_embedder.mlp[0], self.t_embedder.mlp[2]):
+                nn.init.normal_(lin.weight, std=0.02)
+            nn.init.constant_(self.final_layer.mlp.fc2.weight, 0)
+            nn.init.constant_(self.final_layer.mlp.fc2.bias, 0)
+
+    def get_vision_tower_2d(self):
+        return self.vision_tower_2d
+
+    def encode_images(self, images):
+        return self.vision_tower_2d(images, self.projector_2d, repeat=self.image_repeat_hint)
+
+    def freeze_backbones(self, stage: str) -> None:
+        """prismatic.py:415-536."""
+        if stage == "pretrain":
+            self.vision_tower_2d.requires_grad_(True)
+            self.llm_backbone.requires_grad_(True)
+            self.projector_2d.requires_grad_(True)
+            if self.use_pointcloud:
+                self.vision_tower_3d.requires_grad_(True)
+                self.projector_3d.requires_grad_(True)
+            self.trainable_module_keys = ["vision_tower_2d", "projector_2d", "llm_backbone", "proprio_embedder"]
+            if self.use_diff:
+                self.trainable_module_keys.extend(["x_embedder", "t_embedder", "final_layer"])
+            if self.use_pointcloud:
+                self.trainable_module_keys.extend(["vision_tower_3d", "projector_3d"])
+            self.vision_backbone_requires_grad = True
+        elif stage in {"finetune", "post-training"}:
+            if stage == "post-training" and not self.use_generation:
+                raise ValueError("post-training needs the generation manager")
+            self.vision_tower_2d.requires_grad_(False)
+            self.llm_backbone.requires_grad_(True)
+            self.projector_2d.requires_grad_(True)
+            if self.use_pointcloud:
+                self.vision_tower_3d.requires_grad_(False)
+                self.projector_3d.requires_grad_(True)
+            self.trainable_module_keys = ["llm_backbone", "projector_2d", "proprio_embedder"]
+            if self.use_diff:
+                self.trainable_module_keys.extend(["x_embedder", "t_embedder", "final_layer"])
+            if self.use_pointcloud:
+                self.trainable_module_keys.extend(["projector_3d"])
+            self.vision_backbone_requires_grad = False
+        else:
+            raise ValueError(f"Stage `{stage}` is not supported! Try < pretrain | finetune | post-training >")
+
+    def get_fsdp_wrapping_policy(self):
+        """prismatic.py:560-596: union of {VisionTokenizer, PointTokenizer}, the LLM's decoder-layer policy and
+        {MLPProjector, MLP_GELU}; anything else folds into the root unit."""
+        llm_policy = self.llm_backbone.get_fsdp_wrapping_policy()
+        classes = (VisionTokenizer, PointTokenizer, MLPProjector, MLP_GELU)
+        return lambda module: isinstance(module, classes) or llm_policy(module)
+
+    # ------------------------------------------------------------------------------------------ fused tokens
+    def get_fused_tokens(self, images, pointcloud, tactile, gripper_xyz, camera_name):
+        """prismatic.py:598-769 -> (fused [B, 513, H], patch_indices [B, 256, 2], valid_mask [B, 256], None, None, None)."""
+        if self.use_tactile and tactile is not None:
+            raise NotImplementedError("tactile tokens")
+        get_camera_params(camera_name)  # raises on unknown names, like camera.py:54-56
+        views: Dict[str, torch.Tensor] = images if isinstance(images, dict) else {"front_image": images}
+        assert "front_image" in views, "front_image must be present in multi-view images"
+        front, _ = self.encode_images(views["front_image"])
+        front = torch.stack(front, dim=0)
+        B, n_img, H = front.shape
+        if self.use_pointcloud and pointcloud is not None:
+            pc_emb, centers = self.vision_tower_3d(pointcloud)
+            pc_tok = self.projector_3d(pc_emb)
+            patch_indices, valid_mask = get_projection_func(camera_name)(
+                centers, image_size_resize=(672, 672), vision_strides={"patch_stride": 14, "conv_stride": 3})
+        else:
+            pc_tok = torch.zeros((B, n_img, self.token_size), dtype=front.dtype, device=front.device)
+            patch_indices = torch.zeros((B, n_img, 2), dtype=torch.long, device=front.device)
+            valid_mask = torch.zeros((B, n_img), dtype=torch.bool, device=front.device)
+        assert pc_tok.shape[1] == front.shape[1], f"Token count mismatch: PC={pc_tok.shape[1]}, Front Img={front.shape[1]}"
+        parts = [pc_tok, front]
+        for key in views:
+            if key != "front_image":
+                extra, _ = self.encode_images(views[key])
+                parts.append(torch.stack(extra, dim=0))
+        parts.append(torch.zeros((B, 1, self.token_size), dtype=front.dtype, device=front.device))  # zero tactile slot (:752-763)
+        return parts, patch_indices, valid_mask, None, None, None
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x=None, t=None, z=None, proprio=None, gripper_xyz=None, input_ids=None, attention_mask=None, images=None,
+                camera_name=None, point_cloud=None, tactile=None, labels=None, inputs_embeds=None, past_key_values=None,
+                use_cache=None, output_attentions=None, output_hidden_states=True, return_dict=None, multimodal_indices=None,
+                gen_discret_action=None, use_diff=None, next_images=None, next_point_cloud=None, next_tactile=None, **kwargs):
+        if use_diff is not None:
+            self.use_diff = use_diff
+        if not self.use_diff:
+            raise NotImplementedError("the autoregressive branch is dead code in the reference (SURVEY Appendix A #15)")
+        if past_key_values is not None or input_ids.shape[1] == 1 or images is None:
+            raise RuntimeError("Invalid `forward()` call! (generation / cache paths are inference-side)")
+        bf16 = torch.bfloat16
+        proprio = proprio.to(bf16) if proprio is not None else None      # prismatic.py:873-880
+        x = x.to(bf16) if x is not None else None
+        t = t.to(bf16) if t is not None else None
+        tag_0 = 2 if self.training else 29871                              # :882-887
+
+        parts, patch_indices, valid_mask, _, _, _ = self.get_fused_tokens(images, point_cloud, tactile, gripper_xyz, camera_name)
+        n_fused = sum(p.shape[1] for p in parts)
+        N_pc = N_img = 256
+        pc_idx = (1, 1 + N_pc)
+        img_idx = (pc_idx[1], pc_idx[1] + N_img)
+
+        text_emb = self.llm_backbone.embed_input_ids(input_ids)             # [B, L, H]
+        proprio_e = self.proprio_embedder(proprio)                          # [B, 1, H]
+        x_e = self.x_embedder(x)                                            # [B, T, H]
+        t_e = self.t_embedder(t).unsqueeze(1)                               # [B, 1, H]
+        B, L, H = text_emb.shape
+        T = x_e.shape[1]
+        ins = proprio_e.shape[1] + 1 + T
+        dev = input_ids.device
+
+        # ---- vectorised form of the per-sample splice loop (:981-1038)
+        flat, k, fused_attention_mask, fused_labels = build_splice_plan(input_ids, attention_mask, labels, n_fused, ins, tag_0)
+        S = L + n_fused + ins
+        P = S
+        pool = torch.cat([text_emb] + parts + [proprio_e, t_e, x_e], dim=1).reshape(B * P, H)
+        fused_embeddings = ops.gather_rows(pool, flat).view(B, S, H)
+
+        output: CausalLMOutputWithPast = self.llm_backbone(
+            input_ids=None, attention_mask=fused_attention_mask, position_ids=None, past_key_values=None,
+            inputs_embeds=fused_embeddings, labels=fused_labels, use_cache=use_cache, output_attentions=output_attentions,
+            output_hidden_states=True, return_dict=True, pc_token_indices=pc_idx, img_token_indices=img_idx,
+            tac_token_indices=None, patch_correspondence_indices=patch_indices, correspondence_valid_mask=valid_mask,
+            positive_pc_indices_for_tac=None, linear_positive_img_indices_for_tac=None,
+            compute_token_contrastive_loss=self.use_contrastive, compute_tactile_contrastive_loss=False)
+
+        # ---- action read-out (:1115-1126): rows k+2 .. k+2+T of the last hidden state -> FinalLayer
+        last_hidden = output.hidden_states[-1]
+        rows = (torch.arange(B, device=dev)[:, None] * S + k + 2 + torch.arange(T, device=dev)[None]).reshape(-1)
+        picked = ops.gather_rows(last_hidden.reshape(B * S, H), rows)
+        noise_pred = self.final_layer(picked).view(B, T, -1)
+        if self.training:
+            return output, noise_pred, {}, {}
+        return output, noise_pred

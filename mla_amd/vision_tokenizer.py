@@ -1,0 +1,121 @@
+"""Encoder-free vision tokenizer (reference: models/mla/image/vision_tokenizer.py:14-159), batched on HIP kernels.
+
+Same module tree / parameter names as the reference (patch_embedding, class_embedding, split_embedding,
+local_attention.{q,kv,proj}, global_attention.{q,kv,proj}); GlobalAttention's output is discarded by the reference
+(:142,149) so it is never computed here -- its parameters exist for state-dict parity and receive no gradient.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip, ops
+from .llama import Linear
+
+
+class _AttnParams(nn.Module):
+    def __init__(self, input_size, with_stride=None, num_heads=8):
+        super().__init__()
+        if with_stride is not None:
+            self.conv_stride = with_stride
+        self.num_heads = num_heads
+        self.scale = input_size ** -0.5   # NB: input_size, not head_dim (vision_tokenizer.py:19,54)
+        self.q = nn.Sequential(nn.LayerNorm(input_size), Linear(input_size, input_size, bias=False))
+        self.kv = nn.Sequential(nn.LayerNorm(input_size), Linear(input_size, input_size * 2, bias=False))
+        self.proj = Linear(input_size, input_size)
+
+
+class LocalAttention(_AttnParams):
+    def __init__(self, input_size, conv_stride, num_heads=8):
+        super().__init__(input_size, conv_stride, num_heads)
+
+
+class GlobalAttention(_AttnParams):
+    def __init__(self, input_size, num_heads=8):
+        super().__init__(input_size, None, num_heads)
+
+
+class MLP_GELU(nn.Module):
+    """vision_tokenizer.py:79-89 (projector_2d = MLP_GELU(1024, token_size, 2)); trainable -> autograd ops."""
+
+    def __init__(self, input_size, hidden_size, depth):
+        super().__init__()
+        layers = [Linear(input_size, hidden_size)]
+        for _ in range(1, depth):
+            layers.append(nn.GELU())
+            layers.append(Linear(hidden_size, hidden_size))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, x):
+        for m in self.mlp:
+            x = ops.act(x, hip.ACT_GELU_ERF) if isinstance(m, nn.GELU) else m(x)
+        return x
+
+
+class VisionTokenizer(nn.Module):
+    def __init__(self, input_size):
+        super().__init__()
+        self.is_loaded = True
+        self.hidden_size = input_size
+        # the reference holds a CLIPImageProcessor(size=672, crop 672, rescale, normalise) here (:98-105); image
+        # preprocessing is the data side of the boundary -- only its settings are kept.
+        self.image_processor = SimpleNamespace(size=672, crop_size=672, do_resize=True, do_center_crop=True, do_normalize=True,
+                                               do_rescale=True, image_mean=[0.48145466, 0.4578275, 0.40821073],
+                                               image_std=[0.26862954, 0.26130258, 0.27577711])
+        self.patch_stride = 14
+        self.conv_stride = 3
+        self.patch_embedding = nn.Conv2d(3, input_size, kernel_size=14, stride=14, bias=False)
+        self.class_embedding = nn.Parameter(torch.randn(input_size))
+        self.split_embedding = nn.Parameter(torch.randn(input_size))
+        self.local_attention = LocalAttention(input_size, self.conv_stride)
+        self.global_attention = GlobalAttention(input_size)
+
+    @property
+    def dtype(self):
+        return self.patch_embedding.weight.dtype
+
+    @property
+    def device(self):
+        return self.patch_embedding.weight.device
+
+    def tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """[B, 4, 672, 672] (RGB + mask channel, fp32 or bf16) -> [B, 256, C] bf16 tokens (before the projector)."""
+        if any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("trainable vision tokenizer (stage 'pretrain') is not built; SFT/post-training freeze it")
+        B, CT, Hi, Wi = pixel_values.shape
+        P, cs, C = self.patch_stride, self.conv_stride, self.hidden_size
+        gh, gw = Hi // P, Wi // P
+        masks = pixel_values[:, -1]
+        if not bool((masks == 1).all()):
+            raise NotImplementedError("cropped pixel masks: only the all-ones mask yields the 256 tokens the reference's "
+                                      "N_img = 256 layout needs (models/vlm/prismatic.py:932-933)")
+        with torch.no_grad():
+            kreal = 3 * P * P
+            kpad = ((kreal + 31) // 32) * 32
+            rows = hip.im2col_patch(pixel_values.contiguous(), P, kpad)
+            w = F.pad(self.patch_embedding.weight.reshape(C, kreal), (0, kpad - kreal)).contiguous()
+            pe = hip.gemm(rows, w)                                             # [B*gh*gw, C]
+            red = hip.avgpool_tokens(pe, B, gh, gw, cs)                        # [B*256, C]
+            la = self.local_attention
+            qv = hip.gemm(hip.layernorm_fwd(red, la.q[0].weight, la.q[0].bias, la.q[0].eps), la.q[1].weight)
+            kv = hip.gemm(hip.layernorm_fwd(pe, la.kv[0].weight, la.kv[0].bias, la.kv[0].eps), la.kv[1].weight)
+            agg = hip.local_attn(qv, kv, B, gh, gw, cs, la.num_heads, la.scale)
+            tok = hip.gemm(agg, la.proj.weight, bias=la.proj.bias, residual=red)
+        return tok.view(B, (gh // cs) * (gw // cs), C)
+
+    def forward(self, pixel_values, modules, repeat: int = 1):
+        """Reference signature (pixel_values, projector) -> (list of [256, token_size] tokens, list of [h, w]).
+        ``repeat``: the batch is ``repeat`` tiled copies of its first B/repeat samples (MLA.forward tiles every input
+        R times, models/mla/model_mla.py:159-169); the frozen, deterministic tower then runs once per distinct image."""
+        B = pixel_values.shape[0]
+        if repeat > 1:
+            tok = self.tokens(pixel_values[: B // repeat]).repeat(repeat, 1, 1)
+        else:
+            tok = self.tokens(pixel_values)
+        out = modules(tok)
+        h = w = int(round(out.shape[1] ** 0.5))
+        hw = torch.tensor([h, w], dtype=torch.long, device=out.device)
+        return list(out.unbind(0)), [hw] * B

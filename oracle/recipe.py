@@ -1,0 +1,79 @@
+"""Deterministic weights and synthetic batches shared by oracle/capture_golden.py (build container, real reference)
+and the tests (GPU box, no reference): everything is a function of the tensor's NAME and a seed, so no large weight or
+image files have to be committed -- only the captured outputs are stored under tests/golden/."""
+import zlib
+
+import torch
+
+TINY_LLAMA = dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=9, num_attention_heads=2,
+                  rms_norm_eps=1e-5)
+TOKEN_SIZE = 256
+PAD_ID = 512  # tokenizer.pad_token_id == base vocab size (llama2.py:75-77); embedding table has vocab + 1 rows
+
+
+def _gen(name: str, seed: int = 0) -> torch.Generator:
+    return torch.Generator().manual_seed((zlib.crc32(name.encode()) + 1000003 * seed) & 0x7FFFFFFF)
+
+
+def det_randn(name, shape, scale=1.0, seed=0):
+    return torch.randn(*shape, generator=_gen(name, seed)) * scale
+
+
+def det_weight(name: str, shape, seed: int = 0) -> torch.Tensor:
+    """Initialisation recipe by parameter role (all fp32)."""
+    shape = tuple(shape)
+    leaf = name.split(".")[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.long)
+    if leaf == "running_mean":
+        return torch.zeros(shape)
+    if leaf == "running_var":
+        return torch.ones(shape)
+    if len(shape) <= 1 and leaf == "weight":                      # norm / BatchNorm scales
+        return 1.0 + det_randn(name, shape, 0.1, seed)
+    if leaf == "bias":
+        return det_randn(name, shape, 0.05, seed)
+    if leaf in ("cls_token", "pos_embed", "class_embedding", "split_embedding"):
+        return det_randn(name, shape, 0.02, seed)
+    if "embed_tokens" in name:
+        return det_randn(name, shape, 0.5, seed)
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return det_randn(name, shape, fan_in ** -0.5, seed)
+
+
+def make_state_dict(shapes: dict, seed: int = 0) -> dict:
+    return {k: det_weight(k, s, seed) for k, s in shapes.items()}
+
+
+def make_batch(B: int = 2, L: int = 16, R: int = 2, ragged: bool = True, seed: int = 0, vocab: int = 512, n_points: int = 1024,
+               img: int = 672):
+    """Synthetic batch with the collator's schema (util/data_utils.py:179-193) + the random draws of one step."""
+    g = _gen("batch", seed)
+    rgb = torch.randn(B, 3, img, img, generator=g)
+    images = torch.cat([rgb, torch.ones(B, 1, img, img)], dim=1)
+    lo = torch.tensor([0.0, -0.4, 0.75])
+    hi = torch.tensor([0.6, 0.4, 1.25])
+    pc = lo + (hi - lo) * torch.rand(B, n_points, 3, generator=g)
+    ids = torch.randint(3, vocab - 12, (B, L), generator=g)
+    ids[:, 0] = 1
+    lens = [L] * B
+    if ragged and B > 1:
+        lens[1] = L - 3
+    for b in range(B):
+        ids[b, lens[b] - 1] = 2
+        ids[b, lens[b]:] = PAD_ID
+    attention_mask = ids != PAD_ID
+    labels = torch.full_like(ids, -100)
+    for b in range(B):
+        labels[b, lens[b] - 1] = 2        # diffusion mode keeps only the final </s> (datasets.py:158-164)
+    actions = torch.rand(B, 1, 7, generator=g) * 2 - 1
+    proprio = torch.rand(B, 1, 7, generator=g) * 2 - 1
+    Bp = B * R
+    draws = dict(noise=torch.randn(Bp, 1, 7, generator=g), timestep=torch.randint(0, 100, (Bp,), generator=g),
+                 fps_start0=torch.randint(0, n_points, (Bp,), generator=g),
+                 fps_start1=torch.randint(0, n_points // 2, (Bp,), generator=g))
+    batch = dict(input_ids=ids, attention_mask=attention_mask, labels=labels, images={"front_image": images}, point_cloud=pc,
+                 actions=actions, proprio=proprio, action_masks=torch.ones(B, 1, dtype=torch.bool), camera_name="rlbench_front")
+    return batch, draws

@@ -58,6 +58,10 @@ def causal_attention(q, k, v, seqlens: Optional[torch.Tensor] = None, zero_pad_r
     scores = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(D)
     mask = torch.full((S, S), float("-inf"), dtype=scores.dtype).triu(1)
     scores = scores + mask
+    if seqlens is not None and not zero_pad_rows:
+        # eager path: _update_causal_mask (modeling_llama.py:1081-1103) also masks padded KEY columns for every query
+        keypad = torch.arange(S)[None, :] >= seqlens[:, None]               # [B, S]
+        scores = scores.masked_fill(keypad[:, None, None, :], float("-inf"))
     p = torch.softmax(scores.float(), dim=-1).to(q.dtype)
     out = torch.matmul(p, v)
     if seqlens is not None and zero_pad_rows:
@@ -71,7 +75,7 @@ def swiglu_mlp(x, w_gate, w_up, w_down):
     return F.linear(F.silu(F.linear(x, w_gate)) * F.linear(x, w_up), w_down)
 
 
-def decoder_layer(x, p: dict, cos_half, sin_half, n_heads: int, eps: float, seqlens=None):
+def decoder_layer(x, p: dict, cos_half, sin_half, n_heads: int, eps: float, seqlens=None, zero_pad_rows: bool = True):
     """LlamaDecoderLayer.forward, modeling_llama.py:695-767 (pre-norm residual block). p holds the 9 weights with
     the reference's leaf names (input_layernorm.weight, self_attn.{q,k,v,o}_proj.weight, post_attention_layernorm.weight,
     mlp.{gate,up,down}_proj.weight)."""
@@ -82,7 +86,7 @@ def decoder_layer(x, p: dict, cos_half, sin_half, n_heads: int, eps: float, seql
     k = F.linear(h, p["self_attn.k_proj.weight"]).view(B, S, n_heads, D).transpose(1, 2)
     v = F.linear(h, p["self_attn.v_proj.weight"]).view(B, S, n_heads, D).transpose(1, 2)
     q, k = apply_rope(q, k, cos_half, sin_half)
-    a = causal_attention(q, k, v, seqlens).transpose(1, 2).reshape(B, S, Hd)
+    a = causal_attention(q, k, v, seqlens, zero_pad_rows).transpose(1, 2).reshape(B, S, Hd)
     x = x + F.linear(a, p["self_attn.o_proj.weight"])
     h = rmsnorm(x, p["post_attention_layernorm.weight"], eps)
     return x + swiglu_mlp(h, p["mlp.gate_proj.weight"], p["mlp.up_proj.weight"], p["mlp.down_proj.weight"])
@@ -138,10 +142,21 @@ def cosine_beta_schedule(num_steps: int = 100, max_beta: float = 0.999) -> np.nd
                     dtype=np.float64)
 
 
+def respaced_betas(num_steps: int = 100) -> np.ndarray:
+    """SpacedDiffusion.__init__ models/diffusion/respace.py:75-89 with use_timesteps = all steps: the betas are
+    RE-DERIVED from the base process' cumulative products (1 - ac_i / ac_{i-1}), which differs from the base betas in
+    the last float64 bits -- and these are the betas the training tables are built from."""
+    base_ac = np.cumprod(1.0 - cosine_beta_schedule(num_steps), axis=0)
+    last, out = 1.0, []
+    for a in base_ac:
+        out.append(1 - a / last)
+        last = a
+    return np.array(out)
+
+
 def diffusion_tables(num_steps: int = 100):
-    """GaussianDiffusion.__init__ tables, gaussian_diffusion.py:166-184 (float64)."""
-    betas = cosine_beta_schedule(num_steps)
-    ac = np.cumprod(1.0 - betas, axis=0)
+    """GaussianDiffusion.__init__ tables, gaussian_diffusion.py:166-184 (float64), on the respaced betas."""
+    ac = np.cumprod(1.0 - respaced_betas(num_steps), axis=0)
     return np.sqrt(ac), np.sqrt(1.0 - ac)
 
 

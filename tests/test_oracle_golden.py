@@ -1,0 +1,112 @@
+"""CPU: the oracle (oracle/*.py) against vectors captured from the REAL reference (tests/golden/*.npz, produced by
+oracle/capture_golden.py in the build container). This is what pins the oracle; the GPU tests then compare the HIP
+path with the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mla_oracle, recipe
+from oracle import torch_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def comp():
+    return np.load(os.path.join(G, "components.npz"))
+
+
+@pytest.fixture(scope="module")
+def e2e():
+    return np.load(os.path.join(G, "mla_tiny_e2e.npz"), allow_pickle=True)
+
+
+def test_action_tokenizer_bit_exact(comp):
+    at = O.ActionTokenizerOracle(32000)
+    ids = at.encode_ids(comp["at_actions"])
+    assert np.array_equal(ids, comp["at_ids"])
+    assert np.array_equal(at.decode_token_ids_to_actions(ids), comp["at_decoded"])
+    # SURVEY 8a-19 known answers
+    a = np.array([-1, -0.999, -0.5, 0, 1e-9, 0.5, 0.996, 1, 1.5, -2.0])
+    assert at.encode_ids(a).tolist() == [31999, 31999, 31936, 31872, 31872, 31808, 31745, 31744, 31744, 31999]
+
+
+def test_diffusion_schedule_and_q_sample(comp):
+    sa, s1 = O.diffusion_tables(100)
+    assert np.array_equal(O.respaced_betas(100), comp["betas"])
+    assert np.array_equal(sa, comp["sqrt_ac"]) and np.array_equal(s1, comp["sqrt_1mac"])
+    out = O.q_sample(torch.from_numpy(comp["qs_x0"]), torch.from_numpy(comp["qs_t"]), torch.from_numpy(comp["qs_noise"]))
+    assert np.array_equal(out.numpy(), comp["qs_out"])
+    assert abs(comp["betas"][0] - 6.3128e-4) < 1e-7 and abs(sa[50] - 0.69156680) < 1e-7  # SURVEY 8a-2 constants
+
+
+@pytest.mark.parametrize("cam", ["rlbench_front", "franka_right", "franka_front"])
+def test_projection_exact(comp, cam):
+    idx, valid = O.project_points(torch.from_numpy(comp["proj_pts"]), cam)
+    assert np.array_equal(idx.numpy(), comp[f"proj_idx_{cam}"])
+    assert np.array_equal(valid.numpy(), comp[f"proj_valid_{cam}"])
+
+
+def _sd(prefix, shapes):
+    return {k: recipe.det_weight(prefix + k, s) for k, s in shapes.items()}
+
+
+def test_point_tokenizer_indices_and_tokens(comp):
+    from tests_shapes import MLA_TINY_SHAPES
+    sd = recipe.make_state_dict({k: v for k, v in MLA_TINY_SHAPES.items() if k.startswith("vlm.vision_tower_3d.")})
+    batch, draws = recipe.make_batch(R=1)
+    with torch.no_grad():
+        tok, ctr, dbg = O.point_tokenizer(batch["point_cloud"], mla_oracle.point_weights(sd), [draws["fps_start0"], draws["fps_start1"]])
+    assert np.array_equal(dbg[0][0].numpy(), comp["pt_fps0"]) and np.array_equal(dbg[1][0].numpy(), comp["pt_fps1"])
+    assert np.array_equal(np.sort(dbg[0][1].numpy(), -1), comp["pt_knn0_sorted"])
+    assert np.array_equal(np.sort(dbg[1][1].numpy(), -1), comp["pt_knn1_sorted"])
+    assert np.allclose(ctr.numpy(), comp["pt_centers"], atol=0)
+    assert np.allclose(tok[:, :, :64].numpy(), comp["pt_tokens_slice"], rtol=1e-4, atol=1e-4)
+
+
+def test_vision_tokenizer_tokens(comp):
+    from tests_shapes import MLA_TINY_SHAPES
+    sd = recipe.make_state_dict({k: v for k, v in MLA_TINY_SHAPES.items()
+                                 if k.startswith("vlm.vision_tower_2d.") or k.startswith("vlm.projector_2d.")})
+    batch, _ = recipe.make_batch(R=1)
+    P = "vlm.projector_2d.mlp."
+    with torch.no_grad():
+        tok = O.vision_tokenizer(batch["images"]["front_image"], mla_oracle.vision_weights(sd),
+                                 dict(w0=sd[P + "0.weight"], b0=sd[P + "0.bias"], w2=sd[P + "2.weight"], b2=sd[P + "2.bias"]))
+    assert np.allclose(tok[:, :, :64].numpy(), comp["vt_tokens_slice"], rtol=2e-4, atol=2e-4)
+
+
+def test_mla_e2e_forward_backward_matches_reference(e2e):
+    """Whole tiny-MLA step in fp32 (reference mode A): losses, activations and gradients."""
+    from tests_shapes import MLA_TINY_SHAPES
+    sd = recipe.make_state_dict(MLA_TINY_SHAPES)
+    names = [str(n) for n in e2e["grad_names"]]
+    for n in names:
+        sd[n].requires_grad_(True)
+    batch, draws = recipe.make_batch(R=2)
+    out = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, zero_pad_rows=False)  # eager semantics = CPU reference
+    assert abs(float(out["total_loss"].detach()) - float(e2e["A_total_loss"])) < 2e-5
+    assert abs(float(out["contrastive"]) - float(e2e["A_contrastive"])) < 2e-5
+    assert abs(float(out["ce"] + out["contrastive"]) - float(e2e["A_llm_loss"])) < 5e-5
+    assert np.allclose(out["logits"][:, -8:, :64].detach().numpy(), e2e["A_logits_slice"], rtol=1e-3, atol=2e-4)
+    assert np.allclose(out["hidden_states"][8][:, 250:270, :32].detach().numpy(), e2e["A_hidden8_slice"], rtol=1e-3, atol=2e-4)
+    assert np.allclose(out["hidden_states"][-1][:, -8:, :32].detach().numpy(), e2e["A_last_hidden_slice"], rtol=1e-3, atol=2e-4)
+    out["total_loss"].backward()
+    norms = np.array([float(sd[n].grad.norm()) for n in names])
+    assert np.allclose(norms, e2e["A_gradnorms"], rtol=2e-3, atol=1e-7)
+    for key in e2e.files:
+        if key.startswith("A_grad::"):
+            n = key[len("A_grad::"):]
+            g = sd[n].grad
+            ref = e2e[key]
+            got = g.numpy() if g.shape == ref.shape else g[:16, :64].numpy()
+            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-8, n
+
+
+def test_reference_bf16_mode_spread_is_recorded(e2e):
+    """Mode C (bf16 reference) vs mode A (fp32 reference): the yardstick for the bf16 HIP path (SURVEY 8c protocol ii)."""
+    spread = np.abs(e2e["C_hidden8_slice"] - e2e["A_hidden8_slice"]).max() / np.abs(e2e["A_hidden8_slice"]).max()
+    assert 1e-4 < spread < 0.5
+    assert abs(float(e2e["C_total_loss"]) - float(e2e["A_total_loss"])) < 0.1
