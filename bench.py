@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: MLA-Llama2-7B SFT training step (bf16) on N MI355X -- BASELINE.json configs[1] (N=1) / [2] (N=8).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one micro-step of the reference's training loop (base_strategy_mla.py:303-379): forward + backward of the whole
+MLA model on a synthetic batch of 8 samples per GPU (x4 diffusion repeats = 32 sequences of 548 tokens), global grad-norm
+clip, AdamW step. Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (MFMA GEMM family, timed
+with HIP events around every launch on the launch stream) and `cpu_baseline` (the oracle's decoder layer on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+S_FUSED, L_TEXT, R_DIFF, B_PER_GPU = 513, 32, 4, 8
+
+
+def model_flops_per_sample(S, H=4096, I=11008, L=32, V=32064, R=R_DIFF):
+    """per token per layer fwd = 8 H^2 + 6 H I + causal attention 2*2*(S/2)*H; model FLOPs = 3x fwd
+    (no recompute credit); + lm_head fwd. Returns (decoder_flops, total_flops) per dataset sample."""
+    per_tok_layer = 8 * H * H + 6 * H * I + 2 * 2 * (S / 2) * H
+    dec = 3 * per_tok_layer * L * S * R
+    lm = 2 * H * V * S * R
+    return dec, dec + lm
+
+
+def build(device, save_level, tiny=False):
+    from mla_amd.backbones import LLaMa2LLMBackbone
+    from mla_amd.llama import LlamaConfig
+    from mla_amd.mla import MLA
+    from mla_amd.prismatic import PrismaticVLM
+    with torch.device(device):
+        if tiny:
+            cfg = LlamaConfig(vocab_size=32000, hidden_size=512, intermediate_size=1024, num_hidden_layers=9, num_attention_heads=4,
+                              activation_save_level=save_level)
+        else:
+            cfg = LlamaConfig(activation_save_level=save_level)   # Llama-2-7b
+        bb = LLaMa2LLMBackbone("llama2-7b-pure", config=cfg)
+        vlm = PrismaticVLM("mla-7b", bb, token_size=cfg.hidden_size, action_dim=7, use_diff=True, use_pointcloud=True,
+                           use_contrastive=True, use_generation=False, future_action_window_size=0)
+        mla = MLA(vlm, None, token_size=cfg.hidden_size, action_dim=7, future_action_window_size=0, use_diff=True,
+                  use_pointcloud=True, use_contrastive=True, use_generation=False)
+        # <BOD>, <EOD> added by scripts/train.py:132-155 stay inside the 32064 rows; give final_layer a non-zero read-out
+        torch.nn.init.normal_(mla.vlm.final_layer.mlp.fc2.weight, std=0.02)
+    mla.freeze_backbones("finetune")
+    return mla
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle decoder layer (fp32, true 7B dims) fwd+bwd on the host cores; extrapolated to samples/s."""
+    from oracle import torch_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    H, I, nh, S, Bs = 4096, 11008, 32, L_TEXT + S_FUSED + 3, 2
+    g = torch.Generator().manual_seed(0)
+    names = ["input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+             "self_attn.o_proj.weight", "post_attention_layernorm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+             "mlp.down_proj.weight"]
+    shapes = [(H,), (H, H), (H, H), (H, H), (H, H), (H,), (I, H), (I, H), (H, I)]
+    p = {n: (torch.randn(*s, generator=g) * 0.02).requires_grad_(True) for n, s in zip(names, shapes)}
+    x = torch.randn(Bs, S, H, generator=g).requires_grad_(True)
+    cos, sin = O.rope_tables(S, H // nh)
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
+        t0 = time.time()
+        O.decoder_layer(x, p, cos, sin, nh, 1e-5).sum().backward()
+        times.append(time.time() - t0)
+        if time.time() > t_end and len(times) >= 2:
+            break
+    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    tok_per_s_layer = Bs * S / t
+    samples_per_s = tok_per_s_layer / 32 / (S * R_DIFF)
+    return {"value": samples_per_s, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle LlamaDecoderLayer fwd+bwd fp32 at 7B dims, {Bs}x{S} tokens, median of {len(times)-1} runs "
+                      f"({t:.2f} s), extrapolated x32 layers (encoders/heads excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--save-level", type=int, default=1, help="activation policy: 2 keep all, 1 recompute cheap elementwise, 0 full recompute")
+    ap.add_argument("--tiny", action="store_true", help="small model for smoke runs (NOT the benchmark config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs through torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mla_amd import hip
+    from mla_amd.strategy import FSDPStrategy
+    from mla_amd.synthetic import make_batch
+
+    torch.manual_seed(42 + rank)
+    mla = build(device, args.save_level, args.tiny)
+    strat = FSDPStrategy(mla, local_rank, stage="finetune", global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
+                         learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
+                         enable_gradient_checkpointing=False, repeated_diffusion_steps=R_DIFF)
+    strat.run_setup(n_train_examples=10_000)
+    batch = make_batch(B=B_PER_GPU, L_text=L_TEXT, seed=42 + rank, device=device)
+    S = L_TEXT + S_FUSED + 3
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        losses = strat.train_step(batch)
+    prof = None if args.no_gemm_profile else []
+    sync()
+    hip.GEMM_PROFILE = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = strat.train_step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    hip.GEMM_PROFILE = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B_PER_GPU * args.steps / elapsed
+        dec_fl, tot_fl = model_flops_per_sample(S)
+        roof = None
+        if prof:
+            big = [(e0.elapsed_time(e1), fl, key) for e0, e1, fl, key in prof if fl > 1e11]
+            tsum = sum(t for t, _, _ in big) * 1e-3
+            fsum = sum(fl for _, fl, _ in big)
+            ach = fsum / tsum / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm128_kernel<AMODE,BMODE> (bf16 MFMA GEMM family, launches >= 0.1 TFLOP)",
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
+                    "gemm_ms_per_step": round(tsum / args.steps * 1e3, 1)}
+        out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]: MLA-Llama2-7B SFT, use_pointcloud+use_contrastive, 672x672(+mask) image + "
+                                      "1024 points + 32 text tokens, per-GPU batch 8 x 4 diffusion repeats = 32 x 548 tokens"
+                                      + (" [TINY SMOKE MODEL - not the benchmark]" if args.tiny else ""),
+                          "model": "mla-llama2-7b" if not args.tiny else "tiny", "global_batch": B_PER_GPU * world, "seq_len": S,
+                          "parallelism": f"fsdp-rccl x{world}" if world > 1 else "single-gpu", "activation_save_level": args.save_level,
+                          "optimizer": "fused AdamW + grad clip inside the timed region"},
+               "model_tflop_per_sample": round(tot_fl / 1e12, 2),
+               "model_tflops_per_gpu": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12, 1),
+               "mfu_vs_2.5PF": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+               "loss": {k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1},
+               "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

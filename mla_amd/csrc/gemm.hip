@@ -28,7 +28,10 @@ struct GemmArgs {
   int out_fp32;    // 0: C is bf16, 1: C is fp32
   int accumulate;  // fp32 output only: C += result
   float alpha;
+  int debug;  // experiments only (tools/): bit0 = read tr tiles with b128, bit1 = stage mode-1 tiles with mode-0 addresses
 };
+
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, hipStream_t stream);  // gemm256.hip
 
 namespace {
 
@@ -283,8 +286,9 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
   MLA_CHECK_ARG(!accumulate || out_fp32, "mla_gemm_bf16: accumulate needs fp32 output");
   MLA_CHECK_ARG(R == nullptr || ldr >= N, "mla_gemm_bf16: bad ldr");
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)R, (const bf16_t*)bias, M, N, K,
-             lda, ldb, ldc, ldr, out_fp32, accumulate, alpha};
-  bool mfma_ok = !force_generic && (K % 32 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
+             lda, ldb, ldc, ldr, out_fp32, accumulate, alpha, force_generic >> 4};
+  force_generic &= 15;
+  bool mfma_ok = (force_generic != 1) && (K % 32 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                  (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
   if (a_mode == 1 && (M % 8 != 0)) mfma_ok = false;
   if (b_mode == 1 && (N % 8 != 0)) mfma_ok = false;
@@ -292,6 +296,11 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
   if (!out_fp32 && (((uintptr_t)C & 7) != 0)) mfma_ok = false;
   if (R && (((uintptr_t)R & 7) != 0)) mfma_ok = false;
   if (bias && (((uintptr_t)bias & 7) != 0)) mfma_ok = false;
+  // the 256x256 kernel is used for k-contiguous operands only: its reduction-major (ds_read_b64_tr_b16) path is slower than
+  // the 128x128 kernel's (issue-limited at 2 waves/SIMD); force_generic == 3 forces it for tests / experiments
+  if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 &&
+      ((force_generic == 0 && a_mode == 0 && b_mode == 0) || force_generic == 3))
+    return mla_gemm256_dispatch(&p, a_mode, b_mode, stream);
   if (mfma_ok) {
     if (a_mode == 0 && b_mode == 0) return launch128<0, 0>(p, stream);
     if (a_mode == 0 && b_mode == 1) return launch128<0, 1>(p, stream);

@@ -1,0 +1,315 @@
+// 256x256x64 bf16 MFMA GEMM for the large Llama GEMMs (M, N >= 256, K % 64 == 0); same contract as gemm128_kernel.
+//
+// Why a second kernel: a 128x128 tile moves 32 KiB of operands per 2.1 MFLOP (64 flop/B) -- at the 2.5 PFLOP/s MFMA
+// peak that is ~39 TB/s of L2->LDS traffic, above what the 8 XCD L2s deliver (~34.5 TB/s, MI355X_MICROARCH.md).
+// 256x256 halves the operand traffic per flop (128 flop/B) and the LDS->register traffic per MFMA.
+//
+// Schedule (DESIGN.md "GEMM 256"):  8 waves = 2 (M) x 4 (N), per-wave output 128x64 = 8x4 MFMA fragments (128 acc VGPRs).
+// A K-tile (BK = 64) lives in one of two 64 KiB LDS buffers as four 16 KiB "half-tile" slots arranged by C-quadrant:
+//   SA0/SA1 = the A rows every wave needs for its upper/lower 64 output rows, SB0/SB1 = the B rows for its left/right 32
+//   output columns.  Per K-tile each wave runs 4 phases = 4 quadrants of 16 MFMAs x 2 k-steps:
+//     ph1: read SA0,SB0 -> Q00   ph2: read SB1 -> Q01   ph3: read SA1 -> Q11   ph4: (no read) -> Q10
+//   Every phase also issues ONE half-tile of global_load_lds (2 x 16 B per lane) for a future K-tile, into a slot whose
+//   last reader finished >= 2 phases earlier:  ph1: SB1(t+1)  ph2: SA1(t+1)  ph3: SA0(t+2)  ph4: SB0(t+2).
+//   Loads are therefore 1-2 K-tiles ahead and are retired with a COUNTED s_waitcnt vmcnt(8) (4 half-tiles stay in
+//   flight across the barriers; never vmcnt(0) in the loop).
+// The two wave rows run staggered by one barrier (wave row 1 executes one extra s_barrier up front), so on every SIMD
+// one wave is in its ds_read/issue segment while its partner is in its MFMA segment; s_setprio(1) wraps the MFMAs.
+#include "common.h"
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const bf16_t* R;
+  const bf16_t* bias;
+  int M, N, K;
+  int lda, ldb, ldc, ldr;
+  int out_fp32;
+  int accumulate;
+  float alpha;
+  int debug;  // experiments only (tools/): bit0 = read tr tiles with b128, bit1 = stage mode-1 tiles with mode-0 addresses
+};
+
+namespace {
+
+constexpr int SLOT = 16384;
+constexpr int SA0 = 0, SB0 = SLOT, SB1 = 2 * SLOT, SA1 = 3 * SLOT, BUF = 4 * SLOT;
+
+__device__ __forceinline__ int hsw(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// global source of the 16-B chunk this lane stages for (operand, half h, wave instruction `instr` in 0..15), K-tile 0.
+// Half-tile h of an operand = the CONTIGUOUS global rows/cols [base + h*128, base + h*128 + 128): quadrant QI of every
+// wave lives in half QI (wave wr owns rows QI*128 + wr*64 + ..), so each LDS row of a reduction-major tile is one
+// contiguous 256-B global run (split 64/128-B runs measured 1.5-2x slower on the L2->LDS path).
+template <int MODE, bool IS_A>
+__device__ __forceinline__ const bf16_t* stage_src(const bf16_t* g, int ld, int base, int lim, int h, int instr, int lane) {
+  const int p = instr * 64 + lane;
+  if (MODE == 0) {
+    const int rp = p >> 3, cp = p & 7;
+    const int c = cp ^ (rp & 7);
+    int gi = base + h * 128 + rp;
+    gi = gi < lim ? gi : lim - 1;
+    return g + (size_t)gi * ld + c * 8;
+  } else {
+    const int kr = p >> 4, cp = p & 15;
+    const int c = cp ^ (hsw(kr) << 1);
+    const int ip = c * 8;
+    int gi = base + h * 128 + ip;
+    gi = (gi + 8 <= lim) ? gi : 0;
+    return g + (size_t)kr * ld + gi;
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int li = lane & 15, lg = lane >> 4;
+
+  const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GROUP_M = 4;
+  const int in_group = GROUP_M * num_n;
+  const int group_id = pid / in_group;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = (num_m - first_m) < GROUP_M ? (num_m - first_m) : GROUP_M;
+  const int pid_m = first_m + (pid % in_group) % gsz;
+  const int pid_n = (pid % in_group) / gsz;
+  const int m0 = pid_m * 256, n0 = pid_n * 256;
+  const int nt = p.K / 64;
+
+  // ---- staging pointers: [slot][it]; each advances one K-tile per use
+  const size_t stepA = (p.debug & 2) ? 64 : (AMODE == 0 ? 64 : (size_t)64 * p.lda);
+  const size_t stepB = (p.debug & 2) ? 64 : (BMODE == 0 ? 64 : (size_t)64 * p.ldb);
+  const bf16_t* pA0[2]; const bf16_t* pA1[2]; const bf16_t* pB0[2]; const bf16_t* pB1[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (p.debug & 2) {   // EXPERIMENT: k-contiguous address pattern regardless of the mode (wrong data, timing only)
+      pA0[it] = stage_src<0, true>(p.A, 4096, 0, 4096, 0, wave * 2 + it, lane);
+      pA1[it] = stage_src<0, true>(p.A, 4096, 0, 4096, 1, wave * 2 + it, lane);
+      pB0[it] = stage_src<0, false>(p.B, 4096, 0, 4096, 0, wave * 2 + it, lane);
+      pB1[it] = stage_src<0, false>(p.B, 4096, 0, 4096, 1, wave * 2 + it, lane);
+      continue;
+    }
+    pA0[it] = stage_src<AMODE, true>(p.A, p.lda, m0, p.M, 0, wave * 2 + it, lane);
+    pA1[it] = stage_src<AMODE, true>(p.A, p.lda, m0, p.M, 1, wave * 2 + it, lane);
+    pB0[it] = stage_src<BMODE, false>(p.B, p.ldb, n0, p.N, 0, wave * 2 + it, lane);
+    pB1[it] = stage_src<BMODE, false>(p.B, p.ldb, n0, p.N, 1, wave * 2 + it, lane);
+  }
+  int tA0 = 0, tA1 = 0, tB0 = 0, tB1 = 0;  // next K-tile index each slot stages (wave-uniform)
+
+#define STAGE(PTR, TCNT, STEP, SLOTOFF)                                                           \
+  do {                                                                                            \
+    const size_t back__ = (TCNT < nt) ? 0 : (size_t)TCNT * (STEP); /* dummy re-load of K-tile 0 past the end */ \
+    char* dst__ = smem + (TCNT & 1) * BUF + (SLOTOFF) + wave * 2048;                              \
+    glds16(PTR[0] - back__, dst__);                                                               \
+    glds16(PTR[1] - back__, dst__ + 1024);                                                        \
+    PTR[0] += (STEP); PTR[1] += (STEP); ++TCNT;                                                   \
+  } while (0)
+
+  // ---- fragment read offsets (bytes inside a slot)
+  int offA[4], offB[2];  // mode 0: [0] = ks 0 base (rb/cb added as immediates), mode 1: one per rb / cb
+  if (AMODE == 0) {
+    offA[0] = (wr * 64 + li) * 128 + ((lg ^ (li & 7)) * 16);
+    offA[1] = offA[2] = offA[3] = 0;
+  } else {
+    const int h = ((li >> 2) & 3) | ((lg & 1) << 2);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+      offA[rb] = ((lg * 8 + (li >> 2)) * 16 + ((wr * 8 + rb * 2 + ((li & 3) >> 1)) ^ (h << 1))) * 16 + (li & 1) * 8;
+  }
+  if (BMODE == 0) {
+    offB[0] = (wc * 32 + li) * 128 + ((lg ^ (li & 7)) * 16);
+    offB[1] = 0;
+  } else {
+    const int h = ((li >> 2) & 3) | ((lg & 1) << 2);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+      offB[cb] = ((lg * 8 + (li >> 2)) * 16 + ((wc * 4 + cb * 2 + ((li & 3) >> 1)) ^ (h << 1))) * 16 + (li & 1) * 8;
+  }
+
+  auto ldA = [&](const char* slot, int rb, int ks) -> bf16x8_t {
+    if (AMODE == 0) {
+      return *(const bf16x8_t*)(slot + ((offA[0] + rb * 2048) ^ (ks * 64)));
+    } else {
+      if (p.debug & 1) return *(const bf16x8_t*)(slot + (((wr * 64 + li) * 128 + ((lg ^ (li & 7)) * 16) + rb * 2048) ^ (ks * 64)));
+      union { bf16x8_t v; short4_t h2[2]; } u;
+      u.h2[0] = lds_tr16_b64(slot + offA[rb] + ks * 8192);
+      u.h2[1] = lds_tr16_b64(slot + offA[rb] + ks * 8192 + 1024);
+      return u.v;
+    }
+  };
+  auto ldB = [&](const char* slot, int cb, int ks) -> bf16x8_t {
+    if (BMODE == 0) {
+      return *(const bf16x8_t*)(slot + ((offB[0] + cb * 2048) ^ (ks * 64)));
+    } else {
+      if (p.debug & 1) return *(const bf16x8_t*)(slot + (((wc * 32 + li) * 128 + ((lg ^ (li & 7)) * 16) + cb * 2048) ^ (ks * 64)));
+      union { bf16x8_t v; short4_t h2[2]; } u;
+      u.h2[0] = lds_tr16_b64(slot + offB[cb] + ks * 8192);
+      u.h2[1] = lds_tr16_b64(slot + offB[cb] + ks * 8192 + 1024);
+      return u.v;
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+
+#define READ_A(SLOTP)                                              \
+  _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) {               \
+    fa[rb][0] = ldA(SLOTP, rb, 0); fa[rb][1] = ldA(SLOTP, rb, 1);  \
+  }
+#define READ_B(DST, SLOTP)                                          \
+  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                \
+    DST[cb][0] = ldB(SLOTP, cb, 0); DST[cb][1] = ldB(SLOTP, cb, 1); \
+  }
+#define SEG_END()                                                  \
+  __builtin_amdgcn_sched_barrier(0);                               \
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 \
+  __builtin_amdgcn_s_barrier();                                    \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+  __builtin_amdgcn_sched_barrier(0);
+#define MMA(QI, QJ, FB)                                                                                          \
+  __builtin_amdgcn_s_setprio(1);                                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+  _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                               \
+  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                               \
+    acc[QI * 4 + rb][QJ * 2 + cb] =                                                                              \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[cb][ks], fa[rb][ks], acc[QI * 4 + rb][QJ * 2 + cb], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                             \
+  asm volatile("" ::: "memory");                                                                                 \
+  __builtin_amdgcn_s_barrier();                                                                                  \
+  asm volatile("" ::: "memory");
+
+  // ---- prologue: K-tiles 0 (all four slots) and 1 (SA0, SB0)
+  STAGE(pA0, tA0, stepA, SA0);
+  STAGE(pB0, tB0, stepB, SB0);
+  STAGE(pB1, tB1, stepB, SB1);
+  STAGE(pA1, tA1, stepA, SA1);
+  STAGE(pA0, tA0, stepA, SA0);
+  STAGE(pB0, tB0, stepB, SB0);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // SA0(0), SB0(0) of this wave have landed
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger wave row 1 by one barrier
+
+  for (int t = 0; t < nt; ++t) {
+    const char* buf = smem + (t & 1) * BUF;
+    // phase 1
+    STAGE(pB1, tB1, stepB, SB1);
+    READ_A(buf + SA0)
+    READ_B(fb0, buf + SB0)
+    SEG_END()
+    MMA(0, 0, fb0)
+    // phase 2
+    STAGE(pA1, tA1, stepA, SA1);
+    READ_B(fb1, buf + SB1)
+    SEG_END()
+    MMA(0, 1, fb1)
+    // phase 3
+    STAGE(pA0, tA0, stepA, SA0);
+    READ_A(buf + SA1)
+    SEG_END()
+    MMA(1, 1, fb1)
+    // phase 4
+    STAGE(pB0, tB0, stepB, SB0);
+    SEG_END()
+    MMA(1, 0, fb0)
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // re-balance the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the dummy tail loads before the wave retires
+
+  // ---- epilogue (operands were passed swapped: lane holds C[m][n..n+3])
+  const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0);
+#pragma unroll
+  for (int ri = 0; ri < 8; ++ri) {
+    const int m = m0 + (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const int n = n0 + (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[ri][ci][r] * p.alpha;
+      if (n + 3 < p.N && vec_ok) {
+        if (p.bias) {
+          const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
+          v[0] += bflo(bb[0]); v[1] += bfhi(bb[0]); v[2] += bflo(bb[1]); v[3] += bfhi(bb[1]);
+        }
+        if (p.R) {
+          const u32x2_t rr = *(const u32x2_t*)(p.R + (size_t)m * p.ldr + n);
+          v[0] += bflo(rr[0]); v[1] += bfhi(rr[0]); v[2] += bflo(rr[1]); v[3] += bfhi(rr[1]);
+        }
+        if (p.out_fp32) {
+          float* c = (float*)p.C + (size_t)m * p.ldc + n;
+          f32x4_t o = {v[0], v[1], v[2], v[3]};
+          if (p.accumulate) o += *(const f32x4_t*)c;
+          *(f32x4_t*)c = o;
+        } else {
+          u32x2_t o;
+          o[0] = pack2bf(v[0], v[1]);
+          o[1] = pack2bf(v[2], v[3]);
+          *(u32x2_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        }
+      } else {
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+          float x = v[r];
+          if (p.bias) x += bf2f(p.bias[n + r]);
+          if (p.R) x += bf2f(p.R[(size_t)m * p.ldr + n + r]);
+          if (p.out_fp32) {
+            float* c = (float*)p.C + (size_t)m * p.ldc + n + r;
+            *c = p.accumulate ? (*c + x) : x;
+          } else {
+            ((bf16_t*)p.C)[(size_t)m * p.ldc + n + r] = f2bf(x);
+          }
+        }
+      }
+    }
+  }
+#undef STAGE
+#undef READ_A
+#undef READ_B
+#undef SEG_END
+#undef MMA
+}
+
+template <int AM, int BM_>
+int launch256(const GemmArgs& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+    attr_set = true;
+  }
+  const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
+  hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mla_set_error("gemm256 launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// called by mla_gemm_bf16 (gemm.hip) when M, N >= 256 and K % 64 == 0
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, hipStream_t stream) {
+  const GemmArgs& p = *(const GemmArgs*)args;
+  if (a_mode == 0 && b_mode == 0) return launch256<0, 0>(p, stream);
+  if (a_mode == 0 && b_mode == 1) return launch256<0, 1>(p, stream);
+  if (a_mode == 1 && b_mode == 0) return launch256<1, 0>(p, stream);
+  return launch256<1, 1>(p, stream);
+}

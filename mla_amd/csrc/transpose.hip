@@ -1,0 +1,107 @@
+// Tile transposes feeding the wgrad / dgrad GEMMs (DESIGN.md "all-NT backward").
+// The MFMA fragment of an operand needs 8 consecutive reduction elements per lane. For the backward products
+// (dx = dy W, dW = dy^T x) the natural layouts are reduction-major, which forces ds_read_b64_tr_b16 gathers; those
+// reads are issue-limited at the 2 waves/SIMD a 256x256 tile leaves (measured: 470-700 TFLOP/s vs 1100-1250 with
+// ds_read_b128 on the same bytes, 0 bank conflicts either way). So the backward GEMMs are fed k-contiguous operands
+// instead: W^T, x^T and dy^T are produced by these HBM-bound kernels (64x64 tiles through LDS, 16-B global accesses
+// on both sides), two of them fused with the elementwise op that (re)computes the tensor anyway.
+#include "common.h"
+
+namespace {
+
+struct CopyOp {
+  __device__ __forceinline__ void load8(const bf16_t* src, long long ld, long long r, int c, float* v) const {
+    const u32x4_t w = *(const u32x4_t*)(src + r * ld + c);
+    v[0] = bflo(w[0]); v[1] = bfhi(w[0]); v[2] = bflo(w[1]); v[3] = bfhi(w[1]);
+    v[4] = bflo(w[2]); v[5] = bfhi(w[2]); v[6] = bflo(w[3]); v[7] = bfhi(w[3]);
+  }
+};
+// y = w * bf16(x * rstd[row])  (LlamaRMSNorm with the statistic saved by the forward pass)
+struct RmsApplyOp {
+  const bf16_t* w; const float* rstd;
+  __device__ __forceinline__ void load8(const bf16_t* src, long long ld, long long r, int c, float* v) const {
+    const u32x4_t x = *(const u32x4_t*)(src + r * ld + c);
+    const u32x4_t ww = *(const u32x4_t*)(w + c);
+    const float rs = rstd[r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = bflo(ww[j]) * bf2f(f2bf(bflo(x[j]) * rs));
+      v[2 * j + 1] = bfhi(ww[j]) * bf2f(f2bf(bfhi(x[j]) * rs));
+    }
+  }
+};
+// act = silu(gate) * up from gu = [gate | up] (row stride ld = 2I); logical source width = I
+struct SwigluOp {
+  int I;
+  __device__ __forceinline__ void load8(const bf16_t* src, long long ld, long long r, int c, float* v) const {
+    const u32x4_t g = *(const u32x4_t*)(src + r * ld + c);
+    const u32x4_t u = *(const u32x4_t*)(src + r * ld + I + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = bflo(g[j]), g1 = bfhi(g[j]);
+      const float s0 = 1.f / (1.f + __expf(-g0)), s1 = 1.f / (1.f + __expf(-g1));
+      v[2 * j] = (g0 * s0) * bflo(u[j]);
+      v[2 * j + 1] = (g1 * s1) * bfhi(u[j]);
+    }
+  }
+};
+
+// dst[c][r] = op(src)[r][c];  src logical [R, C] (row stride ld), dst [C, R] (row stride ldt). R % 8 == 0, C % 8 == 0.
+template <typename OP>
+__global__ __launch_bounds__(256) void tile_transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, long long R,
+                                                             int C, long long ld, long long ldt, OP op) {
+  __shared__ unsigned short t[64][66];
+  const long long r0 = (long long)blockIdx.y * 64;
+  const int c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rr = (tid >> 3) + it * 32, cc = (tid & 7) * 8;
+    if (r0 + rr < R && c0 + cc < C) {
+      float v[8];
+      op.load8(src, ld, r0 + rr, c0 + cc, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[cc + j][rr] = f2bf(v[j]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int cc = (tid >> 3) + it * 32, rr = (tid & 7) * 8;
+    if (c0 + cc < C && r0 + rr < R) {
+      const uint32_t* p = (const uint32_t*)&t[cc][rr];
+      u32x4_t w = {p[0], p[1], p[2], p[3]};
+      *(u32x4_t*)(dst + (long long)(c0 + cc) * ldt + r0 + rr) = w;
+    }
+  }
+}
+
+template <typename OP>
+int launch_tt(const void* src, void* dst, long long R, int C, long long ld, long long ldt, OP op, hipStream_t stream, const char* who) {
+  if (!(src && dst && R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && ld % 8 == 0 && ldt % 8 == 0)) {
+    mla_set_error("%s: need R, C, ld, ldt multiples of 8", who);
+    return -1;
+  }
+  if ((((uintptr_t)src) & 15) || (((uintptr_t)dst) & 15)) { mla_set_error("%s: 16-B alignment", who); return -1; }
+  dim3 grid((C + 63) / 64, (unsigned)((R + 63) / 64));
+  hipLaunchKernelGGL(tile_transpose_kernel<OP>, grid, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, R, C, ld, ldt, op);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mla_set_error("%s: launch failed: %s", who, hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mla_transpose_bf16(const void* src, void* dst, long long R, int C, long long ld, long long ldt, hipStream_t stream) {
+  return launch_tt(src, dst, R, C, ld, ldt, CopyOp{}, stream, "mla_transpose_bf16");
+}
+// dst[h][t] = w[h] * bf16(x[t][h] * rstd[t])
+extern "C" int mla_rmsnorm_apply_t(const void* x, const void* w, const float* rstd, void* dst, long long rows, int H, long long ldt,
+                                   hipStream_t stream) {
+  if (!w || !rstd) { mla_set_error("mla_rmsnorm_apply_t: null pointer"); return -1; }
+  return launch_tt(x, dst, rows, H, H, ldt, RmsApplyOp{(const bf16_t*)w, rstd}, stream, "mla_rmsnorm_apply_t");
+}
+// dst[i][t] = silu(gu[t][i]) * gu[t][I + i]
+extern "C" int mla_swiglu_fwd_t(const void* gu, void* dst, long long rows, int I, long long ldt, hipStream_t stream) {
+  return launch_tt(gu, dst, rows, I, 2LL * I, ldt, SwigluOp{I}, stream, "mla_swiglu_fwd_t");
+}

@@ -18,6 +18,9 @@ _lib = None
 
 ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream (roofline.achieved)
+GEMM_PROFILE = None
+
 # name -> argtypes (restype is always int unless noted) -- mirrors include/mla_hip.h
 _SIGNATURES = {
     "mla_query": [c_int],
@@ -140,10 +143,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
          M: Optional[int] = None, N: Optional[int] = None, K: Optional[int] = None, lda: Optional[int] = None,
          ldb: Optional[int] = None, ldc: Optional[int] = None, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None, out_dtype=torch.bfloat16,
-         accumulate: bool = False, alpha: float = 1.0, force_generic: bool = False) -> torch.Tensor:
+         accumulate: bool = False, alpha: float = 1.0, force_generic: int = 0) -> torch.Tensor:
     """C[M,N] = alpha * sum_k Aop(m,k) Bop(n,k) (+bias[n]) (+residual[m,n]) (+C if accumulate).
 
     a_mode/b_mode 0: operand stored [rows, K] (k contiguous); 1: stored [K, rows] (reduction-major).
+    force_generic: 0 = auto (256x256 kernel for large k-contiguous shapes, else 128x128, else SIMT fallback),
+    1 = SIMT fallback, 2 = never use the 256x256 kernel, 3 = force the 256x256 kernel for any mode (tests / A-B).
     2-D tensors with unit inner stride; leading dimension taken from stride(0).
     """
     _req(a, torch.bfloat16, "gemm a")
@@ -172,8 +177,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         ldr = residual.stride(0) if ldr is None else ldr
     if bias is not None:
         _req(bias, torch.bfloat16, "gemm bias")
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()   # torch's current stream == the stream the kernel is launched on (see _stream())
     call("mla_gemm_bf16", _p(a), _p(b), _p(out), _p(residual), _p(bias), M, N, K, lda, ldb, ldc, ldr or 0, a_mode, b_mode,
-         out_fp32, 1 if accumulate else 0, float(alpha), 1 if force_generic else 0)
+         out_fp32, 1 if accumulate else 0, float(alpha), int(force_generic))
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (a_mode, b_mode, M, N, K)))
     return out
 
 
@@ -382,7 +394,34 @@ register_signatures({
     "mla_local_attn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "mla_colstats_blocks": [c_longlong],
     "mla_gather_rows_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+    "mla_transpose_bf16": [c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_longlong, c_void_p],
+    "mla_rmsnorm_apply_t": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p],
+    "mla_swiglu_fwd_t": [c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p],
 })
+
+
+def transpose(x2d, out=None):
+    """out[c][r] = x2d[r][c] (bf16, unit inner stride, any row stride)."""
+    R, C = x2d.shape
+    if out is None:
+        out = torch.empty((C, R), dtype=torch.bfloat16, device=x2d.device)
+    call("mla_transpose_bf16", _p(x2d), _p(out), R, C, x2d.stride(0), out.stride(0))
+    return out
+
+
+def rmsnorm_apply_t(x2d, w, rstd):
+    """[H, T] = transpose(rmsnorm(x) with the saved rstd) -- recompute + transpose in one pass."""
+    rows, H = x2d.shape
+    out = torch.empty((H, rows), dtype=torch.bfloat16, device=x2d.device)
+    call("mla_rmsnorm_apply_t", _p(x2d), _p(w), _p(rstd), _p(out), rows, H, rows)
+    return out
+
+
+def swiglu_fwd_t(gu2d):
+    rows, two_i = gu2d.shape
+    out = torch.empty((two_i // 2, rows), dtype=torch.bfloat16, device=gu2d.device)
+    call("mla_swiglu_fwd_t", _p(gu2d), _p(out), rows, two_i // 2, rows)
+    return out
 
 
 def gather_rows(src2d, idx, out_rows=None, scatter=False):

@@ -72,6 +72,31 @@ def deliver_wgrad(weights: Sequence[torch.Tensor], dy2: torch.Tensor, x2: torch.
     return grads
 
 
+def deliver_wgrad_nt(weights: Sequence[torch.Tensor], dyT: torch.Tensor, xT: torch.Tensor, needs: Sequence[bool]):
+    """Same as deliver_wgrad with pre-transposed operands: dW_i = dyT[rows_i] @ xT^T  (dyT [sum N_i, T], xT [K, T], both
+    k-contiguous -> the fast NT kernel)."""
+    grads: List[Optional[torch.Tensor]] = [None] * len(weights)
+    mgs = [getattr(w, "main_grad", None) for w in weights]
+    if all(m is not None for m in mgs) and all(needs):
+        mcat = cat_view(mgs)
+        states = {bool(getattr(w, "_mg_touched", False)) for w in weights}
+        if mcat is not None and len(states) == 1:
+            hip.gemm(dyT, xT, out=mcat, accumulate=states.pop())
+            for w in weights:
+                w._mg_touched = True
+            return grads
+    off = 0
+    for i, w in enumerate(weights):
+        n = w.shape[0]
+        if needs[i]:
+            if mgs[i] is not None:
+                hip.gemm(dyT[off:off + n], xT, out=mgs[i], accumulate=_touch(w))
+            else:
+                grads[i] = hip.gemm(dyT[off:off + n], xT, out_dtype=torch.float32).to(w.dtype)
+        off += n
+    return grads
+
+
 def deliver_vec_grad(param: torch.Tensor, compute):
     """compute(out_f32, accumulate) fills a 1-D fp32 gradient. Routes to main_grad or returns a tensor."""
     mg = getattr(param, "main_grad", None)
@@ -393,41 +418,53 @@ class DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        """All-NT backward: every large GEMM gets k-contiguous operands (W^T, x^T, dy^T from the HBM-bound tile-transpose
+        kernels; x^T of the normalised inputs and of the SwiGLU product are recomputed straight into transposed layout),
+        so dgrad and wgrad run on the same 256x256 ds_read_b128 kernel as the forward (mla_amd/csrc/transpose.hip)."""
         w = ctx.w
         ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
         B, S, H, nheads, eps = ctx.dims
         seqlens, cos, sin = ctx.aux
         D = H // nheads
-        if ctx.save_level >= 2:
+        T = B * S
+        lvl = ctx.save_level
+        xn1 = xn2 = act_ = None
+        if lvl >= 2:
             h2, xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_ = ctx.saved_tensors
-        elif ctx.save_level == 1:
+        elif lvl == 1:
             h2, rstd1, qkv, o, lse, h1, rstd2, gu = ctx.saved_tensors
-            xn1, _ = hip.rmsnorm_fwd(h2, ln1, eps)
-            xn2, _ = hip.rmsnorm_fwd(h1, ln2, eps)
-            act_ = hip.swiglu_fwd(gu)
         else:
             (h2,) = ctx.saved_tensors
             _, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w)
+        if T % 8 != 0:
+            raise NotImplementedError("decoder backward needs batch*seq to be a multiple of 8 (tile transposes)")
         need = ctx.needs_input_grad[7:]
-        d2 = dout.reshape(B * S, H)
+        d2 = dout.reshape(T, H)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * 9
 
-        # ---- MLP
-        dact = hip.gemm(d2, wd, b_mode=1)
-        grads[8] = deliver_wgrad((wd,), d2, act_, need[8:9])[0]
-        del act_
+        def wT(ws):
+            wc = cat_view(ws)
+            return hip.transpose(wc if wc is not None else torch.cat(list(ws), 0))
+
+        # ---- MLP: down projection
+        dact = hip.gemm(d2, wT((wd,)))                                   # [T, I]
+        if need[8]:
+            actT = hip.swiglu_fwd_t(gu) if act_ is None else hip.transpose(act_)
+            grads[8] = deliver_wgrad_nt((wd,), hip.transpose(d2), actT, need[8:9])[0]
+            del actT
+        act_ = None
         dgu, _ = hip.swiglu_bwd(dact, gu)
         del dact
-        wgu = cat_view((wg, wu))
-        I = wg.shape[0]
-        if wgu is not None:
-            dxn2 = hip.gemm(dgu, wgu, b_mode=1)
-        else:
-            dxn2 = hip.add_bf16(hip.gemm(dgu[:, :I], wg, b_mode=1, K=I), hip.gemm(dgu[:, I:], wu, b_mode=1, K=I))
-        grads[6], grads[7] = deliver_wgrad((wg, wu), dgu, xn2, need[6:8])
-        del dgu, xn2
+        # ---- MLP: gate | up projection
+        dxn2 = hip.gemm(dgu, wT((wg, wu)))                               # [T, H], K = 2I
+        if need[6] or need[7]:
+            xn2T = hip.rmsnorm_apply_t(h1, ln2, rstd2) if xn2 is None else hip.transpose(xn2)
+            grads[6], grads[7] = deliver_wgrad_nt((wg, wu), hip.transpose(dgu), xn2T, need[6:8])
+            del xn2T
+        del dgu
+        xn2 = None
         holder = {}
 
         def ln2_run(dw_out, acc):
@@ -440,24 +477,22 @@ class DecoderLayerFn(torch.autograd.Function):
         dh1 = holder["dh1"]
         del dxn2
 
-        # ---- attention
-        do = hip.gemm(dh1, wo, b_mode=1)
-        grads[4] = deliver_wgrad((wo,), dh1, o, need[4:5])[0]
+        # ---- attention output projection
+        do = hip.gemm(dh1, wT((wo,)))
+        if need[4]:
+            grads[4] = deliver_wgrad_nt((wo,), hip.transpose(dh1), hip.transpose(o), need[4:5])[0]
         dqkv = torch.empty_like(qkv)
         hip.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, seqlens, dqkv[:, :H], dqkv[:, H:2 * H],
                      dqkv[:, 2 * H:], B, S, nheads, D, 3 * H, 1.0 / math.sqrt(D))
         del do
         hip.rope_inplace(dqkv, cos, sin, S, nheads, D, 0, H, backward=True)
-        wqkv = cat_view((wq, wk, wv))
-        if wqkv is not None:
-            dxn1 = hip.gemm(dqkv, wqkv, b_mode=1)
-        else:
-            dxn1 = None
-            for i, wi in enumerate((wq, wk, wv)):
-                part = hip.gemm(dqkv[:, i * H:(i + 1) * H], wi, b_mode=1, K=H)
-                dxn1 = part if dxn1 is None else hip.add_bf16(dxn1, part)
-        grads[1], grads[2], grads[3] = deliver_wgrad((wq, wk, wv), dqkv, xn1, need[1:4])
-        del dqkv, xn1
+        # ---- q | k | v projection
+        dxn1 = hip.gemm(dqkv, wT((wq, wk, wv)))                          # [T, H], K = 3H
+        if need[1] or need[2] or need[3]:
+            xn1T = hip.rmsnorm_apply_t(h2, ln1, rstd1) if xn1 is None else hip.transpose(xn1)
+            grads[1], grads[2], grads[3] = deliver_wgrad_nt((wq, wk, wv), hip.transpose(dqkv), xn1T, need[1:4])
+            del xn1T
+        del dqkv
 
         def ln1_run(dw_out, acc):
             holder["dh"] = hip.rmsnorm_bwd(dxn1, h2, ln1, rstd1, dres=dh1, dw_out=dw_out, dw_accumulate=acc)

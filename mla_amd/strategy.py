@@ -1,0 +1,107 @@
+"""Training strategy counterpart (reference: training/strategies/base_strategy_mla.py:251-404 run_vla_training and
+training/strategies/fsdp.py:176-310 run_setup / clip_grad_norm), driving mla_amd.fsdp.ShardedModel.
+
+One call to ``train_step(batch)`` = one micro-step of the reference's hot loop with grad_accumulation_steps == 1:
+forward (bf16), backward, global grad-norm clip, AdamW step, LR-scheduler step. Logging / W&B / checkpoint I/O of the
+reference's loop are out of scope; the loss dict keys are the reference's (base_strategy_mla.py:326-334).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from .fsdp import ShardedModel
+
+
+def cosine_with_warmup(step: int, warmup: int, total: int) -> float:
+    """transformers.optimization.get_cosine_schedule_with_warmup (optimization.py:144) multiplier."""
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    progress = float(step - warmup) / float(max(1, total - warmup))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+
+class FSDPStrategy:
+    def __init__(self, vlm, device_id, stage: str = "finetune", epochs: int = 1, max_steps: Optional[int] = None,
+                 global_batch_size: int = 8, per_device_batch_size: int = 8, learning_rate: float = 2e-5,
+                 weight_decay: float = 0.0, max_grad_norm: float = 1.0, lr_scheduler_type: str = "constant",
+                 warmup_ratio: float = 0.0, enable_gradient_checkpointing: bool = True,
+                 enable_mixed_precision_training: bool = True, reduce_in_full_precision: bool = True,
+                 repeated_diffusion_steps: int = 4, cast_forward_inputs: bool = True, local_ops=None, **_):
+        self.vlm, self.stage = vlm, stage
+        self.device = torch.device("cuda", device_id) if isinstance(device_id, int) else torch.device(device_id)
+        self.epochs, self.max_steps = epochs, max_steps
+        self.global_batch_size, self.per_device_batch_size = global_batch_size, per_device_batch_size
+        self.learning_rate, self.weight_decay, self.max_grad_norm = learning_rate, weight_decay, max_grad_norm
+        self.lr_scheduler_type, self.warmup_ratio = lr_scheduler_type, warmup_ratio
+        self.enable_gradient_checkpointing = enable_gradient_checkpointing
+        self.repeated_diffusion_steps = repeated_diffusion_steps
+        self.cast_forward_inputs = cast_forward_inputs
+        if not enable_mixed_precision_training or not reduce_in_full_precision:
+            raise NotImplementedError("only the shipped policy is built: bf16 parameters/compute, fp32 gradient reduction")
+        self.local_ops = local_ops
+        self.sharded: Optional[ShardedModel] = None
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        assert self.global_batch_size % (self.per_device_batch_size * self.world) == 0
+        self.grad_accumulation_steps = self.global_batch_size // self.per_device_batch_size // self.world
+        if self.grad_accumulation_steps != 1:
+            raise NotImplementedError("gradient accumulation > 1 (every shipped script uses global = per-device x world)")
+        self.step = 0
+        self.num_training_steps = self.num_warmup_steps = 0
+
+    def run_setup(self, n_train_examples: int = 0, run_dir=None) -> None:
+        """fsdp.py:176-306: shard, (checkpointing), AdamW groups (no decay on <2-D / bias), LR schedule."""
+        if self.enable_gradient_checkpointing:
+            self.vlm.llm_backbone.enable_gradient_checkpointing()
+        self.sharded = ShardedModel(self.vlm, self.vlm.get_fsdp_wrapping_policy(), self.device, ops=self.local_ops)
+        n = math.ceil(max(n_train_examples, 1) / self.global_batch_size) * self.global_batch_size
+        self.num_training_steps = self.max_steps if self.max_steps is not None else (n * self.epochs) // self.global_batch_size
+        if self.lr_scheduler_type == "linear-warmup+cosine-decay":
+            self.num_warmup_steps = int(self.num_training_steps * self.warmup_ratio)
+        elif self.lr_scheduler_type == "constant":
+            self.num_warmup_steps = 0
+        else:
+            raise ValueError(f"Learning Rate Schedule with type `{self.lr_scheduler_type}` is not supported!")
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+
+    def current_lr(self) -> float:
+        if self.lr_scheduler_type == "constant":
+            return self.learning_rate
+        return self.learning_rate * cosine_with_warmup(self.step, self.num_warmup_steps, self.num_training_steps)
+
+    def _cast_inputs(self, batch: Dict) -> Dict:
+        """torch FSDP casts every floating-point forward input to the compute dtype at the root
+        (cast_root_forward_inputs default); reproduced at the module boundary."""
+        def c(v):
+            if torch.is_tensor(v):
+                v = v.to(self.device, non_blocking=True)
+                return v.to(torch.bfloat16) if (self.cast_forward_inputs and v.is_floating_point()) else v
+            if isinstance(v, dict):
+                return {k: c(x) for k, x in v.items()}
+            return v
+        return {k: c(v) for k, v in batch.items()}
+
+    def train_step(self, batch: Dict) -> Dict[str, torch.Tensor]:
+        sm = self.sharded
+        sm.begin_step()
+        self.vlm.train()
+        b = self._cast_inputs(batch)
+        loss_dict, _output = self.vlm(
+            input_ids=b["input_ids"], attention_mask=b["attention_mask"], images=b["images"], next_images=b.get("next_images"),
+            camera_name=b["camera_name"], point_cloud=b.get("point_cloud"), next_point_cloud=b.get("next_point_cloud"),
+            tactile=b.get("tactile"), next_tactile=b.get("next_tactile"), labels=b["labels"], actions=b["actions"],
+            proprio=b["proprio"], gripper_xyz=b.get("gripper_xyz"), action_masks=b.get("action_masks"), output_hidden_states=True,
+            repeated_diffusion_steps=self.repeated_diffusion_steps, use_diff=True)
+        loss_dict["total_loss"].backward()
+        sm.finish_backward()
+        self.clip_grad_norm()
+        sm.optimizer_step(self.current_lr(), weight_decay=self.weight_decay)
+        self.step += 1
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
+
+    def clip_grad_norm(self):
+        return self.sharded.grad_norm_and_clip(self.max_grad_norm)

@@ -44,6 +44,29 @@ def test_gemm_modes(dev, am, bm, M, N, K):
     assert fro_rel(out32, ref) < 2e-4
 
 
+@pytest.mark.parametrize("am,bm", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (1000, 520, 1024), (264, 4096, 128), (2200, 1032, 4096)])
+def test_gemm256_modes(dev, am, bm, M, N, K):
+    """Large shapes dispatch to the 256x256 deep-pipelined kernel; compare with fp32 matmul and with the 128 kernel."""
+    from mla_amd import hip
+    a = bfr(M, K, seed=1) if am == 0 else bfr(K, M, seed=1)
+    b = bfr(N, K, seed=2) if bm == 0 else bfr(K, N, seed=2)
+    A = a.float() if am == 0 else a.float().t()
+    B = b.float() if bm == 0 else b.float().t()
+    ref = A @ B.t()
+    ad, bd = a.to(dev), b.to(dev)
+    out32 = hip.gemm(ad, bd, a_mode=am, b_mode=bm, out_dtype=torch.float32, force_generic=3)
+    assert fro_rel(out32, ref) < 2e-4 and max_rel(out32, ref) < 1e-3
+    for _ in range(3):  # race screen: repeated launches must be bit-identical
+        again = hip.gemm(ad, bd, a_mode=am, b_mode=bm, out_dtype=torch.float32, force_generic=3)
+        assert torch.equal(again, out32)
+    out128 = hip.gemm(ad, bd, a_mode=am, b_mode=bm, out_dtype=torch.float32, force_generic=2)
+    assert fro_rel(out128, out32) < 1e-5
+    bias, res = bfr(N, seed=5), bfr(M, N, seed=6)
+    o = hip.gemm(ad, bd, a_mode=am, b_mode=bm, bias=bias.to(dev), residual=res.to(dev), alpha=0.25, force_generic=3)
+    assert fro_rel(o, 0.25 * ref + bias.float() + res.float()) < 4e-3
+
+
 def test_gemm_epilogues(dev):
     from mla_amd import hip
     M, N, K = 300, 264, 160
@@ -259,3 +282,18 @@ def test_adamw_embedding_misc(dev):
     sa, s1 = O.diffusion_tables(100)
     xt = hip.q_sample(x0.to(dev), nz.to(dev), t.to(dev), torch.from_numpy(sa).float().to(dev), torch.from_numpy(s1).float().to(dev))
     assert fro_rel(xt, O.q_sample(x0, t, nz)) < 1e-6
+
+
+def test_tile_transposes(dev):
+    from mla_amd import hip
+    for R, C in [(64, 64), (200, 136), (1096, 4096)]:
+        x = bfr(R, C, seed=R)
+        assert torch.equal(hip.transpose(x.to(dev)).cpu(), x.t().contiguous())
+    wide = bfr(128, 512, seed=3).to(dev)
+    assert torch.equal(hip.transpose(wide[:, 128:256]).cpu(), wide[:, 128:256].t().contiguous().cpu())  # strided source
+    rows, H = 136, 1024
+    x, w = bfr(rows, H, seed=4), bfr(H, seed=5)
+    y, rstd = hip.rmsnorm_fwd(x.to(dev), w.to(dev), 1e-5)
+    assert torch.equal(hip.rmsnorm_apply_t(x.to(dev), w.to(dev), rstd).cpu(), y.t().contiguous().cpu())
+    gu = bfr(72, 2 * 256, seed=6).to(dev)
+    assert torch.equal(hip.swiglu_fwd_t(gu).cpu(), hip.swiglu_fwd(gu).t().contiguous().cpu())
