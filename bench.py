@@ -56,10 +56,10 @@ def build(device, save_level, tiny=False):
     return mla
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle decoder layer (fp32, true 7B dims) fwd+bwd on the host cores; extrapolated to samples/s."""
+def cpu_baseline(seconds_budget=24.0):
+    """Oracle decoder layer (fp32, true 7B dims) fwd+bwd on the host cores (bounded sample), extrapolated to samples/s.
+    Thread counts {64, all cores} are tried (oversubscribing a many-core host slows torch's CPU GEMMs down); the best is reported."""
     from oracle import torch_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
     H, I, nh, S, Bs = 4096, 11008, 32, L_TEXT + S_FUSED + 3, 2
     g = torch.Generator().manual_seed(0)
     names = ["input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
@@ -69,20 +69,28 @@ def cpu_baseline(seconds_budget=20.0):
     p = {n: (torch.randn(*s, generator=g) * 0.02).requires_grad_(True) for n, s in zip(names, shapes)}
     x = torch.randn(Bs, S, H, generator=g).requires_grad_(True)
     cos, sin = O.rope_tables(S, H // nh)
-    times = []
+    ncpu = os.cpu_count() or 1
+    best = None
     t_end = time.time() + seconds_budget
-    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
-        t0 = time.time()
-        O.decoder_layer(x, p, cos, sin, nh, 1e-5).sum().backward()
-        times.append(time.time() - t0)
-        if time.time() > t_end and len(times) >= 2:
+    for nthreads in sorted({min(64, ncpu), ncpu}):
+        torch.set_num_threads(nthreads)
+        times = []
+        for it in range(4):
+            t0 = time.time()
+            O.decoder_layer(x, p, cos, sin, nh, 1e-5).sum().backward()
+            times.append(time.time() - t0)
+            if time.time() > t_end:
+                break
+        t = min(times[1:]) if len(times) > 1 else times[0]
+        if best is None or t < best[0]:
+            best = (t, nthreads, len(times))
+        if time.time() > t_end:
             break
-    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
-    tok_per_s_layer = Bs * S / t
-    samples_per_s = tok_per_s_layer / 32 / (S * R_DIFF)
-    return {"value": samples_per_s, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle LlamaDecoderLayer fwd+bwd fp32 at 7B dims, {Bs}x{S} tokens, median of {len(times)-1} runs "
-                      f"({t:.2f} s), extrapolated x32 layers (encoders/heads excluded)"}
+    t, nthreads, n = best
+    samples_per_s = (Bs * S / t) / 32 / (S * R_DIFF)
+    return {"value": samples_per_s, "unit": "samples/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle LlamaDecoderLayer fwd+bwd fp32 at 7B dims, {Bs}x{S} tokens, best of {n} runs ({t:.2f} s/iter on "
+                      f"{nthreads} threads of {ncpu} host CPUs), extrapolated x32 layers (encoders / heads / optimizer excluded)"}
 
 
 def main():

@@ -72,6 +72,14 @@ int mla_cast_bf16_to_f32(const void* x, float* y, long long n, mla_stream_t stre
 int mla_add_bf16(const void* a, const void* b, void* y, long long n, mla_stream_t stream);
 int mla_gather_rows_bf16(const void* src, const long long* idx, void* out, long long rows, int H, int scatter, mla_stream_t stream);
 
+/* ---- tile transposes feeding the all-NT backward GEMMs (dx = dy W and dW = dy^T x of every Linear on the decoder path,
+ * i.e. autograd of modeling_llama.py:240,351-353,390): dst[c][r] = src[r][c]; the two fused forms recompute the
+ * normalised input (modeling_llama.py:85-90 with the saved rstd) / the SwiGLU product (:240) straight into [C, R]. */
+int mla_transpose_bf16(const void* src, void* dst, long long R, int C, long long ld, long long ldt, mla_stream_t stream);
+int mla_rmsnorm_apply_t(const void* x, const void* w, const float* rstd, void* dst, long long rows, int H, long long ldt,
+                        mla_stream_t stream);
+int mla_swiglu_fwd_t(const void* gu, void* dst, long long rows, int I, long long ldt, mla_stream_t stream);
+
 /* ---- embedding: LlamaModel.embed_tokens modeling_llama.py:975-976 (deterministic, atomics-free backward) */
 int mla_embedding_fwd(const long long* ids, const void* table, void* out, long long tokens, int H, int vocab, mla_stream_t stream);
 int mla_embedding_bwd(const long long* ids, const void* dy, float* grad, long long tokens, int H, int vocab, mla_stream_t stream);

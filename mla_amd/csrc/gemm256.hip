@@ -68,6 +68,8 @@ __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* g, int ld, int 
 
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
+  const bool LGKM_BEFORE = (p.debug & 4) != 0;
+  const int GROUP_M = (p.debug & 8) ? 8 : ((p.debug & 16) ? 16 : 4);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +78,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  constexpr int GROUP_M = 4;
   const int in_group = GROUP_M * num_n;
   const int group_id = pid / in_group;
   const int first_m = group_id * GROUP_M;
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   }
 #define SEG_END()                                                  \
   __builtin_amdgcn_sched_barrier(0);                               \
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 \
+  if (LGKM_BEFORE) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); \
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
   __builtin_amdgcn_s_barrier();                                    \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
   __builtin_amdgcn_sched_barrier(0);

@@ -1,0 +1,175 @@
+"""CPU, world_size = 2 over gloo: the sharding / collective / optimizer logic of mla_amd.fsdp.ShardedModel.
+
+The local arithmetic is injected (TorchLocalOps below -- test infrastructure; the product always uses HipLocalOps), the
+toy model is plain torch so its gradients are copied into the main_grad views the HIP wgrad epilogues would have written.
+Checked against a single-process AdamW on the rank-averaged gradients: identical bf16 compute weights on every rank,
+identical fp32 master weights after gathering the shards, global grad-norm clip, decay / no-decay split."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class TorchLocalOps:
+    def cast_to_bf16(self, src32, dst16):
+        dst16.copy_(src32.to(torch.bfloat16))
+
+    def adamw(self, p32, g32, m, v, p16, lr, betas, eps, wd, step, grad_scale):
+        g = g32 * (grad_scale if grad_scale is not None else 1.0)
+        p32.mul_(1 - lr * wd)
+        m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        bc1, bc2 = 1 - betas[0] ** step, 1 - betas[1] ** step
+        p32.addcdiv_(m, (v.sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
+        p16.copy_(p32.to(torch.bfloat16))
+
+    def sumsq(self, x32, out1, accumulate):
+        s = (x32.double() ** 2).sum().float()
+        out1.copy_(out1 + s if accumulate else s.reshape(1))
+
+    def clip_coef(self, sumsq1, max_norm, coef1, norm1):
+        n = sumsq1.sqrt()
+        coef1.copy_(torch.clamp(max_norm / (n + 1e-6), max=1.0))
+        norm1.copy_(n)
+
+    def stream(self, device):
+        return None
+
+
+class Block(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = nn.Identity()          # marks the block as a "decoder layer" unit for the ordering logic
+        self.a = nn.Linear(d, d, bias=False)
+        self.b = nn.Linear(d, d, bias=True)
+        self.norm = nn.LayerNorm(d)
+        self._grad_hook = None
+
+    def forward(self, x):
+        return x + self.b(torch.tanh(self.a(self.norm(x))))
+
+
+class Toy(nn.Module):
+    def __init__(self, d=24, n=3):
+        super().__init__()
+        self.inp = nn.Linear(10, d)
+        self.frozen = nn.Linear(d, d)
+        self.layers = nn.ModuleList([Block(d) for _ in range(n)])
+        self.out = nn.Linear(d, 5)
+
+    def forward(self, x):
+        x = self.frozen(self.inp(x))
+        for l in self.layers:
+            x = l(x)
+        return self.out(x)
+
+
+def _make(seed=0):
+    torch.manual_seed(seed)
+    m = Toy()
+    m.frozen.requires_grad_(False)
+    return m
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mla_amd.fsdp import ShardedModel
+        model = _make()
+        ref = _make()                                            # fp32 single-process reference (same init)
+        sm = ShardedModel(model, lambda mod: isinstance(mod, Block), torch.device("cpu"), ops=TorchLocalOps())
+        assert [u.name for u in sm.units][0] == "<root>" and len(sm.units) == 4
+        decay = [p for n, p in ref.named_parameters() if p.requires_grad and not (p.ndim <= 1 or n.endswith(".bias"))]
+        nodecay = [p for n, p in ref.named_parameters() if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias"))]
+        opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": nodecay, "weight_decay": 0.0}], lr=1e-2)
+        # the bf16 compute weights start as bf16(init); make the reference start from the same rounded values? no: masters
+        # are fp32(init) on both sides, the compute copy is only used for forward/backward
+        for step in range(3):
+            sm.begin_step()
+            xs = [torch.randn(6, 10, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
+            # --- sharded side: this rank's micro-batch through the bf16 compute weights
+            out = model(xs[rank].to(torch.bfloat16))
+            out.float().pow(2).mean().backward()
+            for p in model.parameters():
+                if p.requires_grad:
+                    p.main_grad.copy_(p.grad.float())
+                    p._mg_touched = True
+                    p.grad = None
+            sm.finish_backward()
+            norm = sm.grad_norm_and_clip(0.5)
+            sm.optimizer_step(1e-2, weight_decay=0.1)
+            # --- reference: same bf16 compute (weights rounded to bf16), gradients averaged over ranks, fp32 AdamW
+            grads = None
+            for r in range(world):
+                shadow = _make()
+                shadow.load_state_dict(ref.state_dict())
+                shadow.frozen.requires_grad_(False)
+                shadow.to(torch.bfloat16)
+                shadow(xs[r].to(torch.bfloat16)).float().pow(2).mean().backward()
+                g = [p.grad.float() if p.grad is not None else None for p in shadow.parameters()]
+                grads = g if grads is None else [a + b if a is not None else None for a, b in zip(grads, g)]
+            for p, g in zip(ref.parameters(), grads):
+                p.grad = None if g is None else g / world
+            total = torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.grad is not None], 0.5)
+            opt.step()
+            assert abs(float(norm) - float(total)) < 1e-4 * max(1.0, float(total)), (float(norm), float(total))
+            full = sm.full_state_dict_fp32()
+            for n, p in ref.named_parameters():
+                assert torch.allclose(full[n], p.detach(), rtol=2e-5, atol=2e-6), (step, n)
+                mine = dict(model.named_parameters())[n]
+                assert mine.dtype == torch.bfloat16 and torch.equal(mine.detach(), full[n].to(torch.bfloat16)), (step, n)
+        # shards partition the flat buffers and only the trainable region carries optimizer state
+        for u in sm.units:
+            assert u.n_total % (8 * world) == 0 and u.master_train.numel() * world == u.n_train
+            assert u.exp_avg.numel() == u.shard_train
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_model_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_sharded_model_world1_matches_adamw():
+    from mla_amd.fsdp import ShardedModel
+    model, ref = _make(), _make()
+    sm = ShardedModel(model, lambda mod: isinstance(mod, Block), torch.device("cpu"), ops=TorchLocalOps())
+    opt = torch.optim.AdamW([p for p in ref.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.0)
+    x = torch.randn(4, 10)
+    for _ in range(2):
+        sm.begin_step()
+        model(x.to(torch.bfloat16)).float().pow(2).mean().backward()
+        shadow = _make()
+        shadow.load_state_dict(ref.state_dict())
+        shadow.frozen.requires_grad_(False)
+        shadow.to(torch.bfloat16)
+        shadow(x.to(torch.bfloat16)).float().pow(2).mean().backward()
+        for p, q, s in zip(model.parameters(), ref.parameters(), shadow.parameters()):
+            if p.requires_grad:
+                p.main_grad.copy_(p.grad.float())
+                p._mg_touched = True
+                p.grad = None
+                q.grad = s.grad.float()
+        sm.finish_backward()
+        sm.grad_norm_and_clip(None)
+        sm.optimizer_step(1e-2)
+        opt.step()
+    full = sm.full_state_dict_fp32()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(full[n], p.detach(), rtol=2e-5, atol=2e-6), n
+    # a parameter that stops receiving gradients is presented with ZERO gradient (not a stale one)
+    sm.begin_step()
+    sm.finish_backward()
+    assert all(float(p.main_grad.abs().max()) == 0.0 for p in model.parameters() if p.requires_grad)

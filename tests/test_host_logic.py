@@ -1,0 +1,103 @@
+"""CPU: host-side logic of the drop-in modules (no kernels): action tokenizer (bit-exact), diffusion tables, sequence
+splice plan vs the reference's per-sample loop (oracle restatement), module surface / state-dict names, LR schedule."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe
+from oracle import torch_oracle as O
+from tests_shapes import MLA_TINY_SHAPES
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_action_tokenizer_bit_exact_vs_reference_golden():
+    from mla_amd.action_tokenizer import ActionTokenizer
+    from mla_amd.backbones import SyntheticLlamaTokenizer
+    comp = np.load(os.path.join(G, "components.npz"))
+    at = ActionTokenizer(SyntheticLlamaTokenizer(32000))
+    ids = at.encode_ids(comp["at_actions"])
+    assert ids.dtype == comp["at_ids"].dtype and np.array_equal(ids, comp["at_ids"])
+    assert np.array_equal(at.decode_token_ids_to_actions(ids), comp["at_decoded"])
+    assert ids.min() == 31744 and ids.max() == 31999 and at.action_token_begin_idx == 32000 - 257
+    assert np.array_equal(at.encode_ids(np.zeros((0,))), np.zeros((0,), dtype=ids.dtype))            # empty input
+    assert at.encode_ids(np.array([np.nextafter(1.0, 2.0), -np.inf, np.inf])).tolist() == [31744, 31999, 31744]
+
+
+def test_diffusion_tables_match_reference_golden():
+    from mla_amd.diffusion import create_diffusion
+    comp = np.load(os.path.join(G, "components.npz"))
+    d = create_diffusion(timestep_respacing="", noise_schedule="squaredcos_cap_v2", diffusion_steps=100)
+    assert d.num_timesteps == 100
+    assert np.array_equal(d.betas, comp["betas"])
+    assert np.array_equal(d.sqrt_alphas_cumprod, comp["sqrt_ac"])
+    assert np.array_equal(d.sqrt_one_minus_alphas_cumprod, comp["sqrt_1mac"])
+
+
+@pytest.mark.parametrize("L,lens,T", [(16, [16, 13], 1), (12, [12, 12, 9, 5], 4), (8, [8], 1)])
+def test_splice_plan_matches_reference_loop(L, lens, T):
+    from mla_amd.prismatic import build_splice_plan
+    B, nf, ins = len(lens), 513, 2 + T
+    g = torch.Generator().manual_seed(L)
+    ids = torch.randint(3, 500, (B, L), generator=g)
+    ids[:, 0] = 1
+    for b, n in enumerate(lens):
+        ids[b, n - 1] = 2
+        ids[b, n:] = 512
+    am = ids != 512
+    labels = torch.where(am, ids, torch.full_like(ids, -100))
+    flat, k, mask, labs = build_splice_plan(ids, am, labels, nf, ins, 2)
+    ks, ref_mask, ref_labs = O.splice_sequence(ids, am, labels, nf, T)
+    assert torch.equal(k.squeeze(1), ks) and torch.equal(mask, ref_mask.bool()) and torch.equal(labs, ref_labs)
+    # gather plan reproduces the reference's concatenation order on a pool of distinct integers
+    S = L + nf + ins
+    pool = torch.arange(B * S).view(B, S)          # [text L | fused nf | inserted ins]
+    got = pool.reshape(-1)[flat].view(B, S)
+    for b in range(B):
+        kk = int(ks[b])
+        z = torch.cat([pool[b, :1], pool[b, L:L + nf], pool[b, 1:L]])
+        exp = torch.cat([z[:kk], pool[b, L + nf:], z[kk:]])
+        assert torch.equal(got[b], exp)
+    assert len(set(flat.tolist())) == flat.numel()  # injective -> the backward scatter needs no atomics
+
+
+def test_module_surface_and_state_dict_names():
+    from mla_amd.backbones import LLaMa2LLMBackbone
+    from mla_amd.llama import LlamaConfig, LlamaDecoderLayer
+    from mla_amd.mla import MLA
+    from mla_amd.prismatic import PrismaticVLM
+    bb = LLaMa2LLMBackbone(config=LlamaConfig(**recipe.TINY_LLAMA), pad_to_multiple_of=1)
+    vlm = PrismaticVLM("tiny", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_pointcloud=True, use_contrastive=True,
+                       use_generation=False)
+    m = MLA(vlm, None, token_size=recipe.TOKEN_SIZE, future_action_window_size=0, use_diff=True, use_pointcloud=True,
+            use_contrastive=True)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == MLA_TINY_SHAPES      # == the reference's key set
+    assert all(p.dtype == torch.float32 for p in m.parameters())                          # fp32 at load (scripts/train.py:303-307)
+    assert bb.transformer_layer_cls is LlamaDecoderLayer and len(bb.tokenizer) == 513
+    assert float(m.vlm.final_layer.mlp.fc2.weight.abs().max()) == 0.0                     # zero-init read-out (prismatic.py:320-321)
+    m.freeze_backbones("finetune")
+    assert m.trainable_module_keys == ["vlm.llm_backbone", "vlm.projector_2d", "vlm.proprio_embedder", "vlm.x_embedder",
+                                       "vlm.t_embedder", "vlm.final_layer", "vlm.projector_3d"]
+    assert not any(p.requires_grad for p in m.vlm.vision_tower_2d.parameters())
+    assert not any(p.requires_grad for p in m.vlm.vision_tower_3d.parameters())
+    pol = m.get_fsdp_wrapping_policy()
+    units = [n for n, mod in m.named_modules() if pol(mod)]
+    assert sum("layers." in u for u in units) == 9 and "vlm.vision_tower_2d" in units and "vlm.projector_3d" in units
+    with pytest.raises(ValueError):
+        m.freeze_backbones("align")
+    with pytest.raises(NotImplementedError):
+        PrismaticVLM("x", bb, token_size=recipe.TOKEN_SIZE, use_diff=True)                # use_generation defaults to True
+
+
+def test_lr_schedule_and_camera_constants():
+    from mla_amd.fuser import get_camera_params, projection_constants
+    from mla_amd.strategy import cosine_with_warmup
+    assert cosine_with_warmup(0, 10, 100) == 0.0 and cosine_with_warmup(10, 10, 100) == 1.0
+    assert abs(cosine_with_warmup(55, 10, 100) - 0.5 * (1 + math.cos(math.pi * 0.5))) < 1e-12
+    with pytest.raises(ValueError):
+        get_camera_params("nope")
+    Rw, tw, Ks = projection_constants("rlbench_front")
+    assert abs(float(Ks[0, 0]) - (-307.7174807 * 3)) < 1e-3 and abs(float(Ks[0, 2]) - 336.0) < 1e-4
