@@ -34,7 +34,7 @@ def model_flops_per_sample(S, H=4096, I=11008, L=32, V=32064, R=R_DIFF):
     return dec, dec + lm
 
 
-def build(device, save_level, tiny=False):
+def build(device, save_level, tiny=False, use_pointcloud=True):
     from mla_amd.backbones import LLaMa2LLMBackbone
     from mla_amd.llama import LlamaConfig
     from mla_amd.mla import MLA
@@ -46,10 +46,10 @@ def build(device, save_level, tiny=False):
         else:
             cfg = LlamaConfig(activation_save_level=save_level)   # Llama-2-7b
         bb = LLaMa2LLMBackbone("llama2-7b-pure", config=cfg)
-        vlm = PrismaticVLM("mla-7b", bb, token_size=cfg.hidden_size, action_dim=7, use_diff=True, use_pointcloud=True,
-                           use_contrastive=True, use_generation=False, future_action_window_size=0)
+        vlm = PrismaticVLM("mla-7b", bb, token_size=cfg.hidden_size, action_dim=7, use_diff=True, use_pointcloud=use_pointcloud,
+                           use_contrastive=use_pointcloud, use_generation=False, future_action_window_size=0)
         mla = MLA(vlm, None, token_size=cfg.hidden_size, action_dim=7, future_action_window_size=0, use_diff=True,
-                  use_pointcloud=True, use_contrastive=True, use_generation=False)
+                  use_pointcloud=use_pointcloud, use_contrastive=use_pointcloud, use_generation=False)
         # <BOD>, <EOD> added by scripts/train.py:132-155 stay inside the 32064 rows; give final_layer a non-zero read-out
         torch.nn.init.normal_(mla.vlm.final_layer.mlp.fc2.weight, std=0.02)
     mla.freeze_backbones("finetune")
@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--save-level", type=int, default=1, help="activation policy: 2 keep all, 1 recompute cheap elementwise, 0 full recompute")
     ap.add_argument("--tiny", action="store_true", help="small model for smoke runs (NOT the benchmark config)")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 4],
+                    help="BASELINE.json configs index: 1 = 7B SFT (the headline metric; also configs[2] when --gpus 8), "
+                         "4 = pretrain shape, use_pointcloud=False, S=2048, activation checkpointing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
     args = ap.parse_args()
@@ -120,14 +123,18 @@ def main():
     from mla_amd.strategy import FSDPStrategy
     from mla_amd.synthetic import make_batch
 
-    torch.manual_seed(42 + rank)
-    mla = build(device, args.save_level, args.tiny)
+    l_text = L_TEXT if args.config == 1 else 2048 - S_FUSED - 3
+    if args.config == 4:
+        args.save_level = 0                    # the config names activation checkpointing (4x the tokens of config 1)
+    torch.manual_seed(42)                      # identical initial weights on every rank (scripts/train.py:76 seed)
+    mla = build(device, args.save_level, args.tiny, use_pointcloud=(args.config == 1))
+    torch.manual_seed(42 + rank)               # rank-local noise / timesteps / FPS starts, like the reference's per-rank RNG
     strat = FSDPStrategy(mla, local_rank, stage="finetune", global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
                          learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
                          enable_gradient_checkpointing=False, repeated_diffusion_steps=R_DIFF)
     strat.run_setup(n_train_examples=10_000)
-    batch = make_batch(B=B_PER_GPU, L_text=L_TEXT, seed=42 + rank, device=device)
-    S = L_TEXT + S_FUSED + 3
+    batch = make_batch(B=B_PER_GPU, L_text=l_text, seed=42 + rank, device=device, use_pointcloud=(args.config == 1))
+    S = l_text + S_FUSED + 3
 
     def sync():
         torch.cuda.synchronize()
@@ -161,15 +168,17 @@ def main():
             tsum = sum(t for t, _, _ in big) * 1e-3
             fsum = sum(fl for _, fl, _ in big)
             ach = fsum / tsum / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm128_kernel<AMODE,BMODE> (bf16 MFMA GEMM family, launches >= 0.1 TFLOP)",
+            roof = {"bound": "mfma", "kernel": "gemm256_kernel<0,0> (+ gemm128_kernel for small shapes): bf16 MFMA GEMM launches >= 0.1 TFLOP",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": None, "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
                     "gemm_ms_per_step": round(tsum / args.steps * 1e3, 1)}
         out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE.json configs[1]: MLA-Llama2-7B SFT, use_pointcloud+use_contrastive, 672x672(+mask) image + "
-                                      "1024 points + 32 text tokens, per-GPU batch 8 x 4 diffusion repeats = 32 x 548 tokens"
+               "config": {"workload": ("BASELINE.json configs[1]: MLA-Llama2-7B SFT, use_pointcloud+use_contrastive, 672x672(+mask) image + "
+                                       "1024 points + 32 text tokens, per-GPU batch 8 x 4 diffusion repeats = 32 x 548 tokens" if args.config == 1 else
+                                       "BASELINE.json configs[4]: MLA pretrain shape, use_pointcloud=False, S=2048, activation checkpointing, "
+                                       "per-GPU batch 8 x 4 diffusion repeats = 32 x 2048 tokens")
                                       + (" [TINY SMOKE MODEL - not the benchmark]" if args.tiny else ""),
                           "model": "mla-llama2-7b" if not args.tiny else "tiny", "global_batch": B_PER_GPU * world, "seq_len": S,
                           "parallelism": f"fsdp-rccl x{world}" if world > 1 else "single-gpu", "activation_save_level": args.save_level,

@@ -123,13 +123,21 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 }
 
 // out[n] (+)= sum_p partial[p][n]   (deterministic second stage for dw / bias-grad reductions)
+// 64 columns x 4 row-lanes per block: 4x the lanes of a column-per-thread layout (P is up to 512, N ~ 4096)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                               int P, int N, int accumulate) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += partial[(size_t)p * N + n];
-  out[n] = accumulate ? out[n] + s : s;
+  if (n < N)
+    for (int p = rl; p < P; p += 4) s += partial[(size_t)p * N + n];
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) {
+    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    out[n] = accumulate ? out[n] + t : t;
+  }
 }
 
 // partial[blockIdx.y][n] = sum over this block's row slice of dy[r][n]   (bias gradients)
@@ -421,12 +429,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
-// partial[blockIdx] = sum of squares of this block's slice (deterministic two-stage grad-norm)
+// partial[blockIdx] = sum of squares of this block's slice (deterministic two-stage grad-norm); 16-B loads
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, long long n) {
   __shared__ float scratch[16];
-  float s = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
-  s = block_sum(s, scratch);
+  float s0 = 0.f, s1 = 0.f;
+  const long long n4 = n >> 2;
+  const f32x4_t* x4 = (const f32x4_t*)x;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4_t v = x4[i];
+    s0 += v[0] * v[0] + v[1] * v[1];
+    s1 += v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[(n4 << 2) + threadIdx.x]; s0 += v * v; }
+  const float s = block_sum(s0 + s1, scratch);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 // out[0] (+)= sum(partial[0..P))
@@ -506,7 +521,7 @@ extern "C" int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
                      (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
   if (dw)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
   MLA_LAUNCH_CHECK();
 }
 
@@ -518,7 +533,7 @@ extern "C" int mla_colsum_bf16(const void* dy, float* out, int accumulate, int r
   const int rs = mla_colsum_blocks(rows);
   MLA_CHECK_ARG(workspace_bytes >= (size_t)rs * N * sizeof(float), "mla_colsum_bf16: workspace too small");
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, (const bf16_t*)dy, workspace, rows, N, ld);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, workspace, out, rs, N, accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, workspace, out, rs, N, accumulate);
   MLA_LAUNCH_CHECK();
 }
 
@@ -610,11 +625,11 @@ extern "C" int mla_adamw_step(float* p, const float* g, float* m, float* v, void
   MLA_LAUNCH_CHECK();
 }
 
-// out[0] (+)= sum(x^2); workspace >= 1024 floats
+// out[0] (+)= sum(x^2); workspace >= 2048 floats
 extern "C" int mla_sumsq_f32(const float* x, long long n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
                              hipStream_t stream) {
-  MLA_CHECK_ARG(x && out && workspace && workspace_bytes >= 1024 * sizeof(float), "mla_sumsq_f32: bad args");
-  const int nb = grid_for(n, 1024);
+  MLA_CHECK_ARG(x && out && workspace && workspace_bytes >= 2048 * sizeof(float) && AL16(x), "mla_sumsq_f32: bad args");
+  const int nb = grid_for(n / 4 + 1, 2048);
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, x, workspace, n);
   hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, stream, workspace, out, nb, accumulate);
   MLA_LAUNCH_CHECK();

@@ -57,7 +57,7 @@ class FlatUnit:
     frozen], each in module order (keeps q|k|v and gate|up adjacent), every tensor padded to 8 elements."""
 
     def __init__(self, name: str, named_params: Sequence[Tuple[str, nn.Parameter]], device, world: int, rank: int, ops,
-                 no_decay: Callable[[str, nn.Parameter], bool]):
+                 no_decay: Callable[[str, nn.Parameter], bool], process_group=None, sync_from_rank0: bool = True):
         self.name, self.world, self.rank, self.ops, self.device = name, world, rank, ops, device
         decay = [(n, p) for n, p in named_params if p.requires_grad and not no_decay(n, p)]
         nodecay = [(n, p) for n, p in named_params if p.requires_grad and no_decay(n, p)]
@@ -81,6 +81,8 @@ class FlatUnit:
         full32 = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         for n, p, o in self.params:
             full32[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+        if world > 1 and sync_from_rank0:
+            dist.broadcast(full32, src=0, group=process_group)      # every rank starts from rank 0's weights (FSDP sync_module_states)
         self.flat16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=device)
         ops.cast_to_bf16(full32, self.flat16)
         # fp32 master weights: the trainable region and the frozen region are each sharded 1/world, so that the weights,
@@ -201,7 +203,7 @@ class ShardedModel:
     def _add_unit(self, name, mod, named, no_decay):
         if not named:
             return
-        u = FlatUnit(name, named, self.device, self.world, self.rank, self.ops, no_decay)
+        u = FlatUnit(name, named, self.device, self.world, self.rank, self.ops, no_decay, self.pg)
         u.module = mod
         self.units.append(u)
 
@@ -235,7 +237,7 @@ class ShardedModel:
         region = u.flat16[:u.n_train]
         shard = region[self.rank * u.shard_train:(self.rank + 1) * u.shard_train]
         if dist.get_backend(self.pg) == "nccl":
-            dist.all_gather_into_tensor(region, shard, group=self.pg)
+            dist.all_gather_into_tensor(region, shard.clone(), group=self.pg)   # separate input: no reliance on in-place support
         else:
             parts = [torch.empty_like(shard) for _ in range(self.world)]
             dist.all_gather(parts, shard.clone(), group=self.pg)

@@ -296,7 +296,7 @@ def adamw_step(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=
 
 
 def sumsq(x32, out1, accumulate):
-    ws = workspace(4096, x32.device)
+    ws = workspace(8192, x32.device)
     call("mla_sumsq_f32", _p(x32), x32.numel(), _p(out1), 1 if accumulate else 0, _p(ws), ws.numel())
 
 

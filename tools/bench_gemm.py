@@ -8,11 +8,11 @@ from mla_amd import hip
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 17536
 dev = torch.device("cuda:0")
 H, I = 4096, 11008
-shapes = [  # name, M, N, K, a_mode, b_mode
-    ("qkv fwd  NT", T, 3 * H, H, 0, 0), ("o    fwd  NT", T, H, H, 0, 0), ("gu   fwd  NT", T, 2 * I, H, 0, 0),
-    ("down fwd  NT", T, H, I, 0, 0), ("qkv dgrad NN", T, H, 3 * H, 0, 1), ("gu  dgrad NN", T, H, 2 * I, 0, 1),
-    ("down dgrad NN", T, I, H, 0, 1), ("qkv wgrad TN", 3 * H, H, T, 1, 1), ("gu  wgrad TN", 2 * I, H, T, 1, 1),
-    ("down wgrad TN", H, I, T, 1, 1),
+shapes = [  # name, M, N, K, a_mode, b_mode -- every large GEMM of a decoder layer in the all-NT formulation
+    ("qkv fwd", T, 3 * H, H, 0, 0), ("o fwd", T, H, H, 0, 0), ("gu fwd", T, 2 * I, H, 0, 0), ("down fwd", T, H, I, 0, 0),
+    ("qkv dgrad", T, H, 3 * H, 0, 0), ("o dgrad", T, H, H, 0, 0), ("gu dgrad", T, H, 2 * I, 0, 0), ("down dgrad", T, I, H, 0, 0),
+    ("qkv wgrad", 3 * H, H, T, 0, 0), ("o wgrad", H, H, T, 0, 0), ("gu wgrad", 2 * I, H, T, 0, 0), ("down wgrad", H, I, T, 0, 0),
+    ("qkv wgrad TN(tr)", 3 * H, H, T, 1, 1),
 ]
 
 
