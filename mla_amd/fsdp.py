@@ -57,8 +57,10 @@ class FlatUnit:
     frozen], each in module order (keeps q|k|v and gate|up adjacent), every tensor padded to 8 elements."""
 
     def __init__(self, name: str, named_params: Sequence[Tuple[str, nn.Parameter]], device, world: int, rank: int, ops,
-                 no_decay: Callable[[str, nn.Parameter], bool], process_group=None, sync_from_rank0: bool = True):
+                 no_decay: Callable[[str, nn.Parameter], bool], process_group=None, sync_from_rank0: bool = True,
+                 collectives: Optional[bool] = None):
         self.name, self.world, self.rank, self.ops, self.device = name, world, rank, ops, device
+        coll = (world > 1) if collectives is None else collectives   # separate shard buffers + real collectives
         decay = [(n, p) for n, p in named_params if p.requires_grad and not no_decay(n, p)]
         nodecay = [(n, p) for n, p in named_params if p.requires_grad and no_decay(n, p)]
         frozen = [(n, p) for n, p in named_params if not p.requires_grad]
@@ -81,14 +83,14 @@ class FlatUnit:
         full32 = torch.zeros(self.n_total, dtype=torch.float32, device=device)
         for n, p, o in self.params:
             full32[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
-        if world > 1 and sync_from_rank0:
+        if coll and sync_from_rank0:
             dist.broadcast(full32, src=0, group=process_group)      # every rank starts from rank 0's weights (FSDP sync_module_states)
         self.flat16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=device)
         ops.cast_to_bf16(full32, self.flat16)
         # fp32 master weights: the trainable region and the frozen region are each sharded 1/world, so that the weights,
         # gradient shard and AdamW moments of one element always live on the same rank
         nf = (self.n_total - self.n_train) // world
-        if world == 1:
+        if not coll:
             self.master_train, self.master_frozen = full32[:self.n_train], full32[self.n_train:]
         else:
             self.master_train = full32[rank * self.shard_train:(rank + 1) * self.shard_train].clone()
@@ -96,7 +98,7 @@ class FlatUnit:
         del full32
         self.grad32 = torch.zeros(self.n_train, dtype=torch.float32, device=device) if self.trainable else None
         if self.trainable:
-            self.gshard = self.grad32 if world == 1 else torch.zeros(self.shard_train, dtype=torch.float32, device=device)
+            self.gshard = self.grad32 if not coll else torch.zeros(self.shard_train, dtype=torch.float32, device=device)
             self.exp_avg = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
             self.exp_avg_sq = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
         # ---- re-point the module parameters at the bf16 compute storage; install fp32 main_grad views
@@ -141,7 +143,7 @@ class FlatUnit:
         n = self.flat16.numel() * 2 + (self.master_train.numel() + self.master_frozen.numel()) * 4
         if self.trainable:
             n += self.grad32.numel() * 4 + (self.exp_avg.numel() + self.exp_avg_sq.numel()) * 4
-            if self.world > 1:
+            if self.gshard is not self.grad32:
                 n += self.gshard.numel() * 4
         return n
 
@@ -155,6 +157,10 @@ class ShardedModel:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        import os
+        # MLA_FORCE_COLLECTIVES=1 runs the sharded code path (separate shards, RCCL calls, side stream) even with one rank:
+        # used to validate the collective plumbing on a single-GPU box
+        self.coll = self.world > 1 or (os.environ.get("MLA_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
         self.ops = ops if ops is not None else HipLocalOps()
         no_decay = no_decay or (lambda n, p: p.ndim <= 1 or n.endswith(".bias"))   # fsdp.py:236-256
         # ---- unit discovery (outermost matches of the policy; the remainder folds into the root unit)
@@ -193,23 +199,23 @@ class ShardedModel:
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
         self._coef = torch.ones(1, dtype=torch.float32, device=device)
         self._norm = torch.zeros(1, dtype=torch.float32, device=device)
-        self.comm_stream = self.ops.stream(device) if self.world > 1 else None
+        self.comm_stream = self.ops.stream(device) if self.coll else None
         # reduce-scatter launch hooks on the decoder layers (fires when the layer's backward has been enqueued)
         for u in self.units:
             mod = getattr(u, "module", None)
-            if mod is not None and hasattr(mod, "_grad_hook") and u.trainable and self.world > 1:
+            if mod is not None and hasattr(mod, "_grad_hook") and u.trainable and self.coll:
                 mod._grad_hook = (lambda uu=u: self._launch_reduce_scatter(uu))
 
     def _add_unit(self, name, mod, named, no_decay):
         if not named:
             return
-        u = FlatUnit(name, named, self.device, self.world, self.rank, self.ops, no_decay, self.pg)
+        u = FlatUnit(name, named, self.device, self.world, self.rank, self.ops, no_decay, self.pg, collectives=self.coll)
         u.module = mod
         self.units.append(u)
 
     # ------------------------------------------------------------------------------------------ collectives
     def _launch_reduce_scatter(self, u: FlatUnit):
-        if self.world == 1 or not u.trainable or u.rs_event is not None:
+        if not self.coll or not u.trainable or u.rs_event is not None:
             return
         cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if cur is not None:
@@ -263,7 +269,7 @@ class ShardedModel:
         for u in self.units:
             if u.trainable:
                 u.finish_backward()
-        if self.world > 1:
+        if self.coll:
             for u in self.units:
                 if u.trainable and u.rs_event is None:
                     self._launch_reduce_scatter(u)
@@ -280,7 +286,7 @@ class ShardedModel:
             if u.trainable:
                 self.ops.sumsq(u.gshard, self._sumsq, not first)
                 first = False
-        if self.world > 1:
+        if self.coll:
             dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.pg)
         self.ops.clip_coef(self._sumsq, float(max_norm) if max_norm is not None else 3.0e38, self._coef, self._norm)
         return self._norm
@@ -294,7 +300,7 @@ class ShardedModel:
                 self.ops.adamw(u.master_train[ls:le], u.gshard[ls:le], u.exp_avg[ls:le], u.exp_avg_sq[ls:le],
                                u.flat16[g0:g0 + (le - ls)], lr, betas, eps, weight_decay if decayed else 0.0, self.step_count,
                                self._coef)
-            if self.world > 1:
+            if self.coll:
                 if self.device.type == "cuda":
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(self.device))
@@ -317,7 +323,7 @@ class ShardedModel:
         return out
 
     def _gather_master(self, u: FlatUnit):
-        if self.world == 1:
+        if not self.coll:
             return torch.cat([u.master_train, u.master_frozen])
         full = torch.empty(u.n_total, dtype=torch.float32, device=self.device)
         parts_t = [torch.empty(u.shard_train, dtype=torch.float32, device=self.device) for _ in range(self.world)]
