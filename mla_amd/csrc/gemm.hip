@@ -299,7 +299,7 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
   // the 256x256 kernel is used for k-contiguous operands only: its reduction-major (ds_read_b64_tr_b16) path is slower than
   // the 128x128 kernel's (issue-limited at 2 waves/SIMD); force_generic == 3 forces it for tests / experiments
   if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 &&
-      ((force_generic == 0 && a_mode == 0 && b_mode == 0) || force_generic == 3))
+      a_mode == 0 && b_mode == 0 && (force_generic == 0 || force_generic == 3))
     return mla_gemm256_dispatch(&p, a_mode, b_mode, stream);
   if (mfma_ok) {
     if (a_mode == 0 && b_mode == 0) return launch128<0, 0>(p, stream);

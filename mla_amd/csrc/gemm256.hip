@@ -11,8 +11,9 @@
 //     ph1: read SA0,SB0 -> Q00   ph2: read SB1 -> Q01   ph3: read SA1 -> Q11   ph4: (no read) -> Q10
 //   Every phase also issues ONE half-tile of global_load_lds (2 x 16 B per lane) for a future K-tile, into a slot whose
 //   last reader finished >= 2 phases earlier:  ph1: SB1(t+1)  ph2: SA1(t+1)  ph3: SA0(t+2)  ph4: SB0(t+2).
-//   Loads are therefore 1-2 K-tiles ahead and are retired with a COUNTED s_waitcnt vmcnt(8) (4 half-tiles stay in
-//   flight across the barriers; never vmcnt(0) in the loop).
+//   Loads are therefore 1-2 K-tiles ahead and are retired with a COUNTED s_waitcnt vmcnt(6) (3 half-tiles stay in
+//   flight across the barriers; never vmcnt(0) in the loop). The next tile's B0 fragments are prefetched in ph4, so the
+//   per-phase ds_read counts are 8/4/8/4 (ablation: LDS reads + LDS-DMA writes cost ~35 % of the MFMA-only rate).
 // The two wave rows run staggered by one barrier (wave row 1 executes one extra s_barrier up front), so on every SIMD
 // one wave is in its ds_read/issue segment while its partner is in its MFMA segment; s_setprio(1) wraps the MFMAs.
 #include "common.h"
@@ -68,8 +69,9 @@ __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* g, int ld, int 
 
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
-  const bool LGKM_BEFORE = (p.debug & 4) != 0;
-  const int GROUP_M = (p.debug & 8) ? 8 : ((p.debug & 16) ? 16 : 4);
+  const bool LGKM_BEFORE = false;
+  const int GROUP_M = 4;
+  const bool NO_READ = (p.debug & 4) != 0, NO_STAGE = (p.debug & 8) != 0, NO_BAR2 = (p.debug & 16) != 0, NO_BAR1 = (p.debug & 32) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,8 +113,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   do {                                                                                            \
     const size_t back__ = (TCNT < nt) ? 0 : (size_t)TCNT * (STEP); /* dummy re-load of K-tile 0 past the end */ \
     char* dst__ = smem + (TCNT & 1) * BUF + (SLOTOFF) + wave * 2048;                              \
-    glds16(PTR[0] - back__, dst__);                                                               \
-    glds16(PTR[1] - back__, dst__ + 1024);                                                        \
+    if (!NO_STAGE) {                                                                              \
+      glds16(PTR[0] - back__, dst__);                                                             \
+      glds16(PTR[1] - back__, dst__ + 1024);                                                      \
+    }                                                                                             \
     PTR[0] += (STEP); PTR[1] += (STEP); ++TCNT;                                                   \
   } while (0)
 
@@ -167,20 +171,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+  if (NO_READ) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fa[i][0] = fa[i][1] = bf16x8_t{}; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { fb0[i][0] = fb0[i][1] = fb1[i][0] = fb1[i][1] = bf16x8_t{}; }
+  }
 
 #define READ_A(SLOTP)                                              \
-  _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) {               \
+  if (!NO_READ) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) { \
     fa[rb][0] = ldA(SLOTP, rb, 0); fa[rb][1] = ldA(SLOTP, rb, 1);  \
   }
 #define READ_B(DST, SLOTP)                                          \
-  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                \
+  if (!NO_READ) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {  \
     DST[cb][0] = ldB(SLOTP, cb, 0); DST[cb][1] = ldB(SLOTP, cb, 1); \
   }
 #define SEG_END()                                                  \
   __builtin_amdgcn_sched_barrier(0);                               \
   if (LGKM_BEFORE) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); \
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
-  __builtin_amdgcn_s_barrier();                                    \
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
+  if (!NO_BAR1) __builtin_amdgcn_s_barrier();                      \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
   __builtin_amdgcn_sched_barrier(0);
 #define MMA(QI, QJ, FB)                                                                                          \
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   __builtin_amdgcn_s_setprio(0);                                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                                             \
   asm volatile("" ::: "memory");                                                                                 \
-  __builtin_amdgcn_s_barrier();                                                                                  \
+  if (!NO_BAR2) __builtin_amdgcn_s_barrier();                                                                    \
   asm volatile("" ::: "memory");
 
   // ---- prologue: K-tiles 0 (all four slots) and 1 (SA0, SB0)
@@ -205,31 +215,39 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   STAGE(pB0, tB0, stepB, SB0);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // SA0(0), SB0(0) of this wave have landed
   __builtin_amdgcn_s_barrier();
+  READ_B(fb0, smem + SB0)                            // B0 fragments of K-tile 0 (later tiles prefetch theirs in phase 4)
   if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger wave row 1 by one barrier
 
-  for (int t = 0; t < nt; ++t) {
-    const char* buf = smem + (t & 1) * BUF;
-    // phase 1
-    STAGE(pB1, tB1, stepB, SB1);
-    READ_A(buf + SA0)
-    READ_B(fb0, buf + SB0)
-    SEG_END()
-    MMA(0, 0, fb0)
-    // phase 2
-    STAGE(pA1, tA1, stepA, SA1);
-    READ_B(fb1, buf + SB1)
-    SEG_END()
-    MMA(0, 1, fb1)
-    // phase 3
-    STAGE(pA0, tA0, stepA, SA0);
-    READ_A(buf + SA1)
-    SEG_END()
-    MMA(1, 1, fb1)
-    // phase 4
-    STAGE(pB0, tB0, stepB, SB0);
-    SEG_END()
-    MMA(1, 0, fb0)
+  // One K-tile. X holds the B0 fragments of this tile on entry; Y receives B1 (phase 2) and then the NEXT tile's B0
+  // (phase 4), so the fragment reads are spread 8 / 4 / 8 / 4 over the four phases instead of 12 / 4 / 8 / 0.
+#define TILE_BODY(X, Y, T_)                                          \
+  {                                                                  \
+    const char* buf = smem + ((T_) & 1) * BUF;                       \
+    const char* nbuf = smem + (((T_) + 1) & 1) * BUF;                \
+    STAGE(pB1, tB1, stepB, SB1);                                     \
+    READ_A(buf + SA0)                                                \
+    SEG_END()                                                        \
+    MMA(0, 0, X)                                                     \
+    STAGE(pA1, tA1, stepA, SA1);                                     \
+    READ_B(Y, buf + SB1)                                             \
+    SEG_END()                                                        \
+    MMA(0, 1, Y)                                                     \
+    STAGE(pA0, tA0, stepA, SA0);                                     \
+    READ_A(buf + SA1)                                                \
+    SEG_END()                                                        \
+    MMA(1, 1, Y)                                                     \
+    STAGE(pB0, tB0, stepB, SB0);                                     \
+    READ_B(Y, nbuf + SB0)                                            \
+    SEG_END()                                                        \
+    MMA(1, 0, X)                                                     \
   }
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    TILE_BODY(fb0, fb1, t)
+    TILE_BODY(fb1, fb0, t + 1)
+  }
+  if (t < nt) TILE_BODY(fb0, fb1, t)
+#undef TILE_BODY
   if (wr == 0) __builtin_amdgcn_s_barrier();          // re-balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the dummy tail loads before the wave retires
 
@@ -307,11 +325,12 @@ int launch256(const GemmArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-// called by mla_gemm_bf16 (gemm.hip) when M, N >= 256 and K % 64 == 0
+// called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>
+// instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, hipStream_t stream) {
-  const GemmArgs& p = *(const GemmArgs*)args;
-  if (a_mode == 0 && b_mode == 0) return launch256<0, 0>(p, stream);
-  if (a_mode == 0 && b_mode == 1) return launch256<0, 1>(p, stream);
-  if (a_mode == 1 && b_mode == 0) return launch256<1, 0>(p, stream);
-  return launch256<1, 1>(p, stream);
+  if (a_mode != 0 || b_mode != 0) {
+    mla_set_error("gemm256: k-contiguous operands only");
+    return -1;
+  }
+  return launch256<0, 0>(*(const GemmArgs*)args, stream);
 }
