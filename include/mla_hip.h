@@ -139,6 +139,47 @@ int mla_avgpool_tokens(const void* x, void* y, int B, int gh, int gw, int C, int
 int mla_local_attn(const void* q, const void* kv, void* out, int B, int gh, int gw, int C, int cs, int heads, float scale,
                    mla_stream_t stream);
 
+/* ---- batched GEMM (two-level batch: outer = sample, inner = head) for the generation heads' nn.MultiheadAttention products
+ * (models/mla/generation/models.py:44,103-122: QK^T, PV and their gradients). Same operand modes as mla_gemm_bf16; batch
+ * (o, i) adds o*s?o + i*s?i ELEMENTS to each base pointer; n_inner >= 1. No bias / residual. */
+int mla_gemm_batched_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_mode, int b_mode,
+                          int out_fp32, float alpha, int n_outer, int n_inner, long long sAo, long long sAi, long long sBo,
+                          long long sBi, long long sCo, long long sCi, mla_stream_t stream);
+
+/* ---- post-training generation heads (BASELINE config[3]): models/mla/generation/models.py
+ * nn.TransformerDecoderLayer :103-122 / TransformerBlock :39-65 pieces: softmax(+attention dropout) over the first nvalid of
+ * ncols key columns, Dropout (+ residual add), DropPath (per-sample scale), LayerNorm with backward; PointCloudGenerationModule
+ * :351-386: sequence mean :359, BatchNorm1d(train) backward :335; chamfer_distance_l2 gen_loss.py:12-18; image loss
+ * models/vlm/prismatic.py:780-816 with ImageGenerationModule._generate_generated_patches models.py:226-286 evaluated for the
+ * all-true ROI mask (use_roi = False, scripts/post_rlbench.sh:26) and images_to_patches utils.py:7-18 addressing.
+ * Dropout decisions are a counter-based hash of (seed, element index): backward regenerates the forward mask. */
+int mla_softmax_rows_fwd(const float* scores, void* P, void* Pd, long long rows, int ncols, int nvalid, float p,
+                         unsigned long long seed, mla_stream_t stream);
+int mla_softmax_rows_bwd(const void* dPd, const void* P, void* dS, long long rows, int ncols, int nvalid, float p,
+                         unsigned long long seed, mla_stream_t stream);
+int mla_dropout_fwd(const void* x, const void* residual, void* y, long long n, float p, unsigned long long seed, mla_stream_t stream);
+int mla_dropout_bwd(const void* dy, void* dx, long long n, float p, unsigned long long seed, mla_stream_t stream);
+int mla_scale_batch(const void* x, const float* scale, void* y, long long batch, long long per, mla_stream_t stream);
+int mla_layernorm_stats_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, long long rows, int H,
+                            float eps, mla_stream_t stream);
+int mla_layernorm_bwd_blocks(long long rows);
+int mla_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx, float* dw,
+                      float* db, int accumulate, long long rows, int H, float* workspace, size_t workspace_bytes,
+                      mla_stream_t stream);
+int mla_seqmean_fwd(const void* x, void* y, int B, int S, int C, mla_stream_t stream);
+int mla_seqmean_bwd(const void* dy, void* dx, int B, int S, int C, mla_stream_t stream);
+int mla_bn_bwd_blocks(long long rows);
+int mla_bn_bwd(const void* dy, const void* x, const float* mean, const float* var, const void* w, void* dx, float* dw, float* db,
+               int accumulate, long long rows, int C, float eps, float* workspace, size_t workspace_bytes, mla_stream_t stream);
+int mla_chamfer_fwd(const float* pred, const float* gt, float* d1, int* i1, float* d2, int* i2, float* loss, int B, int N, int M,
+                    float* workspace, size_t workspace_bytes, mla_stream_t stream);
+int mla_chamfer_bwd(const float* pred, const float* gt, const float* d1, const int* i1, const float* d2, const int* i2,
+                    const float* gscale, float* dpred, int B, int N, int M, mla_stream_t stream);
+int mla_imgloss_fwd(const void* delta_raw, const void* curr, const void* next, int img_fp32, float* sums, int B, int CT_curr,
+                    int CT_next, int HW, int ps, float clip, float* workspace, size_t workspace_bytes, mla_stream_t stream);
+int mla_imgloss_bwd(const void* delta_raw, const void* curr, const void* next, int img_fp32, const float* gscale, void* ddelta_raw,
+                    int B, int CT_curr, int CT_next, int HW, int ps, float clip, mla_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

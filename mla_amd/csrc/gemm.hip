@@ -28,7 +28,10 @@ struct GemmArgs {
   int out_fp32;    // 0: C is bf16, 1: C is fp32
   int accumulate;  // fp32 output only: C += result
   float alpha;
-  int debug;  // experiments only (tools/): bit0 = read tr tiles with b128, bit1 = stage mode-1 tiles with mode-0 addresses
+  int debug;  // experiments only (tools/)
+  // batched launches (gemm128 / generic only): z = blockIdx.y = outer * n_inner + inner, element strides per operand
+  int n_inner;
+  long long sAo, sAi, sBo, sBi, sCo, sCi;
 };
 
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, hipStream_t stream);  // gemm256.hip
@@ -107,6 +110,13 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  if (p.n_inner > 0) {   // batched launch: shift the operand base pointers of this z-slice
+    const int zo = blockIdx.y / p.n_inner, zi = blockIdx.y % p.n_inner;
+    p.A += zo * p.sAo + zi * p.sAi;
+    p.B += zo * p.sBo + zi * p.sBi;
+    const long long co = zo * p.sCo + zi * p.sCi;
+    p.C = p.out_fp32 ? (void*)((float*)p.C + co) : (void*)((bf16_t*)p.C + co);
+  }
 
   const int num_m = (p.M + BM - 1) / BM, num_n = (p.N + BN - 1) / BN;
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
@@ -213,6 +223,13 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p, int amode
   __shared__ float As[16][65];
   __shared__ float Bs[16][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  if (p.n_inner > 0) {
+    const int zo = blockIdx.z / p.n_inner, zi = blockIdx.z % p.n_inner;
+    p.A += zo * p.sAo + zi * p.sAi;
+    p.B += zo * p.sBo + zi * p.sBi;
+    const long long co = zo * p.sCo + zi * p.sCi;
+    p.C = p.out_fp32 ? (void*)((float*)p.C + co) : (void*)((bf16_t*)p.C + co);
+  }
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   float acc[4][4] = {};
   for (int k0 = 0; k0 < p.K; k0 += 16) {
@@ -263,14 +280,14 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p, int amode
 }
 
 template <int AM, int BM_>
-int launch128(const GemmArgs& p, hipStream_t stream) {
+int launch128(const GemmArgs& p, hipStream_t stream, int nbatch = 1) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm128_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     attr_set = true;
   }
   const int num_m = (p.M + BM - 1) / BM, num_n = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm128_kernel<AM, BM_>), dim3(num_m * num_n), dim3(256), 4 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm128_kernel<AM, BM_>), dim3(num_m * num_n, nbatch), dim3(256), 4 * TILE_BYTES, stream, p);
   MLA_LAUNCH_CHECK();
 }
 
@@ -286,7 +303,7 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
   MLA_CHECK_ARG(!accumulate || out_fp32, "mla_gemm_bf16: accumulate needs fp32 output");
   MLA_CHECK_ARG(R == nullptr || ldr >= N, "mla_gemm_bf16: bad ldr");
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)R, (const bf16_t*)bias, M, N, K,
-             lda, ldb, ldc, ldr, out_fp32, accumulate, alpha, force_generic >> 4};
+             lda, ldb, ldc, ldr, out_fp32, accumulate, alpha, force_generic >> 4, 0, 0, 0, 0, 0, 0, 0};
   force_generic &= 15;
   bool mfma_ok = (force_generic != 1) && (K % 32 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                  (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
@@ -308,6 +325,34 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
     return launch128<1, 1>(p, stream);
   }
   dim3 grid((N + 63) / 64, (M + 63) / 64);
+  hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, stream, p, a_mode, b_mode);
+  MLA_LAUNCH_CHECK();
+}
+
+// Batched form (no bias / residual): for z = (outer, inner) in [0, n_outer) x [0, n_inner):
+//   C + o*sCo + i*sCi = alpha * Aop(A + o*sAo + i*sAi) * Bop(B + o*sBo + i*sBi)^T      (strides in elements)
+// Used for multi-head attention with arbitrary head_dim in the post-training generation heads
+// (models/mla/generation/models.py:68-286: nn.TransformerDecoder with 8 heads of 512).
+extern "C" int mla_gemm_batched_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_mode,
+                                     int b_mode, int out_fp32, float alpha, int n_outer, int n_inner, long long sAo, long long sAi,
+                                     long long sBo, long long sBi, long long sCo, long long sCi, hipStream_t stream) {
+  MLA_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && n_outer > 0 && n_inner > 0, "mla_gemm_batched_bf16: bad args");
+  MLA_CHECK_ARG((long long)n_outer * n_inner <= 65535, "mla_gemm_batched_bf16: too many batches");
+  GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, out_fp32, 0, alpha, 0,
+             n_inner, sAo, sAi, sBo, sBi, sCo, sCi};
+  const int nb = n_outer * n_inner;
+  const bool al = ((sAo | sAi | sBo | sBi) % 8 == 0) && ((sCo | sCi) % 4 == 0);
+  bool mfma_ok = al && (K % 32 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
+                 (((uintptr_t)C & 15) == 0);
+  if (a_mode == 1 && (M % 8 != 0)) mfma_ok = false;
+  if (b_mode == 1 && (N % 8 != 0)) mfma_ok = false;
+  if (mfma_ok) {
+    if (a_mode == 0 && b_mode == 0) return launch128<0, 0>(p, stream, nb);
+    if (a_mode == 0 && b_mode == 1) return launch128<0, 1>(p, stream, nb);
+    if (a_mode == 1 && b_mode == 0) return launch128<1, 0>(p, stream, nb);
+    return launch128<1, 1>(p, stream, nb);
+  }
+  dim3 grid((N + 63) / 64, (M + 63) / 64, nb);
   hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, stream, p, a_mode, b_mode);
   MLA_LAUNCH_CHECK();
 }

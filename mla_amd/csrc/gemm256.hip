@@ -29,7 +29,10 @@ struct GemmArgs {
   int out_fp32;
   int accumulate;
   float alpha;
-  int debug;  // experiments only (tools/): bit0 = read tr tiles with b128, bit1 = stage mode-1 tiles with mode-0 addresses
+  int debug;  // experiments only (tools/)
+  // batched launches (gemm128 / generic only): z = blockIdx.y = outer * n_inner + inner, element strides per operand
+  int n_inner;
+  long long sAo, sAi, sBo, sBi, sCo, sCi;
 };
 
 namespace {

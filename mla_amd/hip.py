@@ -517,3 +517,162 @@ def local_attn(q, kv, B, gh, gw, cs, heads, scale):
     out = torch.empty_like(q)
     call("mla_local_attn", _p(q), _p(kv), _p(out), B, gh, gw, C, cs, heads, float(scale))
     return out
+
+
+# --------------------------------------------------------------------------------------------- generation heads
+from ctypes import c_ulonglong  # noqa: E402
+
+register_signatures({
+    "mla_gemm_batched_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                              c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong, c_longlong, c_longlong, c_void_p],
+    "mla_softmax_rows_fwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_ulonglong, c_void_p],
+    "mla_softmax_rows_bwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_ulonglong, c_void_p],
+    "mla_dropout_fwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_ulonglong, c_void_p],
+    "mla_dropout_bwd": [c_void_p, c_void_p, c_longlong, c_float, c_ulonglong, c_void_p],
+    "mla_scale_batch": [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p],
+    "mla_layernorm_stats_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_float, c_void_p],
+    "mla_layernorm_bwd_blocks": [c_longlong],
+    "mla_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int,
+                          c_void_p, c_size_t, c_void_p],
+    "mla_seqmean_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mla_seqmean_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mla_bn_bwd_blocks": [c_longlong],
+    "mla_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_float,
+                   c_void_p, c_size_t, c_void_p],
+    "mla_chamfer_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
+                        c_void_p],
+    "mla_chamfer_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mla_imgloss_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t,
+                        c_void_p],
+    "mla_imgloss_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+})
+
+
+def gemm_batched(a, b, out, *, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, alpha=1.0, n_outer, n_inner, sA, sB, sC):
+    """out[o,i] = alpha * Aop[o,i] . Bop[o,i]^T over a two-level batch; a/b/out are base tensors (offset = data_ptr), strides in
+    elements as (outer, inner) pairs. out may be bf16 or fp32."""
+    _req(a, torch.bfloat16, "gemm_batched A")
+    _req(b, torch.bfloat16, "gemm_batched B")
+    out_fp32 = 1 if out.dtype == torch.float32 else 0
+    if not out_fp32:
+        _req(out, torch.bfloat16, "gemm_batched C")
+    call("mla_gemm_batched_bf16", _p(a), _p(b), _p(out), M, N, K, lda, ldb, ldc, a_mode, b_mode, out_fp32, float(alpha), n_outer,
+         n_inner, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1])
+    return out
+
+
+def softmax_rows_fwd(scores, nvalid, p, seed):
+    ncols = scores.shape[-1]
+    rows = scores.numel() // ncols
+    P = torch.empty(scores.shape, dtype=torch.bfloat16, device=scores.device)
+    Pd = torch.empty_like(P) if p > 0 else P
+    call("mla_softmax_rows_fwd", _p(scores), _p(P), _p(Pd), rows, ncols, nvalid, float(p), seed)
+    return P, Pd
+
+
+def softmax_rows_bwd(dPd, P, nvalid, p, seed):
+    ncols = P.shape[-1]
+    dS = torch.empty_like(P)
+    call("mla_softmax_rows_bwd", _p(dPd), _p(P), _p(dS), P.numel() // ncols, ncols, nvalid, float(p), seed)
+    return dS
+
+
+def dropout_fwd(x, residual, p, seed):
+    y = torch.empty_like(x)
+    call("mla_dropout_fwd", _p(x), _p(residual), _p(y), x.numel(), float(p), seed)
+    return y
+
+
+def dropout_bwd(dy, p, seed):
+    dx = torch.empty_like(dy)
+    call("mla_dropout_bwd", _p(dy), _p(dx), dy.numel(), float(p), seed)
+    return dx
+
+
+def scale_batch(x, scale):
+    y = torch.empty_like(x)
+    call("mla_scale_batch", _p(x), _p(scale), _p(y), x.shape[0], x.numel() // x.shape[0])
+    return y
+
+
+def layernorm_stats_fwd(x2d, w, b, eps):
+    rows, H = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty_like(mean)
+    call("mla_layernorm_stats_fwd", _p(x2d), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, H, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, w, mean, rstd, dw=None, db=None, accumulate=False):
+    rows, H = x2d.shape
+    dx = torch.empty_like(x2d)
+    nb = lib().mla_layernorm_bwd_blocks(rows)
+    ws = workspace(nb * 2 * H * 4, x2d.device)
+    call("mla_layernorm_bwd", _p(dy2d), _p(x2d), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw), _p(db), 1 if accumulate else 0, rows, H,
+         _p(ws), ws.numel())
+    return dx
+
+
+def seqmean_fwd(x3d):
+    B, S, C = x3d.shape
+    y = torch.empty((B, C), dtype=torch.bfloat16, device=x3d.device)
+    call("mla_seqmean_fwd", _p(x3d), _p(y), B, S, C)
+    return y
+
+
+def seqmean_bwd(dy2d, S):
+    B, C = dy2d.shape
+    dx = torch.empty((B, S, C), dtype=torch.bfloat16, device=dy2d.device)
+    call("mla_seqmean_bwd", _p(dy2d), _p(dx), B, S, C)
+    return dx
+
+
+def bn_bwd(dy2d, x2d, mean, var, w, eps, dw=None, db=None, accumulate=False):
+    rows, C = x2d.shape
+    dx = torch.empty_like(x2d)
+    nb = lib().mla_bn_bwd_blocks(rows)
+    ws = workspace((nb * 2 * C + 2 * C) * 4, x2d.device)
+    call("mla_bn_bwd", _p(dy2d), _p(x2d), _p(mean), _p(var), _p(w), _p(dx), _p(dw), _p(db), 1 if accumulate else 0, rows, C, float(eps),
+         _p(ws), ws.numel())
+    return dx
+
+
+def chamfer_fwd(pred, gt):
+    B, N, _ = pred.shape
+    M = gt.shape[1]
+    dev = pred.device
+    d1 = torch.empty((B, N), dtype=torch.float32, device=dev)
+    i1 = torch.empty((B, N), dtype=torch.int32, device=dev)
+    d2 = torch.empty((B, M), dtype=torch.float32, device=dev)
+    i2 = torch.empty((B, M), dtype=torch.int32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    ws = workspace(64, dev)
+    call("mla_chamfer_fwd", _p(pred), _p(gt), _p(d1), _p(i1), _p(d2), _p(i2), _p(loss), B, N, M, _p(ws), ws.numel())
+    return loss, d1, i1, d2, i2
+
+
+def chamfer_bwd(pred, gt, d1, i1, d2, i2, gscale):
+    B, N, _ = pred.shape
+    dpred = torch.empty_like(pred)
+    call("mla_chamfer_bwd", _p(pred), _p(gt), _p(d1), _p(i1), _p(d2), _p(i2), _p(gscale), _p(dpred), B, N, gt.shape[1])
+    return dpred
+
+
+def imgloss_fwd(delta_raw, curr, nxt, ps, clip):
+    B = delta_raw.shape[0]
+    fp32 = curr.dtype == torch.float32
+    if curr.dtype != nxt.dtype or curr.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("imgloss: curr/next images must both be fp32 or both bf16")
+    sums = torch.empty(3, dtype=torch.float32, device=delta_raw.device)
+    ws = workspace(2048 * 3 * 4, delta_raw.device)
+    call("mla_imgloss_fwd", _p(delta_raw), _p(curr), _p(nxt), 1 if fp32 else 0, _p(sums), B, curr.shape[1], nxt.shape[1], curr.shape[2], ps,
+         float(clip), _p(ws), ws.numel())
+    return sums
+
+
+def imgloss_bwd(delta_raw, curr, nxt, ps, clip, gscale):
+    out = torch.empty_like(delta_raw)
+    call("mla_imgloss_bwd", _p(delta_raw), _p(curr), _p(nxt), 1 if curr.dtype == torch.float32 else 0, _p(gscale), _p(out),
+         delta_raw.shape[0], curr.shape[1], nxt.shape[1], curr.shape[2], ps, float(clip))
+    return out
