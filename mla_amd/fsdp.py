@@ -133,6 +133,14 @@ class FlatUnit:
         (torch FSDP with use_orig_params presents zero gradients for them, and AdamW still applies to them)."""
         for _, p, _ in self.params:
             if p.requires_grad:
+                if p.grad is not None:
+                    # gradient delivered by autograd (small broadcast parameters: queries, mask token, position tables)
+                    if p._mg_touched:
+                        p.main_grad.add_(p.grad.to(torch.float32))
+                    else:
+                        p.main_grad.copy_(p.grad)
+                    p._mg_touched = True
+                    p.grad = None
                 if not p._mg_touched and p._mg_dirty:
                     p.main_grad.zero_()
                     p._mg_dirty = False

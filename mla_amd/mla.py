@@ -77,8 +77,12 @@ class MLA(nn.Module):
         if action_masks is not None:
             action_masks = rep(action_masks)
         images = {k_: rep(v) for k_, v in images.items()} if isinstance(images, dict) else rep(images)
+        if self.use_generation and self.gen_image:
+            next_images = rep(next_images)
         if self.use_pointcloud:
             point_cloud = rep(point_cloud)
+        if self.use_pointcloud and self.use_generation and self.gen_pointcloud:
+            next_point_cloud = rep(next_point_cloud)
         if noise is None:
             noise = torch.randn_like(actions_future)
         if timestep is None:
@@ -102,6 +106,12 @@ class MLA(nn.Module):
         diff_loss = ((noise_pred.float() - noise.float()) ** 2).mean()
         self.last_diff_mse = diff_loss.detach().clone()
         total = diff_loss
+        if self.use_generation and self.gen_image:                       # model_mla.py:218-223 (generation terms come first)
+            loss_dict["image_gen_loss"] = generation_losses["image_gen_loss"]
+            total = total + generation_losses["image_gen_loss"].float()
+        if self.use_generation and self.gen_pointcloud:
+            loss_dict["point_cloud_gen_loss"] = generation_losses["point_cloud_gen_loss"]
+            total = total + generation_losses["point_cloud_gen_loss"].float()
         if self.use_contrastive:
             loss_dict["img_pc_contrastive_loss"] = output.img_pc_contrastive_loss
             total = total + output.img_pc_contrastive_loss.float()

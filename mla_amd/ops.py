@@ -159,6 +159,22 @@ class LinearFn(torch.autograd.Function):
         dy2 = _as2d(dy)
         ni = ctx.needs_input_grad
         dx = None
+        T, N = dy2.shape
+        K = x2.shape[1]
+        # large aligned shapes: transpose the operands once and stay on the k-contiguous (NT) MFMA kernel, which is ~2x faster
+        # than the reduction-major variants (DESIGN.md "all-NT backward")
+        big = T >= 256 and N >= 256 and K >= 256 and T % 64 == 0 and N % 8 == 0 and K % 64 == 0 and N % 64 == 0
+        wcat = cat_view(weights) if big else None
+        if wcat is not None and dy2.stride(0) == N and x2.stride(0) == K:
+            if ni[0]:
+                dx = hip.gemm(dy2, hip.transpose(wcat)).view(ctx.in_shape)
+            wg = [None] * len(weights)
+            if any(ni[3:]):
+                wg = deliver_wgrad_nt(weights, hip.transpose(dy2), hip.transpose(x2), ni[3:])
+            db = None
+            if ctx.bias is not None and ni[2]:
+                db = deliver_vec_grad(ctx.bias, lambda out, acc: hip.colsum(dy2, out, acc))
+            return (dx, dy if (ctx.has_res and ni[1]) else None, db, *wg)
         if ni[0]:
             wcat = cat_view(weights)
             if wcat is not None:
@@ -237,18 +253,42 @@ def act(x, kind):
     return ActFn.apply(x, kind)
 
 
+def _deliver_small(param, g32):
+    """Route a small fp32 gradient (already reduced) to main_grad or hand it back to autograd."""
+    mg = getattr(param, "main_grad", None)
+    if mg is None:
+        return g32.to(param.dtype).view(param.shape)
+    if _touch(param):
+        mg.add_(g32.view(mg.shape))
+    else:
+        mg.copy_(g32.view(mg.shape))
+    return None
+
+
 class LayerNormFn(torch.autograd.Function):
-    """Forward-only LayerNorm (the vision tokenizer is frozen in every shipped stage but 'pretrain')."""
+    """nn.LayerNorm (fp32 statistics). Backward: models/mla/generation/models.py:43-46,126 (trainable heads)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
         _check_bf16_cuda(x, weight, bias)
-        return hip.layernorm_fwd(_as2d(x), weight, bias, eps).view(x.shape)
+        x2 = _as2d(x)
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            return hip.layernorm_fwd(x2, weight, bias, eps).view(x.shape)
+        y, mean, rstd = hip.layernorm_stats_fwd(x2, weight, bias, eps)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.weight, ctx.bias = weight, bias
+        return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        raise NotImplementedError("LayerNorm backward: the vision tokenizer is frozen on the SFT/post-training path "
-                                  "(models/vlm/prismatic.py:463-467); stage 'pretrain' is not built yet")
+        x2, mean, rstd = ctx.saved_tensors
+        H = x2.shape[1]
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dwb = torch.empty((2, H), dtype=torch.float32, device=x2.device) if need_w else None
+        dx = hip.layernorm_bwd(_as2d(dy), x2, ctx.weight, mean, rstd, dw=dwb[0] if need_w else None, db=dwb[1] if need_w else None)
+        dw = _deliver_small(ctx.weight, dwb[0]) if ctx.needs_input_grad[1] else None
+        db = _deliver_small(ctx.bias, dwb[1]) if ctx.needs_input_grad[2] else None
+        return dx.view(dy.shape), dw, db, None
 
 
 def layernorm(x, weight, bias, eps=1e-5):
@@ -546,3 +586,249 @@ class UnitBoundaryFn(torch.autograd.Function):
 
 def unit_boundary(x, hook):
     return UnitBoundaryFn.apply(x, hook) if hook is not None else x
+
+
+# ------------------------------------------------------------------------------------------------- generation heads
+_seed_counter = [0]
+
+
+def next_seed() -> int:
+    """Host-side counter-based seed for the dropout kernels (no device sync). Derived from torch's seed so that
+    torch.manual_seed() makes a run reproducible; the kernels hash (seed, element index)."""
+    _seed_counter[0] += 1
+    x = (torch.initial_seed() + 0x9E3779B97F4A7C15 * _seed_counter[0]) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 27
+    return x
+
+
+def param_view(param: torch.Tensor, lo: Optional[int] = None, hi: Optional[int] = None, shape=None) -> torch.Tensor:
+    """A row-slice / reshape of a parameter that still delivers its weight gradient into the matching region of
+    ``param.main_grad`` (nn.MultiheadAttention's packed in_proj_weight, Conv1d(k=1) weights used as matrices)."""
+    v = param if lo is None else param[lo:hi]
+    if shape is not None:
+        v = v.view(shape)
+    mg = getattr(param, "main_grad", None)
+    if mg is not None:
+        g = mg if lo is None else mg[lo:hi]
+        v.main_grad = g.view(shape) if shape is not None else g
+        v._mg_touched = False
+        param._mg_touched = True      # every region of the parameter is written each step by its views
+    return v
+
+
+class DropoutAddFn(torch.autograd.Function):
+    """y = residual + dropout(x, p) (residual optional); the mask is regenerated from (seed, index) in backward."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p, seed):
+        _check_bf16_cuda(x, residual)
+        ctx.p, ctx.seed, ctx.has_res = p, seed, residual is not None
+        return hip.dropout_fwd(x.contiguous(), residual.contiguous() if residual is not None else None, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dyc = dy.contiguous()
+        dx = hip.dropout_bwd(dyc, ctx.p, ctx.seed) if ctx.p > 0 else dyc
+        return dx, (dyc if ctx.has_res else None), None, None
+
+
+def dropout_add(x, residual, p, training):
+    p = p if training else 0.0
+    if p == 0.0 and residual is None:
+        return x
+    return DropoutAddFn.apply(x, residual, p, next_seed() if p > 0 else 0)
+
+
+class ScaleBatchFn(torch.autograd.Function):
+    """timm DropPath: x[b] * scale[b] with scale = bernoulli(keep) / keep (models/mla/generation/models.py:45,63-64)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
+        return hip.scale_batch(x.contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        return hip.scale_batch(dy.contiguous(), scale), None
+
+
+def drop_path(x, p, training):
+    if p == 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    scale = torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+    return ScaleBatchFn.apply(x, scale)
+
+
+class MHACoreFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(hd)) V for every (sample, head) of nn.MultiheadAttention (batch_first), attention dropout
+    included -- torch/nn/functional.py multi_head_attention_forward as called by nn.TransformerDecoderLayer
+    (models/mla/generation/models.py:103-122) and TransformerBlock (:44,62).
+
+    qsrc: [B, Sq, 3E] packed q|k|v (self-attention, kvsrc None) or [B, Sq, E] (cross-attention, kvsrc [B, Skp, 2E] packed
+    k|v). Only the first ``nvalid`` key rows take part (the rest is alignment padding). The QK^T / PV products and their four
+    gradients are batched MFMA GEMMs over (B, heads); scores are fp32."""
+
+    @staticmethod
+    def forward(ctx, qsrc, kvsrc, nheads, nvalid, p, seed):
+        _check_bf16_cuda(qsrc, kvsrc)
+        qsrc = qsrc.contiguous()
+        B, Sq = qsrc.shape[0], qsrc.shape[1]
+        if kvsrc is None:
+            E = qsrc.shape[2] // 3
+            q, k, v = qsrc[..., :E], qsrc[..., E:2 * E], qsrc[..., 2 * E:]
+            Sk = Sq
+        else:
+            kvsrc = kvsrc.contiguous()
+            E = qsrc.shape[2]
+            q, k, v = qsrc, kvsrc[..., :E], kvsrc[..., E:]
+            Sk = kvsrc.shape[1]
+        hd = E // nheads
+        scale = 1.0 / math.sqrt(hd)
+        dev = qsrc.device
+        scores = torch.empty((B, nheads, Sq, Sk), dtype=torch.float32, device=dev)
+        sS = (nheads * Sq * Sk, Sq * Sk)
+        hip.gemm_batched(q, k, scores, M=Sq, N=Sk, K=hd, lda=q.stride(1), ldb=k.stride(1), ldc=Sk, alpha=scale, n_outer=B,
+                         n_inner=nheads, sA=(q.stride(0), hd), sB=(k.stride(0), hd), sC=sS)
+        P, Pd = hip.softmax_rows_fwd(scores, nvalid, p, seed)
+        del scores
+        o = torch.empty((B, Sq, E), dtype=BF16, device=dev)
+        hip.gemm_batched(Pd, v, o, M=Sq, N=hd, K=Sk, lda=Sk, ldb=v.stride(1), ldc=E, b_mode=1, n_outer=B, n_inner=nheads, sA=sS,
+                         sB=(v.stride(0), hd), sC=(Sq * E, hd))
+        ctx.save_for_backward(qsrc, kvsrc, P)
+        ctx.meta = (nheads, nvalid, p, seed, E, Sk)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qsrc, kvsrc, P = ctx.saved_tensors
+        nheads, nvalid, p, seed, E, Sk = ctx.meta
+        do = do.contiguous()
+        B, Sq = qsrc.shape[0], qsrc.shape[1]
+        hd = E // nheads
+        scale = 1.0 / math.sqrt(hd)
+        dqsrc = torch.empty_like(qsrc)
+        if kvsrc is None:
+            q, k, v = qsrc[..., :E], qsrc[..., E:2 * E], qsrc[..., 2 * E:]
+            dq, dk, dv = dqsrc[..., :E], dqsrc[..., E:2 * E], dqsrc[..., 2 * E:]
+            dkvsrc = None
+        else:
+            dkvsrc = torch.empty_like(kvsrc)
+            q, k, v = qsrc, kvsrc[..., :E], kvsrc[..., E:]
+            dq, dk, dv = dqsrc, dkvsrc[..., :E], dkvsrc[..., E:]
+        sS = (nheads * Sq * Sk, Sq * Sk)
+        # dPd = dO V^T
+        dPd = torch.empty_like(P)
+        hip.gemm_batched(do, v, dPd, M=Sq, N=Sk, K=hd, lda=E, ldb=v.stride(1), ldc=Sk, n_outer=B, n_inner=nheads, sA=(Sq * E, hd),
+                         sB=(v.stride(0), hd), sC=sS)
+        # dV = Pd^T dO  (Pd regenerated from P and the dropout hash: Pd = P * mask / (1 - p))
+        if p > 0:
+            Pd = hip.dropout_fwd(P, None, p, seed)
+        else:
+            Pd = P
+        hip.gemm_batched(Pd, do, dv, M=Sk, N=hd, K=Sq, lda=Sk, ldb=E, ldc=dv.stride(1), a_mode=1, b_mode=1, n_outer=B, n_inner=nheads,
+                         sA=sS, sB=(Sq * E, hd), sC=(dv.stride(0), hd))
+        del Pd
+        dS = hip.softmax_rows_bwd(dPd, P, nvalid, p, seed)
+        del dPd
+        # dQ = scale * dS K ; dK = scale * dS^T Q
+        hip.gemm_batched(dS, k, dq, M=Sq, N=hd, K=Sk, lda=Sk, ldb=k.stride(1), ldc=dq.stride(1), b_mode=1, alpha=scale, n_outer=B,
+                         n_inner=nheads, sA=sS, sB=(k.stride(0), hd), sC=(dq.stride(0), hd))
+        hip.gemm_batched(dS, q, dk, M=Sk, N=hd, K=Sq, lda=Sk, ldb=q.stride(1), ldc=dk.stride(1), a_mode=1, b_mode=1, alpha=scale,
+                         n_outer=B, n_inner=nheads, sA=sS, sB=(q.stride(0), hd), sC=(dk.stride(0), hd))
+        return dqsrc, dkvsrc, None, None, None, None
+
+
+def mha_core(qsrc, kvsrc, nheads, nvalid, p, training):
+    p = p if training else 0.0
+    return MHACoreFn.apply(qsrc, kvsrc, nheads, nvalid, p, next_seed() if p > 0 else 0)
+
+
+class SeqMeanFn(torch.autograd.Function):
+    """x.mean(dim=1) over [B, S, C] (PointCloudGenerationModule.forward models/mla/generation/models.py:359)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _check_bf16_cuda(x)
+        ctx.S = x.shape[1]
+        return hip.seqmean_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.seqmean_bwd(dy.contiguous(), ctx.S)
+
+
+class BatchNormTrainFn(torch.autograd.Function):
+    """nn.BatchNorm1d in training mode over rows [rows, C] (+ ReLU): batch statistics forward and the full backward
+    (future_predictor, models/mla/generation/models.py:333-338). Returns (y, mean, biased var) -- the module updates its
+    running statistics from them."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, eps, relu):
+        _check_bf16_cuda(x2, weight, bias)
+        mean, var = hip.colstats(x2)
+        y = hip.bn_apply(x2, mean, var, weight, bias, eps, relu=relu)
+        ctx.save_for_backward(x2, mean, var, y)
+        ctx.weight, ctx.bias, ctx.eps, ctx.relu = weight, bias, eps, relu
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x2, mean, var, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = hip.act_bwd(dy, y, hip.ACT_RELU)      # relu'(pre) == relu'(post) as a 0/1 gate
+        C = x2.shape[1]
+        dwb = torch.empty((2, C), dtype=torch.float32, device=x2.device)
+        dx = hip.bn_bwd(dy, x2, mean, var, ctx.weight, ctx.eps, dw=dwb[0], db=dwb[1])
+        dw = _deliver_small(ctx.weight, dwb[0]) if ctx.needs_input_grad[1] else None
+        db = _deliver_small(ctx.bias, dwb[1]) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+class ChamferFn(torch.autograd.Function):
+    """chamfer_distance_l2 (models/mla/generation/gen_loss.py:12-18): Euclidean nearest-neighbour distances both ways."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        pred32 = pred.to(torch.float32).contiguous()
+        gt32 = gt.to(torch.float32).contiguous()
+        loss, d1, i1, d2, i2 = hip.chamfer_fwd(pred32, gt32)
+        ctx.save_for_backward(pred32, gt32, d1, i1, d2, i2)
+        ctx.in_dtype = pred.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred32, gt32, d1, i1, d2, i2 = ctx.saved_tensors
+        d = hip.chamfer_bwd(pred32, gt32, d1, i1, d2, i2, g.to(torch.float32).contiguous())
+        return d.to(ctx.in_dtype), None
+
+
+class ImageGenLossFn(torch.autograd.Function):
+    """Image generation loss for the all-true ROI (use_roi False): generated = 0.05 * current + clip * tanh(delta_raw)
+    (ImageGenerationModule._generate_generated_patches models.py:264-283 with mask == 1), loss = MSE + 0.5 L1 vs the next
+    frame's patches - 0.1 mean|delta| (models/vlm/prismatic.py:780-816). Returns (loss, mse, l1, mean|delta|)."""
+
+    @staticmethod
+    def forward(ctx, delta_raw, curr_img, next_img, ps, clip):
+        _check_bf16_cuda(delta_raw)
+        delta_raw = delta_raw.contiguous()
+        sums = hip.imgloss_fwd(delta_raw, curr_img, next_img, ps, clip)
+        n = float(delta_raw.numel())
+        parts = sums / n
+        loss = parts[0] + 0.5 * parts[1] - 0.1 * parts[2]
+        ctx.save_for_backward(delta_raw, curr_img, next_img)
+        ctx.ps, ctx.clip = ps, clip
+        ctx.mark_non_differentiable(parts)
+        return loss, parts
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        delta_raw, curr_img, next_img = ctx.saved_tensors
+        d = hip.imgloss_bwd(delta_raw, curr_img, next_img, ctx.ps, ctx.clip, g.to(torch.float32).reshape(1).contiguous())
+        return d, None, None, None, None

@@ -7,7 +7,7 @@ Differences from the reference that do not change results:
 * FinalLayer runs on the T action rows only (the reference runs it on all S positions and then slices, :1115-1126;
   RmsNorm + Mlp are row-wise, so the selected rows are identical);
 * visualize_generation_simple / print side effects (:1129-1135) are not reproduced.
-Post-training generation heads (use_generation, BASELINE config[3]) are not built yet.
+Post-training generation heads (use_generation, BASELINE config[3]) live in mla_amd/generation.py (use_roi=False only).
 """
 from __future__ import annotations
 
@@ -20,6 +20,7 @@ from . import ops
 from .backbones import LLMBackbone
 from .diffusion import ActionEmbedder, FinalLayer, LabelEmbedder, TimestepEmbedder
 from .fuser import get_camera_params, get_projection_func
+from .generation import MultimodalGenerationManager, chamfer_distance_l2
 from .modeling_outputs import CausalLMOutputWithPast
 from .nn_utils import MLPProjector
 from .point_tokenizer import PointTokenizer
@@ -62,7 +63,11 @@ class PrismaticVLM(nn.Module):
                  token_size=4096, future_action_window_size=0, past_action_window_size=0, class_dropout_prob=0.0,
                  norm_stats=None, use_diff=False, use_pointcloud: bool = False, use_tactile: bool = False,
                  use_contrastive: bool = False, llm_vision_layers: int = 1, use_generation: bool = True, gen_image: bool = False,
-                 use_roi: bool = False, gen_pointcloud: bool = True, gen_tactile: bool = True, **kwargs) -> None:
+                 num_image_gen_queries: int = 128, image_decoder_layers: int = 3, image_decoder_heads: int = 8,
+                 image_patch_size: int = 42, use_roi: bool = False, roi_dilation_kernel_size: int = 3, gen_pointcloud: bool = True,
+                 gen_tactile: bool = True, pointcloud_trans_dim: int = 1024, pointcloud_decoder_layers: int = 4,
+                 pointcloud_decoder_heads: int = 8, pointcloud_group_size: int = 8, pointcloud_num_groups: int = 128,
+                 tactile_decoder_layers: int = 2, tactile_decoder_heads: int = 4, **kwargs) -> None:
         super().__init__()
         self.model_family, self.model_id = "prismatic", model_id
         self.llm_backbone = llm_backbone
@@ -75,9 +80,8 @@ class PrismaticVLM(nn.Module):
         self.use_roi = use_roi
         self.gen_pointcloud = gen_pointcloud and use_generation
         self.gen_tactile = gen_tactile and use_generation
-        if use_generation:
-            raise NotImplementedError("post-training generation heads (models/mla/generation, BASELINE config[3]) are not "
-                                      "built yet; construct with use_generation=False")
+        if self.gen_tactile:
+            raise NotImplementedError("tactile generation head: GEN_TAC=false in every BASELINE config (no tactile in the simulator)")
         if use_tactile:
             raise NotImplementedError("tactile inputs are outside BASELINE configs 0-4")
         self.string2idx = {}
@@ -102,11 +106,23 @@ class PrismaticVLM(nn.Module):
             self.z_embedder = LabelEmbedder(in_size=token_size, hidden_size=token_size, dropout_prob=self.class_dropout_prob)
             self.final_layer = FinalLayer(token_size, action_dim)
 
+        if self.use_generation:                                           # prismatic.py:246-270
+            self.generation_manager = MultimodalGenerationManager(
+                token_size=token_size, use_image_generation=self.gen_image, num_image_gen_queries=num_image_gen_queries,
+                image_decoder_layers=image_decoder_layers, image_decoder_heads=image_decoder_heads, image_patch_size=image_patch_size,
+                use_roi=use_roi, roi_dilation_kernel_size=roi_dilation_kernel_size, use_pointcloud_generation=self.gen_pointcloud,
+                pointcloud_trans_dim=pointcloud_trans_dim, pointcloud_decoder_layers=pointcloud_decoder_layers,
+                pointcloud_decoder_heads=pointcloud_decoder_heads, pointcloud_group_size=pointcloud_group_size,
+                pointcloud_num_groups=pointcloud_num_groups, use_tactile_generation=False, tactile_dim=self.tactile_dim,
+                tactile_decoder_layers=tactile_decoder_layers, tactile_decoder_heads=tactile_decoder_heads)
+
         self.all_module_keys = ["vision_tower_2d", "projector_2d", "llm_backbone", "proprio_embedder"]
         if self.use_diff:
             self.all_module_keys.extend(["x_embedder", "t_embedder", "final_layer"])
         if self.use_pointcloud:
             self.all_module_keys.extend(["vision_tower_3d", "projector_3d"])
+        if self.use_generation:
+            self.all_module_keys.append("generation_manager")
         self.trainable_module_keys: List[str] = []
         self.vision_backbone_requires_grad = False
         self.image_repeat_hint = 1   # set by MLA.forward: inputs are R tiled copies (model_mla.py:159-176)
@@ -159,6 +175,8 @@ class PrismaticVLM(nn.Module):
         elif stage in {"finetune", "post-training"}:
             if stage == "post-training" and not self.use_generation:
                 raise ValueError("post-training needs the generation manager")
+            if stage == "post-training":
+                self.generation_manager.requires_grad_(True)              # prismatic.py:501
             self.vision_tower_2d.requires_grad_(False)
             self.llm_backbone.requires_grad_(True)
             self.projector_2d.requires_grad_(True)
@@ -170,6 +188,14 @@ class PrismaticVLM(nn.Module):
                 self.trainable_module_keys.extend(["x_embedder", "t_embedder", "final_layer"])
             if self.use_pointcloud:
                 self.trainable_module_keys.extend(["projector_3d"])
+            if stage == "post-training":
+                # the reference lists the (frozen) towers as "trainable" keys here, i.e. they are saved in checkpoints (:504-512)
+                self.trainable_module_keys = ["vision_tower_2d", "projector_2d", "llm_backbone", "proprio_embedder"]
+                if self.use_diff:
+                    self.trainable_module_keys.extend(["x_embedder", "t_embedder", "final_layer"])
+                if self.use_pointcloud:
+                    self.trainable_module_keys.extend(["vision_tower_3d", "projector_3d"])
+                self.trainable_module_keys.append("generation_manager")
             self.vision_backbone_requires_grad = False
         else:
             raise ValueError(f"Stage `{stage}` is not supported! Try < pretrain | finetune | post-training >")
@@ -209,6 +235,34 @@ class PrismaticVLM(nn.Module):
                 parts.append(torch.stack(extra, dim=0))
         parts.append(torch.zeros((B, 1, self.token_size), dtype=front.dtype, device=front.device))  # zero tactile slot (:752-763)
         return parts, patch_indices, valid_mask, None, None, None
+
+    # ------------------------------------------------------------------------------------------ generation losses
+    def compute_generation_losses(self, generation_outputs, next_images=None, next_point_cloud=None, next_tactile=None):
+        """prismatic.py:771-838. Image branch: with the all-true ROI the background term (:798-806) is empty; MSE + 0.5 L1 on
+        the generated patches and the -0.1 mean|delta| reward come out of one fused kernel that reads the current / next frames in
+        place (images_to_patches addressing) -- ops.ImageGenLossFn."""
+        losses: Dict[str, torch.Tensor] = {}
+        total = 0.0
+        if self.gen_image and next_images is not None and "delta_raw" in generation_outputs:
+            mod = self.generation_manager.image_gen_module
+            cur = generation_outputs["current_front_image"]
+            nxt = next_images
+            assert cur.shape[-1] == cur.shape[-2] == 672 and nxt.shape[1] == 3, "Expected 672x672 RGB frames"   # utils.py:10-11
+            if cur.dtype != nxt.dtype:
+                nxt = nxt.to(cur.dtype)
+            loss, parts = ops.ImageGenLossFn.apply(generation_outputs["delta_raw"], cur.contiguous(), nxt.contiguous(),
+                                                   mod.image_patch_size, float(mod.gen_delta_clip))
+            losses["image_roi_generation_loss"] = (parts[0] + 0.5 * parts[1]).detach()
+            losses["delta_magnitude_reward"] = (-0.1 * parts[2]).detach()
+            losses["image_gen_loss"] = loss
+            total = total + loss
+        if self.gen_pointcloud and next_point_cloud is not None and "pointcloud_coord_generation" in generation_outputs:
+            assert next_point_cloud.shape[2] == 3, "Point cloud must have 3 dimensions (XYZ)"
+            pc_loss = chamfer_distance_l2(generation_outputs["pointcloud_coord_generation"], next_point_cloud)
+            losses["point_cloud_gen_loss"] = pc_loss
+            total = total + pc_loss
+        losses["total_generation_loss"] = total
+        return losses
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x=None, t=None, z=None, proprio=None, gripper_xyz=None, input_ids=None, attention_mask=None, images=None,
@@ -257,11 +311,28 @@ class PrismaticVLM(nn.Module):
             positive_pc_indices_for_tac=None, linear_positive_img_indices_for_tac=None,
             compute_token_contrastive_loss=self.use_contrastive, compute_tactile_contrastive_loss=False)
 
-        # ---- action read-out (:1115-1126): rows k+2 .. k+2+T of the last hidden state -> FinalLayer
         last_hidden = output.hidden_states[-1]
+        # ---- generation heads (:1071-1113). current_point_cloud=None is what the reference passes (:1098), so the FPS prior of
+        # the point head never runs; the per-step visualisation (:1129-1135, hard-coded path) is deliberately not reproduced.
+        generation_outputs: Dict[str, torch.Tensor] = {}
+        generation_losses: Dict[str, torch.Tensor] = {}
+        if self.use_generation and (self.gen_image or self.gen_pointcloud) and self.training:
+            front = (images["front_image"] if isinstance(images, dict) else images)
+            generation_outputs = self.generation_manager(
+                llm_hidden_states=last_hidden, current_image_features=parts[1], current_images_patches=None,
+                current_point_cloud=None, roi_mask_2d=None)
+            if self.gen_image:
+                assert next_images is not None
+                generation_outputs["current_front_image"] = front
+            if self.gen_pointcloud:
+                assert next_point_cloud is not None
+            generation_losses = self.compute_generation_losses(generation_outputs, next_images=next_images,
+                                                               next_point_cloud=next_point_cloud, next_tactile=next_tactile)
+
+        # ---- action read-out (:1115-1126): rows k+2 .. k+2+T of the last hidden state -> FinalLayer
         rows = (torch.arange(B, device=dev)[:, None] * S + k + 2 + torch.arange(T, device=dev)[None]).reshape(-1)
         picked = ops.gather_rows(last_hidden.reshape(B * S, H), rows)
         noise_pred = self.final_layer(picked).view(B, T, -1)
         if self.training:
-            return output, noise_pred, {}, {}
+            return output, noise_pred, generation_outputs, generation_losses
         return output, noise_pred

@@ -38,7 +38,7 @@ def point_weights(sd, pfx="vlm.vision_tower_3d."):
 
 
 def mla_forward(sd: dict, batch: dict, draws: dict, n_layers: int, n_heads: int, eps: float, R: int, use_pointcloud=True,
-                use_contrastive=True, tap: int = 8, zero_pad_rows: bool = True):
+                use_contrastive=True, tap: int = 8, zero_pad_rows: bool = True, gen_cfg: dict = None):
     """zero_pad_rows=True: flash/varlen semantics (pad query rows give zero attention output -- what the GPU reference
     path and the HIP kernels do); False: eager semantics (what the CPU-imported reference does, used to pin this oracle
     against tests/golden). Valid rows and all losses/gradients are identical either way.
@@ -112,5 +112,16 @@ def mla_forward(sd: dict, batch: dict, draws: dict, n_layers: int, n_heads: int,
     T = x_e.shape[1]
     noise_pred = torch.stack([fl[i, ks[i] + 2: ks[i] + 2 + T] for i in range(B)])
     diff = ((noise_pred - noise) ** 2).mean()
-    return dict(total_loss=diff + con, diff_mse=diff, contrastive=con, ce=ce, noise_pred=noise_pred, logits=logits,
-                hidden_states=hidden, patch_indices=patch_idx, valid=valid, mask=mask, labels=flabels, ks=ks)
+    total = diff
+    extra = {}
+    if gen_cfg is not None:
+        # post-training heads read the normed last hidden state of ALL positions, padding included (prismatic.py:1077, no
+        # memory_key_padding_mask); next frames / clouds are tiled R times (model_mla.py:165-170); losses join before the
+        # contrastive term (model_mla.py:218-229)
+        from oracle import gen_oracle as G
+        img_loss, pc_loss, gx = G.generation_losses(hn, images, rep(batch["next_images"]), rep(batch["next_point_cloud"]), sd, gen_cfg,
+                                                    pfx=P + "generation_manager.")
+        total = total + img_loss + pc_loss
+        extra = dict(image_gen_loss=img_loss, point_cloud_gen_loss=pc_loss, gen=gx)
+    return dict(total_loss=total + con, diff_mse=diff, contrastive=con, ce=ce, noise_pred=noise_pred, logits=logits,
+                hidden_states=hidden, patch_indices=patch_idx, valid=valid, mask=mask, labels=flabels, ks=ks, **extra)

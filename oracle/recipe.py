@@ -8,6 +8,9 @@ import torch
 TINY_LLAMA = dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=9, num_attention_heads=2,
                   rms_norm_eps=1e-5)
 TOKEN_SIZE = 256
+# post-training generation heads of the tiny model (BASELINE config[3] scaled down; S of the LLM memory is not a multiple of 32)
+GEN_TINY = dict(num_image_gen_queries=32, image_decoder_layers=2, image_decoder_heads=8, pointcloud_trans_dim=256,
+                pointcloud_decoder_layers=2, pointcloud_decoder_heads=8, pointcloud_group_size=8, pointcloud_num_groups=16)
 PAD_ID = 512  # tokenizer.pad_token_id == base vocab size (llama2.py:75-77); embedding table has vocab + 1 rows
 
 
@@ -31,8 +34,10 @@ def det_weight(name: str, shape, seed: int = 0) -> torch.Tensor:
         return torch.ones(shape)
     if len(shape) <= 1 and leaf == "weight":                      # norm / BatchNorm scales
         return 1.0 + det_randn(name, shape, 0.1, seed)
-    if leaf == "bias":
+    if leaf == "bias" or leaf.endswith("_bias"):                   # incl. nn.MultiheadAttention.in_proj_bias
         return det_randn(name, shape, 0.05, seed)
+    if leaf in ("image_gen_queries", "mae_mask_token", "mae_pos_embed"):
+        return det_randn(name, shape, 0.5, seed)
     if leaf in ("cls_token", "pos_embed", "class_embedding", "split_embedding"):
         return det_randn(name, shape, 0.02, seed)
     if "embed_tokens" in name:
@@ -48,7 +53,7 @@ def make_state_dict(shapes: dict, seed: int = 0) -> dict:
 
 
 def make_batch(B: int = 2, L: int = 16, R: int = 2, ragged: bool = True, seed: int = 0, vocab: int = 512, n_points: int = 1024,
-               img: int = 672):
+               img: int = 672, with_next: bool = False):
     """Synthetic batch with the collator's schema (util/data_utils.py:179-193) + the random draws of one step."""
     g = _gen("batch", seed)
     rgb = torch.randn(B, 3, img, img, generator=g)
@@ -76,4 +81,7 @@ def make_batch(B: int = 2, L: int = 16, R: int = 2, ragged: bool = True, seed: i
                  fps_start1=torch.randint(0, n_points // 2, (Bp,), generator=g))
     batch = dict(input_ids=ids, attention_mask=attention_mask, labels=labels, images={"front_image": images}, point_cloud=pc,
                  actions=actions, proprio=proprio, action_masks=torch.ones(B, 1, dtype=torch.bool), camera_name="rlbench_front")
+    if with_next:
+        batch["next_images"] = torch.randn(B, 3, img, img, generator=_gen("next_images", seed))
+        batch["next_point_cloud"] = lo + (hi - lo) * torch.rand(B, n_points, 3, generator=_gen("next_pc", seed))
     return batch, draws

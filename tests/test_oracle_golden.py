@@ -110,3 +110,82 @@ def test_reference_bf16_mode_spread_is_recorded(e2e):
     spread = np.abs(e2e["C_hidden8_slice"] - e2e["A_hidden8_slice"]).max() / np.abs(e2e["A_hidden8_slice"]).max()
     assert 1e-4 < spread < 0.5
     assert abs(float(e2e["C_total_loss"]) - float(e2e["A_total_loss"])) < 0.1
+
+
+# ----------------------------------------------------------------------------------------------- generation heads (a18)
+GEN_CFG = dict(image_heads=recipe.GEN_TINY["image_decoder_heads"], image_layers=recipe.GEN_TINY["image_decoder_layers"],
+               pc_heads=recipe.GEN_TINY["pointcloud_decoder_heads"], pc_layers=recipe.GEN_TINY["pointcloud_decoder_layers"],
+               pc_groups=recipe.GEN_TINY["pointcloud_num_groups"], pc_group_size=recipe.GEN_TINY["pointcloud_group_size"])
+
+
+def gen_inputs(B=4, S=45):
+    """Same recipe as oracle/capture_golden_gen.py:gen_inputs."""
+    hidden = recipe.det_randn("gen.hidden", (B, S, recipe.TOKEN_SIZE))
+    curr = recipe.det_randn("gen.curr", (B, 4, 672, 672))
+    nxt = recipe.det_randn("gen.next", (B, 3, 672, 672))
+    lo, hi = torch.tensor([0.0, -0.4, 0.75]), torch.tensor([0.6, 0.4, 1.25])
+    npc = lo + (hi - lo) * torch.rand(B, 1024, 3, generator=recipe._gen("gen.next_pc"))
+    return hidden, curr, nxt, npc
+
+
+def gen_state_dict(gold, pfx="vlm.generation_manager."):
+    names = [str(n) for n in gold["param_names"]]
+    shapes = [eval(str(s)) for s in gold["param_shapes"]]
+    return {pfx + n: recipe.det_weight(pfx + n, s) for n, s in zip(names, shapes)}
+
+
+@pytest.fixture(scope="module")
+def gen_gold():
+    return np.load(os.path.join(G, "generation.npz"), allow_pickle=True)
+
+
+def test_generation_heads_match_reference(gen_gold):
+    """Image + point-cloud generation heads and their losses, fp32 (reference mode A, dropout zeroed), forward and backward."""
+    from oracle import gen_oracle
+    pfx = "vlm.generation_manager."
+    sd = gen_state_dict(gen_gold)
+    names = [str(n) for n in gen_gold["grad_names"]]
+    for n in names:
+        sd[pfx + n].requires_grad_(True)
+    hidden, curr, nxt, npc = gen_inputs()
+    hidden.requires_grad_(True)
+    img, pc, ex = gen_oracle.generation_losses(hidden, curr, nxt, npc, sd, GEN_CFG, pfx=pfx)
+    assert abs(float(img) - float(gen_gold["A_image_gen_loss"])) < 2e-5
+    assert abs(float(pc) - float(gen_gold["A_point_cloud_gen_loss"])) < 2e-5
+    assert abs(float(ex["mse"] + 0.5 * ex["l1"]) - float(gen_gold["A_image_roi_generation_loss"])) < 2e-5
+    assert np.allclose(ex["delta_all"][:, ::16, ::97].detach().numpy(), gen_gold["A_delta_slice"], rtol=1e-3, atol=1e-4)
+    assert np.allclose(ex["points"].detach().numpy(), gen_gold["A_points"], rtol=1e-3, atol=1e-4)
+    (img + pc).backward()
+    assert np.abs(hidden.grad.numpy() - gen_gold["A_hidden_grad"]).max() <= 2e-3 * np.abs(gen_gold["A_hidden_grad"]).max()
+    norms = np.array([0.0 if sd[pfx + n].grad is None else float(sd[pfx + n].grad.norm()) for n in names])
+    assert np.allclose(norms, gen_gold["A_gradnorms"], rtol=2e-3, atol=1e-7)
+    for key in gen_gold.files:
+        if key.startswith("A_grad::"):
+            n = key[len("A_grad::"):]
+            g = sd[pfx + n].grad
+            ref = gen_gold[key]
+            got = (g.reshape(g.shape[0], -1)[:16, :64] if ref.ndim == 2 else g.reshape(-1)[:256]).numpy()
+            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-8, n
+
+
+def test_generation_bf16_reference_spread(gen_gold):
+    assert abs(float(gen_gold["C_image_gen_loss"]) - float(gen_gold["A_image_gen_loss"])) < 0.05
+    assert abs(float(gen_gold["C_point_cloud_gen_loss"]) - float(gen_gold["A_point_cloud_gen_loss"])) < 0.05
+
+
+def test_mla_e2e_post_training_matches_reference():
+    """Tiny MLA in post-training mode (BASELINE config[3] scaled down): loss dict + all gradient norms, fp32."""
+    gold = np.load(os.path.join(G, "mla_tiny_e2e_gen.npz"), allow_pickle=True)
+    sd = {str(n): recipe.det_weight(str(n), eval(str(s))) for n, s in zip(gold["param_names"], gold["param_shapes"])}
+    names = [str(n) for n in gold["grad_names"]]
+    for n in names:
+        sd[n].requires_grad_(True)
+    batch, draws = recipe.make_batch(R=2, with_next=True)
+    out = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, zero_pad_rows=False, gen_cfg=GEN_CFG)
+    assert abs(float(out["image_gen_loss"]) - float(gold["A_image_gen_loss"])) < 5e-5
+    assert abs(float(out["point_cloud_gen_loss"]) - float(gold["A_point_cloud_gen_loss"])) < 5e-5
+    assert abs(float(out["total_loss"]) - float(gold["A_total_loss"])) < 1e-4
+    assert float(gold["A_diff_loss"]) == float(gold["A_total_loss"])          # in-place aliasing, model_mla.py:215-229
+    out["total_loss"].backward()
+    norms = np.array([0.0 if sd[n].grad is None else float(sd[n].grad.norm()) for n in names])
+    assert np.allclose(norms, gold["A_gradnorms"], rtol=3e-3, atol=1e-7)
