@@ -101,3 +101,52 @@ def test_lr_schedule_and_camera_constants():
         get_camera_params("nope")
     Rw, tw, Ks = projection_constants("rlbench_front")
     assert abs(float(Ks[0, 0]) - (-307.7174807 * 3)) < 1e-3 and abs(float(Ks[0, 2]) - 336.0) < 1e-4
+
+
+def test_generation_manager_state_dict_matches_reference():
+    """Post-training heads: parameter / buffer names and shapes equal the reference's (captured in generation.npz)."""
+    import os
+    import numpy as np
+    from mla_amd.generation import MultimodalGenerationManager
+    from oracle import recipe
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "generation.npz"), allow_pickle=True)
+    g = recipe.GEN_TINY
+    mgr = MultimodalGenerationManager(
+        token_size=recipe.TOKEN_SIZE, use_image_generation=True, num_image_gen_queries=g["num_image_gen_queries"],
+        image_decoder_layers=g["image_decoder_layers"], image_decoder_heads=g["image_decoder_heads"], image_patch_size=42, use_roi=False,
+        use_pointcloud_generation=True, pointcloud_trans_dim=g["pointcloud_trans_dim"], pointcloud_decoder_layers=g["pointcloud_decoder_layers"],
+        pointcloud_decoder_heads=g["pointcloud_decoder_heads"], pointcloud_group_size=g["pointcloud_group_size"],
+        pointcloud_num_groups=g["pointcloud_num_groups"])
+    mine = {k: str(tuple(v.shape)) for k, v in mgr.state_dict().items()}
+    ref = {str(n): str(s) for n, s in zip(gold["param_names"], gold["param_shapes"])}
+    assert mine == ref
+
+
+def test_post_training_model_keys_and_freeze():
+    """BASELINE config[3] wiring on the host: state-dict keys of the whole model, trainable set, module keys."""
+    import os
+    import numpy as np
+    from mla_amd.backbones import LLaMa2LLMBackbone
+    from mla_amd.llama import LlamaConfig
+    from mla_amd.mla import MLA
+    from mla_amd.prismatic import PrismaticVLM
+    from oracle import recipe
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "mla_tiny_e2e_gen.npz"), allow_pickle=True)
+    bb = LLaMa2LLMBackbone(config=LlamaConfig(**recipe.TINY_LLAMA), pad_to_multiple_of=1)
+    flags = dict(use_generation=True, gen_image=True, use_roi=False, gen_pointcloud=True, gen_tactile=False)
+    vlm = PrismaticVLM("tiny", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_pointcloud=True, use_contrastive=True, **flags,
+                       **recipe.GEN_TINY)
+    m = MLA(vlm, None, token_size=recipe.TOKEN_SIZE, future_action_window_size=0, use_diff=True, use_pointcloud=True, use_contrastive=True,
+            **flags)
+    mine = {k: str(tuple(v.shape)) for k, v in m.state_dict().items()}
+    assert mine == {str(n): str(s) for n, s in zip(gold["param_names"], gold["param_shapes"])}
+    m.freeze_backbones("post-training")
+    assert "vlm.generation_manager" in m.trainable_module_keys and "vlm.generation_manager" in m.all_module_keys
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert set(str(n) for n in gold["grad_names"]) <= trainable
+    assert not any(n.startswith("vlm.vision_tower_2d") or n.startswith("vlm.vision_tower_3d") for n in trainable)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        PrismaticVLM("tiny", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_generation=True, gen_image=True, use_roi=True,
+                     gen_pointcloud=False, gen_tactile=False, **recipe.GEN_TINY).generation_manager.image_gen_module(
+            torch.zeros(1, 8, recipe.TOKEN_SIZE))
