@@ -34,7 +34,7 @@ def model_flops_per_sample(S, H=4096, I=11008, L=32, V=32064, R=R_DIFF):
     return dec, dec + lm
 
 
-def build(device, save_level, tiny=False, use_pointcloud=True):
+def build(device, save_level, tiny=False, use_pointcloud=True, generation=False):
     from mla_amd.backbones import LLaMa2LLMBackbone
     from mla_amd.llama import LlamaConfig
     from mla_amd.mla import MLA
@@ -46,13 +46,14 @@ def build(device, save_level, tiny=False, use_pointcloud=True):
         else:
             cfg = LlamaConfig(activation_save_level=save_level)   # Llama-2-7b
         bb = LLaMa2LLMBackbone("llama2-7b-pure", config=cfg)
+        gen = dict(use_generation=generation, gen_image=generation, use_roi=False, gen_pointcloud=generation, gen_tactile=False)
         vlm = PrismaticVLM("mla-7b", bb, token_size=cfg.hidden_size, action_dim=7, use_diff=True, use_pointcloud=use_pointcloud,
-                           use_contrastive=use_pointcloud, use_generation=False, future_action_window_size=0)
+                           use_contrastive=use_pointcloud, future_action_window_size=0, **gen)
         mla = MLA(vlm, None, token_size=cfg.hidden_size, action_dim=7, future_action_window_size=0, use_diff=True,
-                  use_pointcloud=use_pointcloud, use_contrastive=use_pointcloud, use_generation=False)
+                  use_pointcloud=use_pointcloud, use_contrastive=use_pointcloud, **gen)
         # <BOD>, <EOD> added by scripts/train.py:132-155 stay inside the 32064 rows; give final_layer a non-zero read-out
         torch.nn.init.normal_(mla.vlm.final_layer.mlp.fc2.weight, std=0.02)
-    mla.freeze_backbones("finetune")
+    mla.freeze_backbones("post-training" if generation else "finetune")
     return mla
 
 
@@ -100,8 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--save-level", type=int, default=1, help="activation policy: 2 keep all, 1 recompute cheap elementwise, 0 full recompute")
     ap.add_argument("--tiny", action="store_true", help="small model for smoke runs (NOT the benchmark config)")
-    ap.add_argument("--config", type=int, default=1, choices=[1, 4],
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
                     help="BASELINE.json configs index: 1 = 7B SFT (the headline metric; also configs[2] when --gpus 8), "
+                         "3 = post-training (image + point-cloud generation heads on top of config 1), "
                          "4 = pretrain shape, use_pointcloud=False, S=2048, activation checkpointing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
@@ -123,17 +125,18 @@ def main():
     from mla_amd.strategy import FSDPStrategy
     from mla_amd.synthetic import make_batch
 
-    l_text = L_TEXT if args.config == 1 else 2048 - S_FUSED - 3
+    l_text = L_TEXT if args.config in (1, 3) else 2048 - S_FUSED - 3
+    pc_on, gen_on = args.config in (1, 3), args.config == 3
     if args.config == 4:
         args.save_level = 0                    # the config names activation checkpointing (4x the tokens of config 1)
     torch.manual_seed(42)                      # identical initial weights on every rank (scripts/train.py:76 seed)
-    mla = build(device, args.save_level, args.tiny, use_pointcloud=(args.config == 1))
+    mla = build(device, args.save_level, args.tiny, use_pointcloud=pc_on, generation=gen_on)
     torch.manual_seed(42 + rank)               # rank-local noise / timesteps / FPS starts, like the reference's per-rank RNG
-    strat = FSDPStrategy(mla, local_rank, stage="finetune", global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
+    strat = FSDPStrategy(mla, local_rank, stage="post-training" if gen_on else "finetune", global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
                          learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
                          enable_gradient_checkpointing=False, repeated_diffusion_steps=R_DIFF)
     strat.run_setup(n_train_examples=10_000)
-    batch = make_batch(B=B_PER_GPU, L_text=l_text, seed=42 + rank, device=device, use_pointcloud=(args.config == 1))
+    batch = make_batch(B=B_PER_GPU, L_text=l_text, seed=42 + rank, device=device, use_pointcloud=pc_on, with_next=gen_on)
     S = l_text + S_FUSED + 3
 
     def sync():
@@ -177,6 +180,8 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": ("BASELINE.json configs[1]: MLA-Llama2-7B SFT, use_pointcloud+use_contrastive, 672x672(+mask) image + "
                                        "1024 points + 32 text tokens, per-GPU batch 8 x 4 diffusion repeats = 32 x 548 tokens" if args.config == 1 else
+                                       "BASELINE.json configs[3]: MLA post-training = configs[1] + image (128 queries, 2+3 decoder layers, d=4096) and "
+                                       "point-cloud (4 blocks, d=1024) generation heads, use_roi=False, dropout 0.1 active; 32 x 548 tokens" if args.config == 3 else
                                        "BASELINE.json configs[4]: MLA pretrain shape, use_pointcloud=False, S=2048, activation checkpointing, "
                                        "per-GPU batch 8 x 4 diffusion repeats = 32 x 2048 tokens")
                                       + (" [TINY SMOKE MODEL - not the benchmark]" if args.tiny else ""),

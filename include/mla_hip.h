@@ -175,10 +175,10 @@ int mla_chamfer_fwd(const float* pred, const float* gt, float* d1, int* i1, floa
                     float* workspace, size_t workspace_bytes, mla_stream_t stream);
 int mla_chamfer_bwd(const float* pred, const float* gt, const float* d1, const int* i1, const float* d2, const int* i2,
                     const float* gscale, float* dpred, int B, int N, int M, mla_stream_t stream);
-int mla_imgloss_fwd(const void* delta_raw, const void* curr, const void* next, int img_fp32, float* sums, int B, int CT_curr,
+int mla_imgloss_fwd(const void* delta_raw, int ld, const void* curr, const void* next, int img_fp32, float* sums, int B, int CT_curr,
                     int CT_next, int HW, int ps, float clip, float* workspace, size_t workspace_bytes, mla_stream_t stream);
-int mla_imgloss_bwd(const void* delta_raw, const void* curr, const void* next, int img_fp32, const float* gscale, void* ddelta_raw,
-                    int B, int CT_curr, int CT_next, int HW, int ps, float clip, mla_stream_t stream);
+int mla_imgloss_bwd(const void* delta_raw, int ld, const void* curr, const void* next, int img_fp32, const float* gscale,
+                    void* ddelta_raw, int B, int CT_curr, int CT_next, int HW, int ps, float clip, mla_stream_t stream);
 
 #ifdef __cplusplus
 }

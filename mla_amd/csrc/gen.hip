@@ -329,7 +329,7 @@ __device__ __forceinline__ float img_at(const TI* img, int CT, int HW, int ps, i
 template <typename TI>
 __global__ __launch_bounds__(256) void imgloss_fwd_kernel(const bf16_t* __restrict__ draw, const TI* __restrict__ curr, const TI* __restrict__ next,
                                                           float* __restrict__ partial, int B, int CTc, int CTn, int HW, int ps, int npatch,
-                                                          float clip) {
+                                                          float clip, int ld) {
   __shared__ float scratch[16];
   const int pd = 3 * ps * ps;
   const long long n = (long long)B * npatch * pd;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void imgloss_fwd_kernel(const bf16_t* __restri
     const int e = (int)(i % pd);
     const long long r = i / pd;
     const int patch = (int)(r % npatch), b = (int)(r / npatch);
-    const float delta = clip * tanhf(bf2f(draw[i]));
+    const float delta = clip * tanhf(bf2f(draw[r * ld + e]));
     const float pred = 0.05f * img_at<TI>(curr, CTc, HW, ps, b, patch, e) + delta;
     const float diff = pred - img_at<TI>(next, CTn, HW, ps, b, patch, e);
     a += diff * diff; l1 += fabsf(diff); dl += fabsf(delta);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void imgloss_fwd_kernel(const bf16_t* __restri
 template <typename TI>
 __global__ __launch_bounds__(256) void imgloss_bwd_kernel(const bf16_t* __restrict__ draw, const TI* __restrict__ curr, const TI* __restrict__ next,
                                                           const float* __restrict__ gscale, bf16_t* __restrict__ ddraw, int B, int CTc, int CTn,
-                                                          int HW, int ps, int npatch, float clip) {
+                                                          int HW, int ps, int npatch, float clip, int ld) {
   const int pd = 3 * ps * ps;
   const long long n = (long long)B * npatch * pd;
   const float g = gscale[0] / (float)n;
@@ -358,11 +358,11 @@ __global__ __launch_bounds__(256) void imgloss_bwd_kernel(const bf16_t* __restri
     const int e = (int)(i % pd);
     const long long r = i / pd;
     const int patch = (int)(r % npatch), b = (int)(r / npatch);
-    const float th = tanhf(bf2f(draw[i]));
+    const float th = tanhf(bf2f(draw[r * ld + e]));
     const float delta = clip * th;
     const float diff = 0.05f * img_at<TI>(curr, CTc, HW, ps, b, patch, e) + delta - img_at<TI>(next, CTn, HW, ps, b, patch, e);
     const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f), sd = delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f);
-    ddraw[i] = f2bf(g * (2.f * diff + 0.5f * sg - 0.1f * sd) * clip * (1.f - th * th));
+    ddraw[r * ld + e] = f2bf(g * (2.f * diff + 0.5f * sg - 0.1f * sd) * clip * (1.f - th * th));
   }
 }
 __global__ __launch_bounds__(256) void sum3_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int P) {
@@ -485,32 +485,34 @@ extern "C" int mla_chamfer_bwd(const float* pred, const float* gt, const float* 
   hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, pred, gt, d1, i1, d2, i2, gscale, dpred, B, N, M);
   MLA_LAUNCH_CHECK();
 }
-// sums[3] = { sum (pred-gt)^2, sum |pred-gt|, sum |delta| }; workspace >= 2048*3 floats
-extern "C" int mla_imgloss_fwd(const void* delta_raw, const void* curr, const void* next, int img_fp32, float* sums, int B, int CT_curr,
-                               int CT_next, int HW, int ps, float clip, float* workspace, size_t workspace_bytes, hipStream_t stream) {
-  MLA_CHECK_ARG(delta_raw && curr && next && sums && workspace && HW % ps == 0, "mla_imgloss_fwd: bad args");
+// sums[3] = { sum (pred-gt)^2, sum |pred-gt|, sum |delta| }; workspace >= 2048*3 floats. delta_raw rows have pitch ld >= 3*ps*ps
+// (the delta head's output is padded to the MFMA tile granularity); backward writes only the valid columns
+extern "C" int mla_imgloss_fwd(const void* delta_raw, int ld, const void* curr, const void* next, int img_fp32, float* sums, int B,
+                               int CT_curr, int CT_next, int HW, int ps, float clip, float* workspace, size_t workspace_bytes,
+                               hipStream_t stream) {
+  MLA_CHECK_ARG(delta_raw && curr && next && sums && workspace && HW % ps == 0 && ld >= 3 * ps * ps, "mla_imgloss_fwd: bad args");
   const int nb = 2048;
   MLA_CHECK_ARG(workspace_bytes >= (size_t)nb * 3 * sizeof(float), "mla_imgloss_fwd: workspace too small");
   const int npatch = (HW / ps) * (HW / ps);
   if (img_fp32)
     hipLaunchKernelGGL(imgloss_fwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)delta_raw, (const float*)curr, (const float*)next,
-                       workspace, B, CT_curr, CT_next, HW, ps, npatch, clip);
+                       workspace, B, CT_curr, CT_next, HW, ps, npatch, clip, ld);
   else
     hipLaunchKernelGGL(imgloss_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)delta_raw, (const bf16_t*)curr,
-                       (const bf16_t*)next, workspace, B, CT_curr, CT_next, HW, ps, npatch, clip);
+                       (const bf16_t*)next, workspace, B, CT_curr, CT_next, HW, ps, npatch, clip, ld);
   hipLaunchKernelGGL(sum3_final_kernel, dim3(1), dim3(256), 0, stream, workspace, sums, nb);
   MLA_LAUNCH_CHECK();
 }
-extern "C" int mla_imgloss_bwd(const void* delta_raw, const void* curr, const void* next, int img_fp32, const float* gscale, void* ddelta_raw,
-                               int B, int CT_curr, int CT_next, int HW, int ps, float clip, hipStream_t stream) {
+extern "C" int mla_imgloss_bwd(const void* delta_raw, int ld, const void* curr, const void* next, int img_fp32, const float* gscale,
+                               void* ddelta_raw, int B, int CT_curr, int CT_next, int HW, int ps, float clip, hipStream_t stream) {
   MLA_CHECK_ARG(delta_raw && curr && next && gscale && ddelta_raw, "mla_imgloss_bwd: null pointer");
   const int npatch = (HW / ps) * (HW / ps);
   const long long n = (long long)B * npatch * 3 * ps * ps;
   if (img_fp32)
     hipLaunchKernelGGL(imgloss_bwd_kernel<float>, dim3(gridn(n)), dim3(256), 0, stream, (const bf16_t*)delta_raw, (const float*)curr,
-                       (const float*)next, gscale, (bf16_t*)ddelta_raw, B, CT_curr, CT_next, HW, ps, npatch, clip);
+                       (const float*)next, gscale, (bf16_t*)ddelta_raw, B, CT_curr, CT_next, HW, ps, npatch, clip, ld);
   else
     hipLaunchKernelGGL(imgloss_bwd_kernel<bf16_t>, dim3(gridn(n)), dim3(256), 0, stream, (const bf16_t*)delta_raw, (const bf16_t*)curr,
-                       (const bf16_t*)next, gscale, (bf16_t*)ddelta_raw, B, CT_curr, CT_next, HW, ps, npatch, clip);
+                       (const bf16_t*)next, gscale, (bf16_t*)ddelta_raw, B, CT_curr, CT_next, HW, ps, npatch, clip, ld);
   MLA_LAUNCH_CHECK();
 }

@@ -158,7 +158,8 @@ class ImageGenerationModule(nn.Module):
         tokens = (self.mae_mask_token + self.mae_pos_embed).to(dt).expand(B, -1, -1).contiguous()
         feats = self.mae_decoder(tokens, intent)
         fn = ops.layernorm(feats, self.mae_patch_norm.weight, self.mae_patch_norm.bias, self.mae_patch_norm.eps)
-        delta_raw = ops.linear(fn, self.mae_delta_head.weight, self.mae_delta_head.bias)            # [B, 256, 3*ps*ps]
+        # [B, 256, ld]: 3*ps*ps = 5292 valid columns, padded to ld = 5312 so every GEMM of the head stays on the MFMA path
+        delta_raw = ops.PaddedLinearFn.apply(fn, self.mae_delta_head.weight, self.mae_delta_head.bias)
         roi = torch.ones((B, self.image_num_patches), dtype=torch.bool, device=delta_raw.device)
         # alpha / offset heads (models.py:199-200) only act outside the ROI: with the all-true mask they feed nothing, get no
         # gradient in the reference either, and are not evaluated here.
@@ -169,7 +170,8 @@ class ImageGenerationModule(nn.Module):
         """The reference's full output dict (image_generation / delta_all / alpha_all / offset_all, models.py:218-224) for
         visualisation; not on the training path."""
         fn = outputs["norm_features"]
-        delta_all = torch.tanh(outputs["delta_raw"].float()) * self.gen_delta_clip
+        pd = 3 * self.image_patch_size ** 2
+        delta_all = torch.tanh(outputs["delta_raw"][..., :pd].float()) * self.gen_delta_clip
         alpha = torch.sigmoid(ops.linear(fn, self.mae_alpha_head.weight, self.mae_alpha_head.bias).squeeze(-1).float())
         offset = torch.tanh(ops.linear(fn, self.mae_offset_head.weight, self.mae_offset_head.bias).float()) * float(self.max_patch_shift_pixels)
         gen = 0.05 * current_images_patches.float() + delta_all

@@ -542,9 +542,10 @@ register_signatures({
     "mla_chamfer_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                         c_void_p],
     "mla_chamfer_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "mla_imgloss_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t,
+    "mla_imgloss_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                        c_size_t, c_void_p],
+    "mla_imgloss_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                         c_void_p],
-    "mla_imgloss_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
 })
 
 
@@ -660,19 +661,21 @@ def chamfer_bwd(pred, gt, d1, i1, d2, i2, gscale):
 
 
 def imgloss_fwd(delta_raw, curr, nxt, ps, clip):
-    B = delta_raw.shape[0]
+    """delta_raw [B, npatch, ld] bf16 with ld >= 3*ps*ps (columns beyond are padding)."""
+    B, ld = delta_raw.shape[0], delta_raw.shape[-1]
     fp32 = curr.dtype == torch.float32
     if curr.dtype != nxt.dtype or curr.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("imgloss: curr/next images must both be fp32 or both bf16")
     sums = torch.empty(3, dtype=torch.float32, device=delta_raw.device)
     ws = workspace(2048 * 3 * 4, delta_raw.device)
-    call("mla_imgloss_fwd", _p(delta_raw), _p(curr), _p(nxt), 1 if fp32 else 0, _p(sums), B, curr.shape[1], nxt.shape[1], curr.shape[2], ps,
-         float(clip), _p(ws), ws.numel())
+    call("mla_imgloss_fwd", _p(delta_raw), ld, _p(curr), _p(nxt), 1 if fp32 else 0, _p(sums), B, curr.shape[1], nxt.shape[1], curr.shape[2],
+         ps, float(clip), _p(ws), ws.numel())
     return sums
 
 
 def imgloss_bwd(delta_raw, curr, nxt, ps, clip, gscale):
-    out = torch.empty_like(delta_raw)
-    call("mla_imgloss_bwd", _p(delta_raw), _p(curr), _p(nxt), 1 if curr.dtype == torch.float32 else 0, _p(gscale), _p(out),
+    ld = delta_raw.shape[-1]
+    out = torch.zeros_like(delta_raw) if ld != 3 * ps * ps else torch.empty_like(delta_raw)
+    call("mla_imgloss_bwd", _p(delta_raw), ld, _p(curr), _p(nxt), 1 if curr.dtype == torch.float32 else 0, _p(gscale), _p(out),
          delta_raw.shape[0], curr.shape[1], nxt.shape[1], curr.shape[2], ps, float(clip))
     return out

@@ -819,7 +819,7 @@ class ImageGenLossFn(torch.autograd.Function):
         _check_bf16_cuda(delta_raw)
         delta_raw = delta_raw.contiguous()
         sums = hip.imgloss_fwd(delta_raw, curr_img, next_img, ps, clip)
-        n = float(delta_raw.numel())
+        n = float(delta_raw.numel() // delta_raw.shape[-1] * 3 * ps * ps)     # valid columns only (rows may be padded)
         parts = sums / n
         loss = parts[0] + 0.5 * parts[1] - 0.1 * parts[2]
         ctx.save_for_backward(delta_raw, curr_img, next_img)
@@ -832,3 +832,42 @@ class ImageGenLossFn(torch.autograd.Function):
         delta_raw, curr_img, next_img = ctx.saved_tensors
         d = hip.imgloss_bwd(delta_raw, curr_img, next_img, ctx.ps, ctx.clip, g.to(torch.float32).reshape(1).contiguous())
         return d, None, None, None, None
+
+
+class PaddedLinearFn(torch.autograd.Function):
+    """y = x W^T + b with the output width padded up to a multiple of 64 (pad columns are exactly zero). For heads whose width
+    breaks the 16-byte row alignment the MFMA GEMMs need on the backward operands -- mae_delta_head has 3*42*42 = 5292 outputs
+    (models/mla/generation/models.py:125-127): padded to 5312, forward, dgrad and wgrad all stay on the k-contiguous MFMA kernel
+    instead of the SIMT fallback. The parameter keeps its reference shape; a zero-padded bf16 copy is rebuilt per step."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _check_bf16_cuda(x, weight, bias)
+        x2 = _as2d(x)
+        N, K = weight.shape
+        Np = (N + 63) // 64 * 64
+        wp = torch.zeros((Np, K), dtype=BF16, device=x.device)
+        wp[:N].copy_(weight)
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(Np, dtype=BF16, device=x.device)
+            bp[:N].copy_(bias)
+        out = hip.gemm(x2, wp, bias=bp)
+        ctx.save_for_backward(x2, wp)
+        ctx.weight, ctx.bias, ctx.in_shape = weight, bias, x.shape
+        return out.view(*x.shape[:-1], Np)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wp = ctx.saved_tensors
+        N = ctx.weight.shape[0]
+        dy2 = _as2d(dy)
+        ni = ctx.needs_input_grad
+        dx = hip.gemm(dy2, hip.transpose(wp)).view(ctx.in_shape) if ni[0] else None
+        dw = None
+        if ni[1]:
+            dw = deliver_wgrad_nt((ctx.weight,), hip.transpose(dy2)[:N], hip.transpose(x2), (True,))[0]
+        db = None
+        if ctx.bias is not None and ni[2]:
+            db = deliver_vec_grad(ctx.bias, lambda out, acc: hip.colsum(dy2[:, :N], out, acc))
+        return dx, dw, db

@@ -9,7 +9,8 @@ IGNORE_INDEX = -100
 
 
 def make_batch(B: int = 8, L_text: int = 32, seed: int = 42, device="cpu", ragged: bool = False, use_pointcloud: bool = True,
-               vocab: int = 32000, pad_id: int = PAD_ID, img: int = 672, n_points: int = 1024, action_chunk: int = 1):
+               vocab: int = 32000, pad_id: int = PAD_ID, img: int = 672, n_points: int = 1024, action_chunk: int = 1,
+               with_next: bool = False):
     """input_ids = [1, prompt ids in [3, 31743], 29871, 32001, 32002, 2] (EOS last, no other id 2), right-padded when
     ragged; labels keep only the final </s>; images CLIP-normalised N(0,1) RGB + all-ones mask; points uniform in the
     RLBench workspace box; actions / proprio ~ U[-1, 1]."""
@@ -32,6 +33,9 @@ def make_batch(B: int = 8, L_text: int = 32, seed: int = 42, device="cpu", ragge
                  action_masks=torch.ones(B, action_chunk, dtype=torch.bool), camera_name="rlbench_front")
     if use_pointcloud:
         batch["point_cloud"] = lo + (hi - lo) * torch.rand(B, n_points, 3, generator=g)
+    if with_next:   # post-training targets (datasets.py next-frame fields): next RGB frame and next point cloud
+        batch["next_images"] = torch.randn(B, 3, img, img, generator=g)
+        batch["next_point_cloud"] = lo + (hi - lo) * torch.rand(B, n_points, 3, generator=g)
     dev = torch.device(device)
     mv = lambda v: ({k: x.to(dev) for k, x in v.items()} if isinstance(v, dict) else (v.to(dev) if torch.is_tensor(v) else v))  # noqa: E731
     return {k: mv(v) for k, v in batch.items()}

@@ -236,7 +236,8 @@ def test_generation_heads_against_reference_golden(dev):
     for key, got in (("image_gen_loss", loss_img), ("point_cloud_gen_loss", loss_pc)):
         A, C = float(gold["A_" + key]), float(gold["C_" + key])
         assert abs(float(got) - A) < 2 * abs(C - A) + 2e-2, (key, float(got), A, C)
-    delta = (torch.tanh(outs["delta_raw"].float()) * 5.0)[:, ::16, ::97].detach().cpu().numpy()
+    assert outs["delta_raw"].shape[-1] == 5312 and float(outs["delta_raw"][..., 5292:].float().abs().max()) == 0.0
+    delta = (torch.tanh(outs["delta_raw"][..., :5292].float()) * 5.0)[:, ::16, ::97].detach().cpu().numpy()
     assert err(delta, gold["A_delta_slice"]) < 2 * err(gold["C_delta_slice"], gold["A_delta_slice"]) + 1e-2
     pts = outs["pointcloud_coord_generation"].detach().float().cpu().numpy()
     assert err(pts, gold["A_points"]) < 2 * err(gold["C_points"], gold["A_points"]) + 1e-2
