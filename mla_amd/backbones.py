@@ -68,6 +68,40 @@ class LLaMa2LLMBackbone(LLMBackbone):
         self.llm.config.pad_token_id = self.tokenizer.pad_token_id
         self.llm.config.use_cache = False
 
+    def load_hf_checkpoint(self, path: str) -> dict:
+        """base_llm.py:120-136 loads `meta-llama/Llama-2-7b-hf` through HF `from_pretrained` BEFORE the tokenizer resize; here the
+        HF weight files (``*.safetensors`` shards, else ``pytorch_model*.bin``) of a local directory are read directly -- HF's
+        parameter names are this module's names. Embedding / lm_head tables with fewer rows than the resized ones (32000 vs
+        32064) fill the leading rows, exactly what ``resize_token_embeddings`` keeps. Returns {"loaded": n, "skipped": [...]}."""
+        import glob
+        import os
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if files:
+            from safetensors.torch import load_file
+            shards = (load_file(f) for f in files)
+        else:
+            files = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+            if not files:
+                raise FileNotFoundError(f"no *.safetensors or pytorch_model*.bin under {path}")
+            shards = (torch.load(f, map_location="cpu") for f in files)
+        own = self.llm.state_dict()
+        loaded, skipped = 0, []
+        with torch.no_grad():
+            for shard in shards:
+                for k, v in shard.items():
+                    if k not in own:
+                        skipped.append(k)                      # e.g. rotary inv_freq buffers of older exports
+                        continue
+                    dst = own[k]
+                    if dst.shape == v.shape:
+                        dst.copy_(v)
+                    elif dst.dim() == 2 and v.dim() == 2 and dst.shape[1] == v.shape[1] and dst.shape[0] > v.shape[0]:
+                        dst[:v.shape[0]].copy_(v)
+                    else:
+                        raise ValueError(f"{k}: checkpoint shape {tuple(v.shape)} does not fit {tuple(dst.shape)}")
+                    loaded += 1
+        return {"loaded": loaded, "skipped": skipped}
+
     @property
     def transformer_layer_cls(self) -> Type[nn.Module]:
         return LlamaDecoderLayer

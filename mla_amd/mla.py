@@ -42,6 +42,62 @@ class MLA(nn.Module):
             self.diffusion = create_diffusion(timestep_respacing="", noise_schedule="squaredcos_cap_v2", diffusion_steps=100,
                                               sigma_small=True, learn_sigma=False)
 
+    @classmethod
+    def from_pretrained(cls, action_tokenizer, pretrained_checkpoint, model_id: str, llm_backbone, enable_mixed_precision_training: bool = True,
+                        arch_specifier: str = "gelu-mlp", freeze_weights: bool = True, action_dim: int = 7,
+                        future_action_window_size: int = 15, past_action_window_size: int = 0, use_ema: bool = False, norm_stats=None,
+                        class_dropout_prob: float = 0.0, use_diff: bool = False, use_pointcloud: bool = False, use_tactile: bool = False,
+                        use_contrastive: bool = False, use_generation: bool = False, gen_image: bool = False, use_roi: bool = False,
+                        gen_pointcloud: bool = False, gen_tactile: bool = False, **kwargs) -> "MLA":
+        """model_mla.py:311-492: build the VLM, then load the per-module state dicts of a ``{"model": {...}}`` checkpoint with
+        the reference's rules (missing optional modules keep their initialisation; the LLM loads non-strictly; embedders load
+        only when their input width matches ``action_dim``; generation sub-modules load by key prefix)."""
+        token_size = llm_backbone.llm.lm_head.in_features
+        vlm = PrismaticVLM(model_id, llm_backbone, enable_mixed_precision_training=enable_mixed_precision_training,
+                           class_dropout_prob=class_dropout_prob, use_diff=use_diff, action_dim=action_dim, token_size=token_size,
+                           use_pointcloud=use_pointcloud, use_tactile=use_tactile, use_contrastive=use_contrastive,
+                           use_generation=use_generation, gen_image=gen_image, use_roi=use_roi, gen_pointcloud=gen_pointcloud,
+                           gen_tactile=gen_tactile, **kwargs)
+        sd = torch.load(pretrained_checkpoint, map_location="cpu")["model"]
+        loaded = []
+
+        def load(name, module, strict=True):
+            module.load_state_dict(sd[name], strict=strict)
+            loaded.append(name)
+
+        if "vision_tower_2d" in sd:
+            load("vision_tower_2d", vlm.vision_tower_2d)
+        if "projector_2d" in sd:
+            load("projector_2d", vlm.projector_2d)
+        if use_pointcloud and "vision_tower_3d" in sd:
+            load("vision_tower_3d", vlm.vision_tower_3d)
+        if use_pointcloud and "projector_3d" in sd:
+            load("projector_3d", vlm.projector_3d)
+        assert "llm_backbone" in sd, "PrismaticVLM `from_pretrained` expects checkpoint with keys for `llm_backbone`!"
+        load("llm_backbone", vlm.llm_backbone, strict=False)
+        if "proprio_embedder" in sd and sd["proprio_embedder"]["mlp.fc1.weight"].shape[-1] == action_dim:
+            load("proprio_embedder", vlm.proprio_embedder)
+        if use_diff and all(k in sd for k in ("x_embedder", "t_embedder", "final_layer")):
+            if sd["x_embedder"]["mlp.fc1.weight"].shape[-1] == action_dim:
+                for k in ("x_embedder", "t_embedder", "final_layer"):
+                    load(k, getattr(vlm, k))
+        if use_generation and "generation_manager" in sd:
+            for flag, sub in ((gen_image, "image_gen_module"), (gen_pointcloud, "pointcloud_gen_module")):
+                part = {k[len(sub) + 1:]: v for k, v in sd["generation_manager"].items() if k.startswith(sub + ".")}
+                if flag and part:
+                    getattr(vlm.generation_manager, sub).load_state_dict(part)
+                    loaded.append("generation_manager." + sub)
+        if freeze_weights:
+            vlm.requires_grad_(False)
+            vlm.eval()
+        model = cls(vlm, action_tokenizer, token_size=token_size, action_dim=action_dim,
+                    future_action_window_size=future_action_window_size, past_action_window_size=past_action_window_size, use_ema=use_ema,
+                    norm_stats=norm_stats, use_diff=use_diff, use_pointcloud=use_pointcloud, use_tactile=use_tactile,
+                    use_contrastive=use_contrastive, use_generation=use_generation, gen_image=gen_image, use_roi=use_roi,
+                    gen_pointcloud=gen_pointcloud, gen_tactile=gen_tactile)
+        model.loaded_module_keys = loaded
+        return model
+
     @property
     def trainable_module_keys(self) -> List[str]:
         return ["vlm." + k for k in self.vlm.trainable_module_keys] + self._trainable_module_keys

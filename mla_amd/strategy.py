@@ -103,5 +103,34 @@ class FSDPStrategy:
         self.step += 1
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
 
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, run_dir, global_step: int, epoch: int, train_loss: Optional[float] = None, only_trainable: bool = True):
+        """training/strategies/fsdp.py:100-141: gather the full fp32 state dict (every rank takes part in the gathers), split it
+        by module key (``vlm.`` prefix dropped), rank 0 writes ``{"model": {mkey: OrderedDict}}`` to
+        ``run_dir/checkpoints/step-XXXXXX-epoch-XX-loss=....pt``. Optimizer state is not saved (commented out in the reference).
+        Returns the path (rank 0) or None."""
+        from collections import OrderedDict
+        from pathlib import Path
+        assert self.sharded is not None, "save_checkpoint needs run_setup() first"
+        full = {k: v.cpu() for k, v in self.sharded.full_state_dict_fp32().items()}
+        mkeys = list(self.vlm.trainable_module_keys if only_trainable else self.vlm.all_module_keys)
+        model_state_dicts = {mkey: OrderedDict() for mkey in mkeys}
+        for key, val in self.vlm.state_dict().items():          # module order; buffers (BatchNorm statistics) come from here
+            for mkey in mkeys:
+                if key.startswith(mkey + "."):
+                    model_state_dicts[mkey][key[len(mkey) + 1:]] = full[key] if key in full else val.detach().cpu().clone()
+        path = None
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if rank == 0:
+            ckpt_dir = Path(run_dir) / "checkpoints"
+            ckpt_dir.mkdir(parents=True, exist_ok=True)
+            tag = "inf" if train_loss is None else f"{train_loss:.4f}"
+            path = ckpt_dir / f"step-{global_step:06d}-epoch-{epoch:02d}-loss={tag}.pt"
+            out = OrderedDict((k[4:] if k.startswith("vlm.") else k, v) for k, v in model_state_dicts.items())
+            torch.save({"model": out}, path)
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        return path
+
     def clip_grad_norm(self):
         return self.sharded.grad_norm_and_clip(self.max_grad_norm)

@@ -150,3 +150,85 @@ def test_post_training_model_keys_and_freeze():
         PrismaticVLM("tiny", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_generation=True, gen_image=True, use_roi=True,
                      gen_pointcloud=False, gen_tactile=False, **recipe.GEN_TINY).generation_manager.image_gen_module(
             torch.zeros(1, 8, recipe.TOKEN_SIZE))
+
+
+def test_hf_llama_weight_files_load_into_backbone(tmp_path):
+    """HF-named safetensors shards (32000-row tables) load into the resized (32064-row style) backbone."""
+    from safetensors.torch import save_file
+    from mla_amd.backbones import LLaMa2LLMBackbone
+    from mla_amd.llama import LlamaConfig
+    cfg = dict(vocab_size=500, hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1, rms_norm_eps=1e-5)
+    bb = LLaMa2LLMBackbone(config=LlamaConfig(**cfg), pad_to_multiple_of=64)
+    own = bb.llm.state_dict()
+    g = torch.Generator().manual_seed(0)
+    hf = {}
+    for k, v in own.items():
+        if "contrastive" in k:
+            continue
+        shape = (500, 128) if k in ("model.embed_tokens.weight", "lm_head.weight") else tuple(v.shape)
+        hf[k] = torch.randn(*shape, generator=g)
+    hf["model.layers.0.self_attn.rotary_emb.inv_freq"] = torch.ones(64)
+    keys = sorted(hf)
+    save_file({k: hf[k] for k in keys[: len(keys) // 2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: hf[k] for k in keys[len(keys) // 2:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    before_tail = own["model.embed_tokens.weight"][500:].clone()
+    info = bb.load_hf_checkpoint(str(tmp_path))
+    assert info["loaded"] == len(hf) - 1 and info["skipped"] == ["model.layers.0.self_attn.rotary_emb.inv_freq"]
+    now = bb.llm.state_dict()
+    assert now["model.embed_tokens.weight"].shape[0] == 512
+    assert torch.equal(now["model.embed_tokens.weight"][:500], hf["model.embed_tokens.weight"])
+    assert torch.equal(now["model.embed_tokens.weight"][500:], before_tail)
+    assert torch.equal(now["model.layers.1.mlp.down_proj.weight"], hf["model.layers.1.mlp.down_proj.weight"])
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    """save_checkpoint writes the reference's layout ({"model": {module_key: {leaf: fp32}}}, `vlm.` dropped, file name pattern,
+    fsdp.py:100-141); MLA.from_pretrained reads it back with the reference's per-module rules (model_mla.py:360-465)."""
+    import numpy as np
+    from test_fsdp_gloo import TorchLocalOps
+    from mla_amd.backbones import LLaMa2LLMBackbone
+    from mla_amd.llama import LlamaConfig
+    from mla_amd.mla import MLA
+    from mla_amd.prismatic import PrismaticVLM
+    from mla_amd.strategy import FSDPStrategy
+    from oracle import recipe
+    flags = dict(use_generation=True, gen_image=True, use_roi=False, gen_pointcloud=True, gen_tactile=False)
+
+    def backbone():
+        return LLaMa2LLMBackbone(config=LlamaConfig(**recipe.TINY_LLAMA), pad_to_multiple_of=1)
+    vlm = PrismaticVLM("tiny", backbone(), token_size=recipe.TOKEN_SIZE, use_diff=True, use_pointcloud=True, use_contrastive=True, **flags,
+                       **recipe.GEN_TINY)
+    m = MLA(vlm, None, token_size=recipe.TOKEN_SIZE, future_action_window_size=0, use_diff=True, use_pointcloud=True, use_contrastive=True,
+            **flags)
+    want = {k: recipe.det_weight(k, v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(want, strict=True)
+    m.freeze_backbones("post-training")
+    strat = FSDPStrategy(m, "cpu", stage="post-training", local_ops=TorchLocalOps(), enable_gradient_checkpointing=False)
+    strat.run_setup(100)
+    assert next(m.parameters()).dtype == torch.bfloat16            # compute weights; fp32 masters live in the shards
+    path = strat.save_checkpoint(tmp_path, global_step=12, epoch=3, train_loss=0.123456)
+    assert path.name == "step-000012-epoch-03-loss=0.1235.pt" and path.parent.name == "checkpoints"
+    ck = torch.load(path, map_location="cpu")
+    assert list(ck) == ["model"]
+    assert set(ck["model"]) == {"vision_tower_2d", "projector_2d", "llm_backbone", "proprio_embedder", "x_embedder", "t_embedder",
+                                "final_layer", "vision_tower_3d", "projector_3d", "generation_manager"}
+    assert "llm.model.layers.0.self_attn.q_proj.weight" in ck["model"]["llm_backbone"]
+    assert "image_gen_module.intent_decoder.layers.0.self_attn.in_proj_weight" in ck["model"]["generation_manager"]
+    for mkey, sd in ck["model"].items():
+        for leaf, v in sd.items():
+            ref = want[f"vlm.{mkey}.{leaf}"]
+            assert v.dtype == ref.dtype and torch.equal(v, ref), (mkey, leaf)       # fp32 masters, bit-exact
+    assert strat.save_checkpoint(tmp_path, 13, 3).name == "step-000013-epoch-03-loss=inf.pt"
+    m2 = MLA.from_pretrained(None, path, "tiny", backbone(), freeze_weights=False, action_dim=7, future_action_window_size=0,
+                             use_diff=True, use_pointcloud=True, use_contrastive=True, **flags, **recipe.GEN_TINY)
+    got = m2.state_dict()
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    assert "generation_manager.image_gen_module" in m2.loaded_module_keys and "llm_backbone" in m2.loaded_module_keys
+    # a checkpoint whose embedders were trained for another action width keeps the fresh initialisation (model_mla.py:400, 417)
+    ck["model"]["proprio_embedder"]["mlp.fc1.weight"] = torch.zeros(recipe.TOKEN_SIZE, 14)
+    ck["model"].pop("projector_3d")
+    torch.save(ck, tmp_path / "other.pt")
+    m3 = MLA.from_pretrained(None, tmp_path / "other.pt", "tiny", backbone(), action_dim=7, future_action_window_size=0, use_diff=True,
+                             use_pointcloud=True, use_contrastive=True, use_generation=False)
+    assert "proprio_embedder" not in m3.loaded_module_keys and "projector_3d" not in m3.loaded_module_keys
+    assert not any(p.requires_grad for p in m3.parameters()) and not m3.vlm.training
