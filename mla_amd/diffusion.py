@@ -1,7 +1,7 @@
 """Diffusion pieces on the MLA training path (reference: models/diffusion/): cosine schedule + q_sample
 (gaussian_diffusion.py:115-140, 166-229), ActionEmbedder / TimestepEmbedder / LabelEmbedder / FinalLayer
 (models.py:28-189; timm 0.9.10 Mlp and RmsNorm restated -- state-dict keys mlp.fc1 / mlp.fc2 / norm_final.weight).
-The DiT / ActionModel / sampling loops are dead code for MLA training (SURVEY header) and are not built.
+The DDIM / DDPM sampling loops serve inference (model_mla.py:592-775); DiT / ActionModel are dead code for MLA and not built.
 """
 from __future__ import annotations
 
@@ -26,17 +26,57 @@ def get_named_beta_schedule(schedule_name: str, num_diffusion_timesteps: int) ->
     return np.array(betas, dtype=np.float64)
 
 
-class GaussianDiffusion:
-    """Training-side subset: float64 tables, q_sample on the GPU."""
+def space_timesteps(num_timesteps: int, section_counts) -> set:
+    """models/diffusion/respace.py:12-66. "ddimN": the first integer stride that yields exactly N steps (N=1 -> {50})."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[len("ddim"):])
+            if want == 1:
+                return {50}
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return set(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    size_per, extra = divmod(num_timesteps, len(section_counts))
+    start, steps = 0, []
+    for i, count in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        frac = 1 if count <= 1 else (size - 1) / (count - 1)
+        cur = 0.0
+        for _ in range(count):
+            steps.append(start + round(cur))
+            cur += frac
+        start += size
+    return set(steps)
 
-    def __init__(self, betas):
+
+class GaussianDiffusion:
+    """Epsilon-prediction, fixed-small-variance Gaussian diffusion (models/diffusion/gaussian_diffusion.py, the configuration
+    create_diffusion builds for MLA: learn_sigma=False, sigma_small=True, predict_xstart=False). float64 tables; q_sample runs
+    a HIP kernel; the sampling loops update [B, T, action_dim] tensors (a few dozen elements) with torch ops between model calls.
+    ``timestep_map`` maps this process's step index to the base process's timestep (respace.py:75-129)."""
+
+    def __init__(self, betas, timestep_map=None, original_num_steps=None):
         betas = np.array(betas, dtype=np.float64)
         self.betas = betas
         self.num_timesteps = int(betas.shape[0])
+        self.timestep_map = list(range(self.num_timesteps)) if timestep_map is None else list(timestep_map)
+        self.original_num_steps = self.num_timesteps if original_num_steps is None else original_num_steps
         alphas = 1.0 - betas
         self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
         self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = (np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+                                               if self.num_timesteps > 1 else np.array([]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
         self._dev_tables = {}
 
     def _tables(self, device):
@@ -53,19 +93,86 @@ class GaussianDiffusion:
         a, b = self._tables(x_start.device)
         return hip.q_sample(x_start.float().contiguous(), noise.float().contiguous(), t.contiguous(), a, b)
 
+    # ------------------------------------------------------------------ sampling (inference side)
+    @staticmethod
+    def _at(table: np.ndarray, t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        """_extract_into_tensor gaussian_diffusion.py:862-875: float64 table -> float32 value per batch element, broadcast."""
+        v = torch.from_numpy(table).to(device=t.device)[t].float()
+        return v.view(-1, *([1] * (like.dim() - 1))).expand(like.shape)
+
+    def _eps(self, model, x, t, model_kwargs):
+        """_WrappedModel.__call__ respace.py:118-129 (maps the step index to the base timestep) + the tuple convention of
+        p_mean_variance gaussian_diffusion.py:279-283 (PrismaticVLM.forward returns (output, noise_pred) in eval mode)."""
+        ts = torch.tensor(self.timestep_map, device=t.device, dtype=t.dtype)[t]
+        out = model(x, ts, **(model_kwargs or {}))
+        if isinstance(out, tuple):
+            out = out[1]
+        return out.float()        # bf16 -> fp32 is exact; the fp32 tables promote the arithmetic in the reference as well
+
+    def _pred_xstart(self, x, t, eps, clip_denoised):
+        px = self._at(self.sqrt_recip_alphas_cumprod, t, x) * x - self._at(self.sqrt_recipm1_alphas_cumprod, t, x) * eps
+        return px.clamp(-1, 1) if clip_denoised else px
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, model_kwargs=None, eta=0.0):
+        """gaussian_diffusion.py:520-568 (Song et al. eq. 12)."""
+        pred_xstart = self._pred_xstart(x, t, self._eps(model, x, t, model_kwargs), clip_denoised)
+        eps = (self._at(self.sqrt_recip_alphas_cumprod, t, x) * x - pred_xstart) / self._at(self.sqrt_recipm1_alphas_cumprod, t, x)
+        ab, ab_prev = self._at(self.alphas_cumprod, t, x), self._at(self.alphas_cumprod_prev, t, x)
+        sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab)) * torch.sqrt(1 - ab / ab_prev)
+        noise = torch.randn_like(x)              # drawn even when eta == 0, like the reference (keeps the RNG stream aligned)
+        mean_pred = pred_xstart * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
+        nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+        return {"sample": mean_pred + nonzero * sigma * noise, "pred_xstart": pred_xstart}
+
+    def p_sample(self, model, x, t, clip_denoised=True, model_kwargs=None):
+        """gaussian_diffusion.py:395-440 with the fixed-small posterior variance."""
+        pred_xstart = self._pred_xstart(x, t, self._eps(model, x, t, model_kwargs), clip_denoised)
+        mean = self._at(self.posterior_mean_coef1, t, x) * pred_xstart + self._at(self.posterior_mean_coef2, t, x) * x
+        logvar = self._at(self.posterior_log_variance_clipped, t, x)
+        noise = torch.randn_like(x)
+        nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+        return {"sample": mean + nonzero * torch.exp(0.5 * logvar) * noise, "pred_xstart": pred_xstart}
+
+    def _loop(self, step, model, shape, noise, device, **kw):
+        assert isinstance(shape, (tuple, list))
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        with torch.no_grad():
+            for i in reversed(range(self.num_timesteps)):
+                t = torch.tensor([i] * shape[0], device=img.device)
+                img = step(model, img, t, **kw)["sample"]
+        return img
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                         device=None, progress=False, eta=0.0):
+        """gaussian_diffusion.py:608-688."""
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn are never passed by MLA (model_mla.py:742-763)")
+        return self._loop(self.ddim_sample, model, shape, noise, device, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta)
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                      device=None, progress=False):
+        """gaussian_diffusion.py:442-518."""
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn are never passed by MLA (model_mla.py:742-763)")
+        return self._loop(self.p_sample, model, shape, noise, device, clip_denoised=clip_denoised, model_kwargs=model_kwargs)
+
 
 def create_diffusion(timestep_respacing="", noise_schedule="squaredcos_cap_v2", diffusion_steps=100, **kwargs):
-    """models/diffusion/__init__.py:12-47 for the training configuration MLA uses (no respacing)."""
-    if timestep_respacing not in (None, "", [diffusion_steps]):
-        raise NotImplementedError("timestep respacing (DDIM sampling) is inference-side (SURVEY 8f rank 2)")
+    """models/diffusion/__init__.py:12-47: SpacedDiffusion over the cosine schedule. Training uses no respacing; inference uses
+    "ddimN" (model_mla.py:1166-1173)."""
     base = GaussianDiffusion(get_named_beta_schedule(noise_schedule, diffusion_steps))
-    # SpacedDiffusion (models/diffusion/respace.py:75-89) re-derives the betas from the base cumulative products even
-    # when every step is kept; the training tables come from those re-derived betas.
-    last, new_betas = 1.0, []
-    for a in base.alphas_cumprod:
-        new_betas.append(1 - a / last)
-        last = a
-    return GaussianDiffusion(np.array(new_betas))
+    if timestep_respacing is None or timestep_respacing == "":
+        timestep_respacing = [diffusion_steps]
+    use = space_timesteps(diffusion_steps, timestep_respacing)
+    # SpacedDiffusion (respace.py:75-89) re-derives the betas from the base cumulative products of the kept steps -- even when
+    # every step is kept; all tables come from those re-derived betas.
+    last, new_betas, tmap = 1.0, [], []
+    for i, a in enumerate(base.alphas_cumprod):
+        if i in use:
+            new_betas.append(1 - a / last)
+            last = a
+            tmap.append(i)
+    return GaussianDiffusion(np.array(new_betas), timestep_map=tmap, original_num_steps=diffusion_steps)
 
 
 class Mlp(nn.Module):

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -176,3 +177,105 @@ class MLA(nn.Module):
         loss_dict["total_loss"] = total
         loss_dict["diff_loss"] = total
         return loss_dict, output
+
+    # ------------------------------------------------------------------------------------------ inference
+    def create_ddim(self, ddim_step=10, noise_schedule="squaredcos_cap_v2", diffusion_steps=100):
+        """model_mla.py:1166-1173."""
+        self.ddim_diffusion = create_diffusion(timestep_respacing="ddim" + str(ddim_step), noise_schedule=noise_schedule,
+                                               diffusion_steps=diffusion_steps, sigma_small=True, learn_sigma=False)
+        return self.ddim_diffusion
+
+    @staticmethod
+    def _check_unnorm_key(norm_stats, unnorm_key):
+        if unnorm_key is None:
+            assert len(norm_stats) == 1, ("Your model was trained on more than one dataset, please pass a `unnorm_key` from the "
+                                          f"following options to choose the statistics used for un-normalizing actions: {norm_stats.keys()}")
+            unnorm_key = next(iter(norm_stats.keys()))
+        assert unnorm_key in norm_stats, f"The `unnorm_key` you chose is not in the set of available dataset statistics, please choose from: {norm_stats.keys()}"
+        return unnorm_key
+
+    def get_action_dim(self, unnorm_key=None):
+        return len(self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]["q01"])
+
+    def get_proprio_stats(self, unnorm_key=None):
+        return self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["proprio"]
+
+    def get_action_stats(self, unnorm_key=None):
+        return self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]
+
+    def normalize_proprio(self, cur_robot_state, unnorm_key=None) -> np.ndarray:
+        """model_mla.py:667-677: q01/q99 -> [-1, 1] on the masked dimensions, clipped."""
+        st = self.get_proprio_stats(unnorm_key)
+        mask = st.get("mask", np.ones_like(st["q01"], dtype=bool))
+        hi, lo = np.array(st["q99"]), np.array(st["q01"])
+        return np.clip(np.where(mask, 2 * (cur_robot_state - lo) / (hi - lo + 1e-8) - 1, cur_robot_state), -1, 1)
+
+    def unnormalize_actions(self, normalized_actions: np.ndarray, unnorm_key=None) -> np.ndarray:
+        """model_mla.py:679-704: clip to [-1, 1], binarise the gripper channel(s) at 0.5, map back through q01/q99."""
+        st = self.get_action_stats(unnorm_key)
+        mask = st.get("mask", np.ones_like(st["q01"], dtype=bool))
+        hi, lo = np.array(st["q99"]), np.array(st["q01"])
+        a = np.clip(normalized_actions, -1, 1)
+        width = a.shape[-1] if a.ndim >= 1 else 0
+        for g in ((6,) if width == 7 else (6, 13) if width == 14 else ()):
+            a[..., g] = np.where(a[..., g] < 0.5, 0, 1)
+        return np.where(mask, 0.5 * (a + 1) * (hi - lo) + lo, a)
+
+    @torch.inference_mode()
+    def predict_action_diff(self, image=None, pointcloud=None, instruction: Optional[str] = None, cur_robot_state=None,
+                            unnorm_key: Optional[str] = None, cfg_scale: float = 0.0, use_ddim: bool = True, num_ddim_steps: int = 8,
+                            action_dim: int = 7, *, input_ids: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+                            camera_name: str = "rlbench_front", **kwargs) -> np.ndarray:
+        """model_mla.py:592-775: 8-step DDIM (eta = 0) over the action chunk with the VLM as the epsilon model, then
+        un-normalisation. The model side is complete; the two data adapters around it are SURVEY 8f rank 4 and not built, so
+        * ``image`` is the already pre-processed frame (float tensor [3|4, 672, 672], CLIP-normalised; a ones mask channel is
+          appended when missing, :657-660) -- not a PIL image;
+        * the prompt arrives tokenised as ``input_ids`` [1, L] (the reference builds it from ``instruction`` with the Llama
+          tokenizer and appends [29871, 32001, 32002, 29871], then drops the last three ids, :629-645, :711-713); pass the ids in
+          either form: if the last id is not 29871 the tail is appended here.
+        ``noise`` optionally fixes the initial sample (the reference draws it with torch.randn, :707). ``camera_name``: the shipped
+        method does not forward it, so the reference's get_camera_params(None) raises (camera.py:54-56); it is an explicit
+        argument here (the evaluation scripts use the RLBench front camera)."""
+        self.vlm.eval()
+        device = next(self.vlm.parameters()).device
+        if input_ids is None:
+            raise NotImplementedError("prompt construction / tokenisation of `instruction` is a data adapter (SURVEY 8f rank 4): "
+                                      "pass input_ids")
+        if cfg_scale > 1.0:
+            raise NotImplementedError("classifier-free guidance (forward_with_cfg) is not used by the shipped evaluation (cfg_scale=0)")
+        if not torch.is_tensor(image):
+            raise NotImplementedError("PIL pre-processing (CLIPImageProcessor) is a data adapter (SURVEY 8f rank 4): pass a tensor")
+        input_ids = input_ids.to(device)
+        if not bool(torch.all(input_ids[:, -1] == 29871)):
+            tail = torch.tensor([[29871, 32001, 32002, 29871]], dtype=torch.long, device=device)
+            input_ids = torch.cat((input_ids, tail), dim=1)[:, :-3]
+        img = image.to(device)
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        if img.shape[1] == 3:
+            img = torch.cat([img, torch.ones_like(img[:, :1])], dim=1)
+        if isinstance(pointcloud, np.ndarray):
+            pointcloud = torch.from_numpy(pointcloud)
+        if pointcloud is not None:
+            pointcloud = pointcloud.to(device).contiguous()
+            if pointcloud.dim() == 2:
+                pointcloud = pointcloud.unsqueeze(0)
+        model_kwargs = {"input_ids": input_ids, "images": img, "point_cloud": pointcloud, "camera_name": camera_name}
+        if cur_robot_state is not None:
+            st = self.normalize_proprio(np.asarray(cur_robot_state), unnorm_key) if self.norm_stats is not None else np.asarray(cur_robot_state)
+            model_kwargs["proprio"] = torch.tensor(st, dtype=torch.float32).reshape(1, 1, -1).to(device)
+        else:
+            raise ValueError("cur_robot_state is required: the proprio token is always spliced in (prismatic.py:985-990)")
+        if noise is None:
+            noise = torch.randn(1, self.future_action_window_size + 1, action_dim, device=device)
+        _ = torch.randint(0, self.diffusion.num_timesteps, (self.future_action_window_size + 1,), device=device)  # drawn, unused (:708)
+        if use_ddim and num_ddim_steps is not None:
+            if self.ddim_diffusion is None:
+                self.create_ddim(ddim_step=num_ddim_steps)
+            samples = self.ddim_diffusion.ddim_sample_loop(self.vlm.forward, noise.shape, noise.to(device).float(), clip_denoised=False,
+                                                           model_kwargs=model_kwargs, progress=False, device=device, eta=0.0)
+        else:
+            samples = self.diffusion.p_sample_loop(self.vlm.forward, noise.shape, noise.to(device).float(), clip_denoised=False,
+                                                   model_kwargs=model_kwargs, progress=False, device=device)
+        normalized = samples[0].float().cpu().numpy()
+        return self.unnormalize_actions(normalized, unnorm_key) if self.norm_stats is not None else normalized

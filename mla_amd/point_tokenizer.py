@@ -72,6 +72,8 @@ class Point_PN_scan(nn.Module):  # Point_PN.py:301-315
 
 def _bn_train(x2d: torch.Tensor, bn: nn.modules.batchnorm._BatchNorm, residual=None, relu=False):
     """BatchNorm with batch statistics over all rows (= over B x spatial), running stats updated like torch does."""
+    if not bn.training:      # inference (vlm.eval(), model_mla.py:619): normalise with the running statistics
+        return hip.bn_apply(x2d, bn.running_mean.float(), bn.running_var.float(), bn.weight, bn.bias, bn.eps, residual=residual, relu=relu)
     mean, var = hip.colstats(x2d)
     y = hip.bn_apply(x2d, mean, var, bn.weight, bn.bias, bn.eps, residual=residual, relu=relu)
     if bn.track_running_stats and bn.running_mean is not None:
@@ -115,7 +117,7 @@ class PointTokenizer(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward(self, p, x=None, **kwargs):
-        if any(q.requires_grad for q in self.parameters()):
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             raise NotImplementedError("trainable point tokenizer (stage 'pretrain') is not built; SFT/post-training freeze it")
         enc = self.patch_embed.EncP
         xyz = p.float().contiguous()                      # pointvit.py:66-74 forces fp32 coordinates

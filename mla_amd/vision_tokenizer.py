@@ -83,7 +83,7 @@ class VisionTokenizer(nn.Module):
 
     def tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
         """[B, 4, 672, 672] (RGB + mask channel, fp32 or bf16) -> [B, 256, C] bf16 tokens (before the projector)."""
-        if any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("trainable vision tokenizer (stage 'pretrain') is not built; SFT/post-training freeze it")
         B, CT, Hi, Wi = pixel_values.shape
         P, cs, C = self.patch_stride, self.conv_stride, self.hidden_size

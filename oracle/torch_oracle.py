@@ -160,6 +160,42 @@ def diffusion_tables(num_steps: int = 100):
     return np.sqrt(ac), np.sqrt(1.0 - ac)
 
 
+def ddim_schedule(n_ddim: int, num_steps: int = 100):
+    """space_timesteps('ddimN') respace.py:33-43 + SpacedDiffusion.__init__ :75-89: kept base timesteps (first integer stride
+    giving exactly N steps) and the cumulative alpha products of the respaced process. Returns (timestep_map, acp, acp_prev)."""
+    keep = None
+    for stride in range(1, num_steps):
+        if len(range(0, num_steps, stride)) == n_ddim:
+            keep = list(range(0, num_steps, stride))
+            break
+    base_ac = np.cumprod(1.0 - cosine_beta_schedule(num_steps), axis=0)
+    last, betas = 1.0, []
+    for i in keep:
+        betas.append(1 - base_ac[i] / last)
+        last = base_ac[i]
+    acp = np.cumprod(1.0 - np.array(betas), axis=0)
+    return keep, acp, np.append(1.0, acp[:-1])
+
+
+def ddim_sample_loop(eps_model, noise: torch.Tensor, n_ddim: int = 8, clip_denoised: bool = False, num_steps: int = 100):
+    """GaussianDiffusion.ddim_sample_loop(eta=0) gaussian_diffusion.py:520-568, 608-688 with the timestep mapping of
+    _WrappedModel respace.py:118-129. eps_model(x, base_timesteps) -> epsilon. Tables float64 -> fp32 per element (:869-881)."""
+    tmap, acp, acp_prev = ddim_schedule(n_ddim, num_steps)
+    x = noise
+    f = lambda a, i: torch.tensor(a[i], dtype=torch.float64).float()  # noqa: E731
+    for i in reversed(range(n_ddim)):
+        t_base = torch.full((x.shape[0],), tmap[i], dtype=torch.long)
+        eps_out = eps_model(x, t_base).float()
+        rec, recm1 = f(np.sqrt(1.0 / acp), i), f(np.sqrt(1.0 / acp - 1), i)
+        x0 = rec * x - recm1 * eps_out
+        if clip_denoised:
+            x0 = x0.clamp(-1, 1)
+        eps = (rec * x - x0) / recm1
+        ab_prev = f(acp_prev, i)
+        x = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev) * eps
+    return x
+
+
 def q_sample(x0: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, num_steps: int = 100) -> torch.Tensor:
     """GaussianDiffusion.q_sample gaussian_diffusion.py:214-229 with _extract_into_tensor :869-881 (tables -> fp32)."""
     sa, s1 = diffusion_tables(num_steps)

@@ -232,3 +232,21 @@ def test_checkpoint_layout_roundtrip(tmp_path):
                              use_pointcloud=True, use_contrastive=True, use_generation=False)
     assert "proprio_embedder" not in m3.loaded_module_keys and "projector_3d" not in m3.loaded_module_keys
     assert not any(p.requires_grad for p in m3.parameters()) and not m3.vlm.training
+
+
+def test_action_unnormalisation_rules():
+    """model_mla.py:667-704: proprio q01/q99 normalisation + clip; action clip, gripper binarisation at 0.5, masked affine map."""
+    import numpy as np
+    from mla_amd.mla import MLA
+    m = MLA.__new__(MLA)
+    m.norm_stats = {"a": {"action": {"q01": [0.0] * 7, "q99": [2.0] * 7, "mask": [True] * 6 + [False]},
+                          "proprio": {"q01": [-1.0] * 7, "q99": [3.0] * 7}}}
+    x = np.array([[-2.0, -1.0, 0.0, 0.5, 1.0, 3.0, 0.4], [0.1] * 6 + [0.6]])
+    got = m.unnormalize_actions(x.copy())
+    assert np.allclose(got[0], [0.0, 0.0, 1.0, 1.5, 2.0, 2.0, 0.0]) and got[1, 6] == 1.0
+    assert np.allclose(m.normalize_proprio(np.array([-1.0, 3.0, 1.0, 5.0, -9.0, 0.0, 2.0])), [-1, 1, 0, 1, -1, -0.5, 0.5], atol=1e-6)
+    m.norm_stats["b"] = m.norm_stats["a"]
+    import pytest
+    with pytest.raises(AssertionError):
+        m.get_action_stats(None)
+    assert m.get_action_dim("b") == 7

@@ -189,3 +189,33 @@ def test_mla_e2e_post_training_matches_reference():
     out["total_loss"].backward()
     norms = np.array([0.0 if sd[n].grad is None else float(sd[n].grad.norm()) for n in names])
     assert np.allclose(norms, gold["A_gradnorms"], rtol=3e-3, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------- inference sampler (8f-2)
+def _toy_eps(x, t, scale=0.3, **kw):
+    return scale * torch.sin(x * 1.7 + t.float().view(-1, 1, 1) * 0.05) + 0.1 * x
+
+
+def test_ddim_sampler_oracle_and_product_match_reference():
+    """DDIM-8 schedule + loop (eta = 0) and the DDPM loop: the oracle restatement AND mla_amd.diffusion (pure host arithmetic
+    around the model call) against vectors captured from the reference's create_diffusion / SpacedDiffusion."""
+    gold = np.load(os.path.join(G, "inference.npz"), allow_pickle=True)
+    tmap, acp, acp_prev = O.ddim_schedule(8)
+    assert tmap == list(gold["ddim8_timestep_map"]) and O.ddim_schedule(10)[0] == list(gold["ddim10_timestep_map"])
+    assert np.array_equal(acp, gold["ddim8_acp"]) and np.array_equal(acp_prev, gold["ddim8_acp_prev"])
+    x0 = torch.from_numpy(gold["toy_noise"])
+    for clip, key in ((False, "toy_ddim8"), (True, "toy_ddim8_clip")):
+        got = O.ddim_sample_loop(_toy_eps, x0, 8, clip_denoised=clip)
+        assert np.allclose(got.numpy(), gold[key], rtol=1e-5, atol=1e-6)
+    from mla_amd.diffusion import create_diffusion
+    d8 = create_diffusion(timestep_respacing="ddim8", diffusion_steps=100)
+    assert d8.timestep_map == tmap and np.array_equal(d8.betas, gold["ddim8_betas"]) and np.array_equal(d8.alphas_cumprod, gold["ddim8_acp"])
+    for clip, key in ((False, "toy_ddim8"), (True, "toy_ddim8_clip")):
+        torch.manual_seed(5)
+        got = d8.ddim_sample_loop(_toy_eps, x0.shape, x0, clip_denoised=clip, model_kwargs={}, device="cpu", eta=0.0)
+        assert np.allclose(got.numpy(), gold[key], rtol=1e-5, atol=1e-6)
+    full = create_diffusion(timestep_respacing="", diffusion_steps=100)
+    assert np.array_equal(full.posterior_variance, gold["post_var"]) and np.array_equal(full.posterior_log_variance_clipped, gold["post_logvar"])
+    torch.manual_seed(5)        # same torch RNG stream as the capture: one randn_like per step
+    got = full.p_sample_loop(_toy_eps, x0.shape, x0, clip_denoised=False, model_kwargs={}, device="cpu")
+    assert np.allclose(got.numpy(), gold["toy_ddpm100"], rtol=1e-4, atol=1e-5)
