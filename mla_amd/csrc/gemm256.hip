@@ -74,7 +74,13 @@ template <int AMODE, int BMODE>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const bool LGKM_BEFORE = false;
   const int GROUP_M = 4;
+#ifdef MLA_GEMM256_ABLATION   // timing experiments only (tools/exp_dbg.py); the runtime flags cost branches in the hot loop
   const bool NO_READ = (p.debug & 4) != 0, NO_STAGE = (p.debug & 8) != 0, NO_BAR2 = (p.debug & 16) != 0, NO_BAR1 = (p.debug & 32) != 0;
+  const int dbg = p.debug;
+#else
+  constexpr bool NO_READ = false, NO_STAGE = false, NO_BAR2 = false, NO_BAR1 = false;
+  constexpr int dbg = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,12 +99,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int nt = p.K / 64;
 
   // ---- staging pointers: [slot][it]; each advances one K-tile per use
-  const size_t stepA = (p.debug & 2) ? 64 : (AMODE == 0 ? 64 : (size_t)64 * p.lda);
-  const size_t stepB = (p.debug & 2) ? 64 : (BMODE == 0 ? 64 : (size_t)64 * p.ldb);
+  const size_t stepA = (dbg & 2) ? 64 : (AMODE == 0 ? 64 : (size_t)64 * p.lda);
+  const size_t stepB = (dbg & 2) ? 64 : (BMODE == 0 ? 64 : (size_t)64 * p.ldb);
   const bf16_t* pA0[2]; const bf16_t* pA1[2]; const bf16_t* pB0[2]; const bf16_t* pB1[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    if (p.debug & 2) {   // EXPERIMENT: k-contiguous address pattern regardless of the mode (wrong data, timing only)
+    if (dbg & 2) {   // EXPERIMENT: k-contiguous address pattern regardless of the mode (wrong data, timing only)
       pA0[it] = stage_src<0, true>(p.A, 4096, 0, 4096, 0, wave * 2 + it, lane);
       pA1[it] = stage_src<0, true>(p.A, 4096, 0, 4096, 1, wave * 2 + it, lane);
       pB0[it] = stage_src<0, false>(p.B, 4096, 0, 4096, 0, wave * 2 + it, lane);
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (AMODE == 0) {
       return *(const bf16x8_t*)(slot + ((offA[0] + rb * 2048) ^ (ks * 64)));
     } else {
-      if (p.debug & 1) return *(const bf16x8_t*)(slot + (((wr * 64 + li) * 128 + ((lg ^ (li & 7)) * 16) + rb * 2048) ^ (ks * 64)));
+      if (dbg & 1) return *(const bf16x8_t*)(slot + (((wr * 64 + li) * 128 + ((lg ^ (li & 7)) * 16) + rb * 2048) ^ (ks * 64)));
       union { bf16x8_t v; short4_t h2[2]; } u;
       u.h2[0] = lds_tr16_b64(slot + offA[rb] + ks * 8192);
       u.h2[1] = lds_tr16_b64(slot + offA[rb] + ks * 8192 + 1024);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     if (BMODE == 0) {
       return *(const bf16x8_t*)(slot + ((offB[0] + cb * 2048) ^ (ks * 64)));
     } else {
-      if (p.debug & 1) return *(const bf16x8_t*)(slot + (((wc * 32 + li) * 128 + ((lg ^ (li & 7)) * 16) + cb * 2048) ^ (ks * 64)));
+      if (dbg & 1) return *(const bf16x8_t*)(slot + (((wc * 32 + li) * 128 + ((lg ^ (li & 7)) * 16) + cb * 2048) ^ (ks * 64)));
       union { bf16x8_t v; short4_t h2[2]; } u;
       u.h2[0] = lds_tr16_b64(slot + offB[cb] + ks * 8192);
       u.h2[1] = lds_tr16_b64(slot + offB[cb] + ks * 8192 + 1024);

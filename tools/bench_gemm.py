@@ -29,7 +29,7 @@ def timeit(fn, iters=10):
     return s.elapsed_time(e) / iters
 
 
-for name, M, N, K, am, bm in shapes:
+for name, M, N, K, am, bm in (shapes if __name__ == "__main__" else []):
     a = torch.randn((M, K) if am == 0 else (K, M), device=dev).to(torch.bfloat16)
     b = torch.randn((N, K) if bm == 0 else (K, N), device=dev).to(torch.bfloat16)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
