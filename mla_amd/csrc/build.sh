@@ -4,12 +4,12 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC ${MLA_EXTRA_FLAGS:-} -Wno-unused-value -Wno-unused-result"
 mkdir -p "$HERE/build"
 pids=()
-for f in api gemm gemm256 transpose elementwise attention loss pointcloud vision gen; do
+for f in api gemm gemm256 gemm_asm transpose elementwise attention loss pointcloud vision gen; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ]; then
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ] || { [ "$f" = gemm_asm ] && [ "$HERE/gemm_asm_8w_loop.inc" -nt "$HERE/build/$f.o" ]; }; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
     pids+=($!)
   fi

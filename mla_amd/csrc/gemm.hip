@@ -35,6 +35,7 @@ struct GemmArgs {
 };
 
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, hipStream_t stream);  // gemm256.hip
+int mla_gemm_asm_dispatch(const void* args, hipStream_t stream);                           // gemm_asm.hip
 
 namespace {
 
@@ -315,6 +316,9 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
   if (bias && (((uintptr_t)bias & 7) != 0)) mfma_ok = false;
   // the 256x256 kernel is used for k-contiguous operands only: its reduction-major (ds_read_b64_tr_b16) path is slower than
   // the 128x128 kernel's (issue-limited at 2 waves/SIMD); force_generic == 3 forces it for tests / experiments
+  // force_generic == 4: the assembly-scheduled 256x256x32 kernel (gemm_asm.hip); K % 128 == 0, N % 4 == 0
+  if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 4)
+    return mla_gemm_asm_dispatch(&p, stream);
   if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 &&
       a_mode == 0 && b_mode == 0 && (force_generic == 0 || force_generic == 3))
     return mla_gemm256_dispatch(&p, a_mode, b_mode, stream);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mla_amd import hip
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 17536
+T = int(sys.argv[1]) if (__name__ == "__main__" and len(sys.argv) > 1) else 17536
 dev = torch.device("cuda:0")
 H, I = 4096, 11008
 shapes = [  # name, M, N, K, a_mode, b_mode -- every large GEMM of a decoder layer in the all-NT formulation

@@ -1,0 +1,345 @@
+#!/usr/bin/env python
+"""Generates the hand-scheduled main loops of the assembly GEMM kernels (mla_amd/csrc/gemm_asm.hip) as inline-asm bodies with
+physical registers:  gemm_asm_8w_loop.inc (+ ablation variants) and gemm_asm_8w_clobbers.inc.
+
+Kernel shape "8w": 256x256 block tile, 8 waves = 2 (M) x 4 (N), 128x64 per wave = 8x4 v_mfma_f32_16x16x32_bf16 fragments in
+a[0:127]; k-step 32; LDS ring of 4 k-step slots of 32 KiB (A 256 rows x 64 B | B 256 rows x 64 B, 16-B chunks XOR-swizzled).
+Per k-step a wave issues 32 MFMAs on fragment buffer P, 12 ds_read_b128 of the next slot into buffer Q and 4
+global_load_lds_dwordx4 (its 32 rows of A and of B, three steps ahead); ONE counted vmcnt wait + ONE barrier per k-step.
+Waves w and w+4 share a SIMD: they run two differently ordered copies of the loop (X: LDS reads first, loads late; Y: loads
+first, reads late) so that one wave's LDS-DMA issue stalls (~60 cycles each) fall into its partner's MFMA stream.
+
+(The 4-wave 128x128-per-wave variant was measured first -- tools/gen_gemm4w.py: MFMA-only 1.80 PFLOP/s, but with ONE wave per
+SIMD every global_load_lds issue stalls the only MFMA issuer: 1.03 PFLOP/s with loads, 1.61 without.)
+
+Register map (per lane), 8w:  a[0:127] accumulators, frag (i, j) at a[(i*4+j)*4 ..+3]
+  buffer b in {0,1}: A frags v[48b + 4i ..], B frags v[48b + 32 + 4j ..]           (v[0:95])
+  v96/v97 A read base (+0 / +65536)   v98/v99 B read base   v100,v101 A load voffsets   v102,v103 B load voffsets
+  s[40:41] A tile base  s[42:43] B tile base  s44 next k byte offset  s45 last valid k byte offset  s46 loop counter
+  s47 this wave's LDS store base  s[48:49]/s[50:51] current A/B source  s52 scratch
+Usage: python tools/gen_gemm_asm.py   (re-run after editing; the .inc files are committed)
+"""
+import os
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mla_amd", "csrc")
+NSLOT, SLOT_BYTES = 4, 32768
+AHEAD = NSLOT - 1
+
+
+class Cfg:
+    def __init__(self, name, fi, fj, nload, flags=()):
+        self.name, self.FI, self.FJ, self.NLOAD, self.flags = name, fi, fj, nload, set(flags)   # NLOAD: glds per operand per step
+        self.fbuf = (fi + fj) * 4                      # VGPRs per fragment buffer
+        self.vbase = 2 * self.fbuf                     # first address register
+        self.nvgpr = self.vbase + 4 + 2 * nload
+        self.nacc = fi * fj * 4
+
+    def acc(self, i, j):
+        b = (i * self.FJ + j) * 4
+        return f"a[{b}:{b + 3}]"
+
+    def afrag(self, buf, i):
+        b = buf * self.fbuf + i * 4
+        return f"v[{b}:{b + 3}]"
+
+    def bfrag(self, buf, j):
+        b = buf * self.fbuf + self.FI * 4 + j * 4
+        return f"v[{b}:{b + 3}]"
+
+    def ds_read(self, dst, is_b, slot, idx):
+        reg = self.vbase + (2 if is_b else 0) + (1 if slot >= 2 else 0)
+        return f"ds_read_b128 {dst}, v{reg} offset:{(slot % 2) * SLOT_BYTES + idx * 1024}"
+
+    def reads_for(self, slot, buf):
+        a = [self.ds_read(self.afrag(buf, x), False, slot, x) for x in range(self.FI)]
+        b = [self.ds_read(self.bfrag(buf, x), True, slot, x) for x in range(self.FJ)]
+        out = []
+        while a or b:                                   # interleave so the operands of the first MFMAs arrive first
+            if a:
+                out.append(a.pop(0))
+            if b:
+                out.append(b.pop(0))
+            if a and len(a) > len(b):
+                out.append(a.pop(0))
+        if "noreads" in self.flags:
+            out = ["s_nop 0"] * len(out)
+        return out
+
+    def load_group(self, slot):
+        ptr = ["s_min_u32 s52, s44, s45", "s_add_u32 s48, s40, s52", "s_addc_u32 s49, s41, 0", "s_add_u32 s50, s42, s52",
+               "s_addc_u32 s51, s43, 0", "s_add_u32 s44, s44, 64"]
+        bundles = [ptr]
+        va, vb = self.vbase + 4, self.vbase + 4 + self.NLOAD
+        for q in range(self.NLOAD):
+            bundles.append([f"s_add_i32 m0, s47, {slot * SLOT_BYTES + q * 1024}", "s_nop 0", f"global_load_lds_dwordx4 v{va + q}, s[48:49]"])
+        for q in range(self.NLOAD):
+            bundles.append([f"s_add_i32 m0, s47, {slot * SLOT_BYTES + 16384 + q * 1024}", "s_nop 0",
+                            f"global_load_lds_dwordx4 v{vb + q}, s[50:51]"])
+        if "noglds" in self.flags:
+            bundles = [bundles[0]] + [b[:2] for b in bundles[1:]]
+        return bundles
+
+    def mfma_order(self):
+        order = []
+        for ib in range(0, self.FI, 2):
+            for jb in range(0, self.FJ, 2):
+                for i in (ib, ib + 1):
+                    for j in (jb, jb + 1):
+                        order.append((i, j))
+        return order
+
+    def step(self, u, sched):
+        cur, nxt = u & 1, (u & 1) ^ 1
+        read_slot, load_slot = (u + 1) % NSLOT, (u + AHEAD) % NSLOT
+        nload = 2 * self.NLOAD
+        lines = [f"; ---- k-step {u} ({sched}): MFMA on buf{cur}, read slot {read_slot} -> buf{nxt}, load slot {load_slot}",
+                 f"s_waitcnt vmcnt({nload * (AHEAD - 2)})", "s_waitcnt lgkmcnt(0)"]
+        if "nobarrier" not in self.flags:
+            lines.append("s_barrier")
+        reads, loads = self.reads_for(read_slot, nxt), self.load_group(load_slot)
+        nm = self.FI * self.FJ
+        aux = {}
+        if sched == "X":            # reads first (one per MFMA), loads in the second half
+            for n, r in enumerate(reads):
+                aux.setdefault(n, []).append(r)
+            first = max(len(reads), nm // 2)
+            aux.setdefault(first, []).extend(loads[0])
+            gap = max(1, (nm - first - 2) // nload)
+            for q in range(nload):
+                aux.setdefault(first + 1 + q * gap, []).extend(loads[1 + q])
+        else:                       # Y: loads first, reads in the second half
+            aux.setdefault(0, []).extend(loads[0])
+            gap = max(1, (nm // 2 - 2) // nload)
+            for q in range(nload):
+                aux.setdefault(1 + q * gap, []).extend(loads[1 + q])
+            first = nm - len(reads) - 8
+            for n, r in enumerate(reads):
+                aux.setdefault(first + n, []).append(r)
+        assert max(aux) < nm, (max(aux), nm)
+        if "noprio" not in self.flags:
+            lines.append("s_setprio 1")
+        for n, (i, j) in enumerate(self.mfma_order()):
+            lines.append(f"v_mfma_f32_16x16x32_bf16 {self.acc(i, j)}, {self.bfrag(cur, j)}, {self.afrag(cur, i)}, {self.acc(i, j)}")
+            lines.extend(aux.get(n, []))
+        if "noprio" not in self.flags:
+            lines.append("s_setprio 0")
+        return lines
+
+    def prologue(self):
+        vb = self.vbase
+        lines = ["; ---- prologue: fixed registers, zero the accumulators, fill the first AHEAD slots, read k-step 0",
+                 "s_mov_b64 s[40:41], %[pA]", "s_mov_b64 s[42:43], %[pB]", "s_mov_b32 s44, 0", "s_mov_b32 s45, %[kmax]",
+                 "s_mov_b32 s46, %[nit]", "s_mov_b32 s47, %[ldsw]",
+                 f"v_mov_b32 v{vb}, %[vA]", f"v_add_u32 v{vb + 1}, 0x10000, v{vb}", f"v_mov_b32 v{vb + 2}, %[vB]",
+                 f"v_add_u32 v{vb + 3}, 0x10000, v{vb + 2}"]
+        for q in range(self.NLOAD):
+            lines.append(f"v_mov_b32 v{vb + 4 + q}, %[oA{q}]")
+            lines.append(f"v_mov_b32 v{vb + 4 + self.NLOAD + q}, %[oB{q}]")
+        for r in range(self.nacc):
+            lines.append(f"v_accvgpr_write_b32 a{r}, 0")
+        for g in range(AHEAD):
+            for b in self.load_group(g):
+                lines.extend(b)
+        lines += [f"s_waitcnt vmcnt({2 * self.NLOAD * (AHEAD - 1)})", "s_barrier"]
+        lines += self.reads_for(0, 0)
+        return lines
+
+    def body(self, two_schedules):
+        out = self.prologue()
+        tail = ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7", "s_nop 7"]
+        if two_schedules:
+            out += ["s_cmp_lg_u32 %[sel], 0", "s_cbranch_scc1 2f", "1:"]
+            for u in range(4):
+                out += self.step(u, "X")
+            out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 1b", "s_branch 3f", "2:"]
+            for u in range(4):
+                out += self.step(u, "Y")
+            out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 2b", "3:"]
+        else:
+            out += ["1:"]
+            for u in range(4):
+                out += self.step(u, "X")
+            out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 1b"]
+        return out + tail
+
+    def emit(self, fname, two_schedules=True):
+        body = self.body(two_schedules)
+        with open(os.path.join(CSRC, fname), "w") as f:
+            f.write("// generated by tools/gen_gemm_asm.py -- do not edit\n")
+            for ln in body:
+                f.write('"' + ln + '\\n"\n')
+        return len(body)
+
+    def emit_clobbers(self, fname, macro):
+        regs = [f"v{i}" for i in range(self.nvgpr)] + [f"a{i}" for i in range(self.nacc)]
+        with open(os.path.join(CSRC, fname), "w") as f:
+            f.write(f"// generated by tools/gen_gemm_asm.py -- do not edit\n#define {macro} \\\n")
+            for k in range(0, len(regs), 16):
+                last = k + 16 >= len(regs)
+                f.write("  " + ", ".join(f'"{r}"' for r in regs[k:k + 16]) + ("\n" if last else ", \\\n"))
+
+
+class CfgK64(Cfg):
+    """Same tile / wave layout, but LDS holds 64-k tiles with 128-B rows (chunk ^= row & 7, the gemm256 layout): every
+    global_load_lds instruction then fetches 8 full 128-B lines instead of 16 half lines. Ring of two 64 KiB tile sets
+    (A 256 x 128 B | B 256 x 128 B); ONE barrier per 64 k.
+      step (t, ks0): lgkmcnt(0);                     MFMA buf0; read (t, ks1) -> buf1
+      step (t, ks1): vmcnt(0) lgkmcnt(0) s_barrier;  MFMA buf1; load tile t+2 -> set t&1; read (t+1, ks0) -> buf0 (set (t+1)&1)
+    address registers: vbase + 2*ks + set for A, vbase + 4 + 2*ks + set for B; voffsets behind them."""
+
+    def __init__(self, name, fi, fj, nload, flags=()):
+        super().__init__(name, fi, fj, nload, flags)
+        self.nvgpr = self.vbase + 8 + 2 * nload
+
+    def ds_read(self, dst, is_b, tset, ks, idx):
+        reg = self.vbase + (4 if is_b else 0) + 2 * ks + tset
+        return f"ds_read_b128 {dst}, v{reg} offset:{idx * 2048}"
+
+    def reads_for(self, tset, ks, buf):
+        a = [self.ds_read(self.afrag(buf, x), False, tset, ks, x) for x in range(self.FI)]
+        b = [self.ds_read(self.bfrag(buf, x), True, tset, ks, x) for x in range(self.FJ)]
+        out = []
+        while a or b:
+            if a:
+                out.append(a.pop(0))
+            if b:
+                out.append(b.pop(0))
+            if a and len(a) > len(b):
+                out.append(a.pop(0))
+        if "noreads" in self.flags:
+            out = ["s_nop 0"] * len(out)
+        return out
+
+    def load_group(self, tset):
+        ptr = ["s_min_u32 s52, s44, s45", "s_add_u32 s48, s40, s52", "s_addc_u32 s49, s41, 0", "s_add_u32 s50, s42, s52",
+               "s_addc_u32 s51, s43, 0", "s_add_u32 s44, s44, 128"]
+        bundles = [ptr]
+        va, vb = self.vbase + 8, self.vbase + 8 + self.NLOAD
+        for q in range(self.NLOAD):
+            bundles.append([f"s_add_i32 m0, s47, {tset * 65536 + q * 1024}", "s_nop 0", f"global_load_lds_dwordx4 v{va + q}, s[48:49]"])
+        for q in range(self.NLOAD):
+            bundles.append([f"s_add_i32 m0, s47, {tset * 65536 + 32768 + q * 1024}", "s_nop 0",
+                            f"global_load_lds_dwordx4 v{vb + q}, s[50:51]"])
+        if "noglds" in self.flags:
+            bundles = [bundles[0]] + [b[:2] for b in bundles[1:]]
+        if "vgprload" in self.flags:      # timing only: plain loads into scratch VGPRs instead of LDS-DMA (no LDS write at all)
+            nb = [bundles[0]]
+            for k, b in enumerate(bundles[1:]):
+                voff, base = b[2].split()[1].rstrip(","), b[2].split()[2]
+                nb.append([f"global_load_dwordx4 v[{self.nvgpr}:{self.nvgpr + 3}], {voff}, {base}"])
+            bundles = nb
+        if "vgprload_w" in self.flags:    # timing only: plain loads + a ds_write_b128 of (stale) registers per load
+            nb = [bundles[0]]
+            for k, b in enumerate(bundles[1:]):
+                voff, base = b[2].split()[1].rstrip(","), b[2].split()[2]
+                r = self.nvgpr
+                nb.append([f"global_load_dwordx4 v[{r}:{r + 3}], {voff}, {base}", f"ds_write_b128 v{self.vbase + 8}, v[0:3] offset:{k * 1024}"])
+            bundles = nb
+        return bundles
+
+    def mfmas(self, cur, aux):
+        lines = []
+        if "noprio" not in self.flags:
+            lines.append("s_setprio 1")
+        for n, (i, j) in enumerate(self.mfma_order()):
+            lines.append(f"v_mfma_f32_16x16x32_bf16 {self.acc(i, j)}, {self.bfrag(cur, j)}, {self.afrag(cur, i)}, {self.acc(i, j)}")
+            lines.extend(aux.get(n, []))
+        if "noprio" not in self.flags:
+            lines.append("s_setprio 0")
+        return lines
+
+    def tile(self, tset):
+        nm = self.FI * self.FJ
+        nload = 2 * self.NLOAD
+        # ---- ks0
+        lines = [f"; ---- tile set {tset}, k-step 0: MFMA buf0, read ks1 -> buf1", "s_waitcnt lgkmcnt(0)"]
+        aux = {}
+        for n, r in enumerate(self.reads_for(tset, 1, 1)):
+            aux.setdefault(n, []).append(r)
+        lines += self.mfmas(0, aux)
+        # ---- ks1
+        lines += [f"; ---- tile set {tset}, k-step 1: MFMA buf1, load tile t+2 -> set {tset}, read next tile ks0 -> buf0",
+                  "s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)"]
+        if "nobarrier" not in self.flags:
+            lines.append("s_barrier")
+        aux = {}
+        loads = self.load_group(tset)
+        reads = self.reads_for(tset ^ 1, 0, 0)
+        if "novmwait" in self.flags:      # timing only: never wait for the loads
+            lines = [ln for ln in lines if ln != "s_waitcnt vmcnt(0)"]
+        if "midbarrier" in self.flags:
+            # top-of-step barrier only orders "tile t fully read" -> loads of t+2; the landing of tile t+1 is awaited mid-step
+            lines = [ln for ln in lines if ln != "s_waitcnt vmcnt(0)"]
+            aux.setdefault(0, []).extend(loads[0])
+            for q in range(nload):
+                aux.setdefault(1 + q * 2, []).extend(loads[1 + q])
+            mid = 2 * nload + 1
+            aux.setdefault(mid, []).extend([f"s_waitcnt vmcnt({nload})"] + ([] if "nobarrier" in self.flags else ["s_barrier"]))
+            for n, r in enumerate(reads):
+                aux.setdefault(mid + 1 + n, []).append(r)
+        elif "loadsfirst" in self.flags:
+            aux.setdefault(0, []).extend(loads[0])
+            for q in range(nload):
+                aux.setdefault(1 + q * 2, []).extend(loads[1 + q])
+            first = nm - len(reads) - 2
+            for n, r in enumerate(reads):
+                aux.setdefault(first + n, []).append(r)
+        else:
+            for n, r in enumerate(reads):
+                aux.setdefault(n, []).append(r)
+            first = len(reads)
+            aux.setdefault(first, []).extend(loads[0])
+            gap = max(1, (nm - first - 2) // nload)
+            for q in range(nload):
+                aux.setdefault(first + 1 + q * gap, []).extend(loads[1 + q])
+        assert max(aux) < nm, (max(aux), nm)
+        lines += self.mfmas(1, aux)
+        return lines
+
+    def prologue(self):
+        vb = self.vbase
+        lines = ["; ---- prologue", "s_mov_b64 s[40:41], %[pA]", "s_mov_b64 s[42:43], %[pB]", "s_mov_b32 s44, 0", "s_mov_b32 s45, %[kmax]",
+                 "s_mov_b32 s46, %[nit]", "s_mov_b32 s47, %[ldsw]",
+                 f"v_mov_b32 v{vb}, %[vA0]", f"v_add_u32 v{vb + 1}, 0x10000, v{vb}", f"v_xor_b32 v{vb + 2}, 64, v{vb}",
+                 f"v_add_u32 v{vb + 3}, 0x10000, v{vb + 2}",
+                 f"v_mov_b32 v{vb + 4}, %[vB0]", f"v_add_u32 v{vb + 5}, 0x10000, v{vb + 4}", f"v_xor_b32 v{vb + 6}, 64, v{vb + 4}",
+                 f"v_add_u32 v{vb + 7}, 0x10000, v{vb + 6}"]
+        # load voffsets: row q*8 further down = + q * (8 rows * ld * 2 B), clamped to the last valid row of the operand
+        va, vbb = vb + 8, vb + 8 + self.NLOAD
+        lines += [f"v_mov_b32 v{va}, %[oA0]", f"v_mov_b32 v{vbb}, %[oB0]"]
+        for q in range(1, self.NLOAD):
+            lines += [f"v_add_u32 v{va + q}, %[sA8], v{va + q - 1}", f"v_add_u32 v{vbb + q}, %[sB8], v{vbb + q - 1}"]
+        for q in range(self.NLOAD):
+            lines += [f"v_min_u32 v{va + q}, v{va + q}, %[oAmax]", f"v_min_u32 v{vbb + q}, v{vbb + q}, %[oBmax]"]
+        for r in range(self.nacc):
+            lines.append(f"v_accvgpr_write_b32 a{r}, 0")
+        for g in range(2):
+            for b in self.load_group(g):
+                lines.extend(b)
+        lines += [f"s_waitcnt vmcnt({2 * self.NLOAD})", "s_barrier"]
+        lines += self.reads_for(0, 0, 0)
+        return lines
+
+    def body(self, two_schedules=False):
+        out = self.prologue() + ["1:"] + self.tile(0) + self.tile(1)
+        out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 1b"]
+        return out + ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7", "s_nop 7"]
+
+
+VARIANTS = {1: {"noglds"}, 2: {"noreads"}, 3: {"noglds", "noreads"}, 4: {"nobarrier"}, 5: {"noprio"}, 6: {"noglds", "noreads", "nobarrier"}}
+
+
+def main():
+    c = CfgK64("8w", 8, 4, 4, {"loadsfirst"})
+    n = c.emit("gemm_asm_8w_loop.inc")
+    c.emit_clobbers("gemm_asm_8w_clobbers.inc", "G8W_CLOBBERS")
+    print(f"8w/k64: {n} lines, {c.nvgpr} VGPRs + {c.nacc} AGPRs")
+    for v, fl in VARIANTS.items():
+        CfgK64("8w", 8, 4, 4, fl | {"loadsfirst"}).emit(f"gemm_asm_8w_loop_v{v}.inc")
+    CfgK64("8w", 8, 4, 4).emit("gemm_asm_8w_loop_v7.inc")
+    CfgK64("8w", 8, 4, 4, {"loadsfirst", "novmwait"}).emit("gemm_asm_8w_loop_v8.inc")
+    CfgK64("8w", 8, 4, 4, {"loadsfirst", "novmwait", "nobarrier"}).emit("gemm_asm_8w_loop_v9.inc")
+
+
+if __name__ == "__main__":
+    main()
