@@ -18,16 +18,16 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 #define MLA_LDS_AS __attribute__((address_space(3)))
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16 cast)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// float -> bfloat16, round-to-nearest-even (matches torch's cast): gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32, two values per instruction) -- the integer emulation costs ~6 VALU instructions per value, which made the
+// attention kernels VALU-bound (687 VALU per 64 MFMAs in the forward loop).
+typedef __attribute__((ext_vector_type(2))) float mla_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 mla_bf16x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const mla_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mla_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, f) & 0xffffu); }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
