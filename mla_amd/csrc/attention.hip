@@ -47,6 +47,22 @@ __device__ __forceinline__ void stage_rows64(const bf16_t* __restrict__ base, lo
   }
 }
 
+// Same staging with the per-lane source pointers of tile 0 precomputed (no row clamp): for tiles that lie fully inside the
+// sequence the address is just ptr + tile * 64 * ld -- keeps ~40 integer VALU instructions per tile out of the main loops.
+template <int SW>
+__device__ __forceinline__ void stage_offs(long long ld, int wave, int lane, unsigned* off) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int p = (wave * 4 + it) * 64 + lane;
+    const int row = p >> 4, cp = p & 15;
+    off[it] = (unsigned)row * (unsigned)ld + (unsigned)(swz<SW>(row, cp) * 8);     // elements; < 64 * ld
+  }
+}
+__device__ __forceinline__ void stage_fast(const bf16_t* __restrict__ tile_base, const unsigned* off, char* tile, int wave) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) glds16(tile_base + off[it], tile + (wave * 4 + it) * 1024);
+}
+
 // A/B fragment of 16 tile rows (rb) x 32 d (ks): lane (i = lane&15 -> row, g = lane>>4 -> d group of 8)
 template <int SW>
 __device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int rb, int ks, int lane) {
@@ -169,6 +185,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
   const float sc2 = p.scale * LOG2E;
 
+  unsigned koff[4], voff[4];
+  stage_offs<0>(p.ld, wave, lane, koff);
+  stage_offs<1>(p.ld, wave, lane, voff);
   stage_rows64<0>(kb_, p.ld, 0, p.S, smem, wave, lane);
   stage_rows64<1>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -178,8 +197,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const char* vt_ = kt_ + TILE_BYTES;
     if (kt + 1 < nkt) {
       char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-      stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
-      stage_rows64<1>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+      if ((kt + 2) * 64 <= p.S) {
+        stage_fast(kb_ + (long long)(kt + 1) * 64 * p.ld, koff, nx, wave);
+        stage_fast(vb_ + (long long)(kt + 1) * 64 * p.ld, voff, nx + TILE_BYTES, wave);
+      } else {
+        stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
+        stage_rows64<1>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+      }
     }
     f32x4_t st[RB][4];
 #pragma unroll
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const char* vt_ = kt_ + TILE_BYTES;
     if (kt + 1 < nkt) {
       char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-      stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
+      stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);       // (register budget: no precomputed offsets here)
       stage_rows64<0>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
     }
     bf16x8_t ds[RB][2];
@@ -441,6 +465,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   int qend = seqlen < p.S ? seqlen : p.S;
   const int nqt_end = (qend + 63) / 64;
   const int qt0 = kb;
+  unsigned qoff[4], dooff[4];
+  stage_offs<0>(p.ld, wave, lane, qoff);
+  stage_offs<0>(p.ld_o, wave, lane, dooff);
   if (qt0 < nqt_end) {
     stage_rows64<0>(qb_, p.ld, qt0 * 64, p.S, smem, wave, lane);
     stage_rows64<0>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
@@ -460,8 +487,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const char* dot_ = qt_ + TILE_BYTES;
     if (qt + 1 < nqt_end) {
       char* nx = smem + (bufi ^ 1) * 2 * TILE_BYTES;
-      stage_rows64<0>(qb_, p.ld, (qt + 1) * 64, p.S, nx, wave, lane);
-      stage_rows64<0>(dob_, p.ld_o, (qt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+      if ((qt + 2) * 64 <= p.S) {
+        stage_fast(qb_ + (long long)(qt + 1) * 64 * p.ld, qoff, nx, wave);
+        stage_fast(dob_ + (long long)(qt + 1) * 64 * p.ld_o, dooff, nx + TILE_BYTES, wave);
+      } else {
+        stage_rows64<0>(qb_, p.ld, (qt + 1) * 64, p.S, nx, wave, lane);
+        stage_rows64<0>(dob_, p.ld_o, (qt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+      }
     }
     f32x4_t s[4], dp[4];
 #pragma unroll
