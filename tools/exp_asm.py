@@ -22,7 +22,7 @@ for (M, N, K) in ((256, 256, 128), (512, 768, 256), (1000, 520, 1024), (264, 409
     print(f"check M={M} N={N} K={K}: rel err fp32-out {err:.2e}  bf16+bias+res {err2:.2e}", flush=True)
 T = 17536
 if len(sys.argv) > 1 and sys.argv[1] == "ablate":
-    names = {0: "full", 1: "no glds", 2: "no ds_read", 3: "no glds, no ds_read", 4: "no barrier", 5: "no setprio", 6: "MFMA only (no glds/reads/barrier)", 7: "reads before loads in k-step 1", 8: "v7 never waiting for loads (timing only)", 9: "v7 no load wait, no barrier (timing only)"}
+    names = {0: "full", 1: "no glds", 2: "no ds_read", 3: "no glds, no ds_read", 4: "no barrier", 5: "no setprio", 6: "MFMA only (no glds/reads/barrier)", 7: "reads before loads in k-step 1", 8: "with L2 prefetch 2 tiles ahead", 9: "never waiting for loads (timing only)"}
     for (M, N, K) in ((4096, 4096, T), (T, 12288, 4096)):
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         b = torch.randn(N, K, device=dev).to(torch.bfloat16)

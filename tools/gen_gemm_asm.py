@@ -171,7 +171,7 @@ class Cfg:
         return len(body)
 
     def emit_clobbers(self, fname, macro):
-        regs = [f"v{i}" for i in range(self.nvgpr)] + [f"a{i}" for i in range(self.nacc)]
+        regs = [f"v{i}" for i in range(self.nvgpr + (3 if "l2pf" in self.flags else 0))] + [f"a{i}" for i in range(self.nacc)]
         with open(os.path.join(CSRC, fname), "w") as f:
             f.write(f"// generated by tools/gen_gemm_asm.py -- do not edit\n#define {macro} \\\n")
             for k in range(0, len(regs), 16):
@@ -187,9 +187,12 @@ class CfgK64(Cfg):
       step (t, ks1): vmcnt(0) lgkmcnt(0) s_barrier;  MFMA buf1; load tile t+2 -> set t&1; read (t+1, ks0) -> buf0 (set (t+1)&1)
     address registers: vbase + 2*ks + set for A, vbase + 4 + 2*ks + set for B; voffsets behind them."""
 
+    PFD = 2
+
     def __init__(self, name, fi, fj, nload, flags=()):
         super().__init__(name, fi, fj, nload, flags)
         self.nvgpr = self.vbase + 8 + 2 * nload
+        self.npf = 2 if "l2pf" in self.flags else 0            # extra VMEM instructions per tile (vmcnt bookkeeping)
 
     def ds_read(self, dst, is_b, tset, ks, idx):
         reg = self.vbase + (4 if is_b else 0) + 2 * ks + tset
@@ -220,6 +223,15 @@ class CfgK64(Cfg):
         for q in range(self.NLOAD):
             bundles.append([f"s_add_i32 m0, s47, {tset * 65536 + 32768 + q * 1024}", "s_nop 0",
                             f"global_load_lds_dwordx4 v{vb + q}, s[50:51]"])
+        if "l2pf" in self.flags:
+            # L2 prefetch: one dword per 128-B line of the rows this wave stages, PFD tiles beyond the tile being loaded, so the
+            # LDS-DMA loads issued later hit L2 instead of exposing HBM latency (the ring only allows one tile of distance)
+            pf = self.nvgpr
+            bundles[0] = bundles[0][:-1] + [f"s_add_u32 s53, s44, {self.PFD * 128}", "s_min_u32 s53, s53, s45",
+                                            "s_add_u32 s54, s40, s53", "s_addc_u32 s55, s41, 0", "s_add_u32 s56, s42, s53",
+                                            "s_addc_u32 s57, s43, 0"] + bundles[0][-1:]
+            bundles.append([f"global_load_dword v{pf + 2}, v{pf}, s[54:55]"])
+            bundles.append([f"global_load_dword v{pf + 2}, v{pf + 1}, s[56:57]"])
         if "noglds" in self.flags:
             bundles = [bundles[0]] + [b[:2] for b in bundles[1:]]
         if "vgprload" in self.flags:      # timing only: plain loads into scratch VGPRs instead of LDS-DMA (no LDS write at all)
@@ -259,14 +271,14 @@ class CfgK64(Cfg):
         lines += self.mfmas(0, aux)
         # ---- ks1
         lines += [f"; ---- tile set {tset}, k-step 1: MFMA buf1, load tile t+2 -> set {tset}, read next tile ks0 -> buf0",
-                  "s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)"]
+                  f"s_waitcnt vmcnt({self.npf})", "s_waitcnt lgkmcnt(0)"]
         if "nobarrier" not in self.flags:
             lines.append("s_barrier")
         aux = {}
         loads = self.load_group(tset)
         reads = self.reads_for(tset ^ 1, 0, 0)
         if "novmwait" in self.flags:      # timing only: never wait for the loads
-            lines = [ln for ln in lines if ln != "s_waitcnt vmcnt(0)"]
+            lines = [ln for ln in lines if not ln.startswith("s_waitcnt vmcnt")]
         if "midbarrier" in self.flags:
             # top-of-step barrier only orders "tile t fully read" -> loads of t+2; the landing of tile t+1 is awaited mid-step
             lines = [ln for ln in lines if ln != "s_waitcnt vmcnt(0)"]
@@ -279,7 +291,7 @@ class CfgK64(Cfg):
                 aux.setdefault(mid + 1 + n, []).append(r)
         elif "loadsfirst" in self.flags:
             aux.setdefault(0, []).extend(loads[0])
-            for q in range(nload):
+            for q in range(len(loads) - 1):
                 aux.setdefault(1 + q * 2, []).extend(loads[1 + q])
             first = nm - len(reads) - 2
             for n, r in enumerate(reads):
@@ -311,12 +323,14 @@ class CfgK64(Cfg):
             lines += [f"v_add_u32 v{va + q}, %[sA8], v{va + q - 1}", f"v_add_u32 v{vbb + q}, %[sB8], v{vbb + q - 1}"]
         for q in range(self.NLOAD):
             lines += [f"v_min_u32 v{va + q}, v{va + q}, %[oAmax]", f"v_min_u32 v{vbb + q}, v{vbb + q}, %[oBmax]"]
+        if "l2pf" in self.flags:
+            lines += [f"v_mov_b32 v{self.nvgpr}, %[pfA]", f"v_mov_b32 v{self.nvgpr + 1}, %[pfB]"]
         for r in range(self.nacc):
             lines.append(f"v_accvgpr_write_b32 a{r}, 0")
         for g in range(2):
             for b in self.load_group(g):
                 lines.extend(b)
-        lines += [f"s_waitcnt vmcnt({2 * self.NLOAD})", "s_barrier"]
+        lines += [f"s_waitcnt vmcnt({2 * self.NLOAD + 2 * self.npf})", "s_barrier"]
         lines += self.reads_for(0, 0, 0)
         return lines
 
@@ -336,9 +350,11 @@ def main():
     print(f"8w/k64: {n} lines, {c.nvgpr} VGPRs + {c.nacc} AGPRs")
     for v, fl in VARIANTS.items():
         CfgK64("8w", 8, 4, 4, fl | {"loadsfirst"}).emit(f"gemm_asm_8w_loop_v{v}.inc")
-    CfgK64("8w", 8, 4, 4).emit("gemm_asm_8w_loop_v7.inc")
-    CfgK64("8w", 8, 4, 4, {"loadsfirst", "novmwait"}).emit("gemm_asm_8w_loop_v8.inc")
-    CfgK64("8w", 8, 4, 4, {"loadsfirst", "novmwait", "nobarrier"}).emit("gemm_asm_8w_loop_v9.inc")
+    CfgK64("8w", 8, 4, 4).emit("gemm_asm_8w_loop_v7.inc")                                     # reads before loads in k-step 1
+    # L2 prefetch (one dword per 128-B line, PFD tiles ahead): measured 1.41 -> 1.05-1.23 PFLOP/s at every distance -- a scattered
+    # dword load costs as many cache-line requests as eight LDS-DMA loads; kept as a documented negative result
+    CfgK64("8w", 8, 4, 4, {"loadsfirst", "l2pf"}).emit("gemm_asm_8w_loop_v8.inc")
+    CfgK64("8w", 8, 4, 4, {"loadsfirst", "novmwait"}).emit("gemm_asm_8w_loop_v9.inc")        # timing only: never wait for loads
 
 
 if __name__ == "__main__":
