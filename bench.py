@@ -34,7 +34,7 @@ def model_flops_per_sample(S, H=4096, I=11008, L=32, V=32064, R=R_DIFF):
     return dec, dec + lm
 
 
-def build(device, save_level, tiny=False, use_pointcloud=True, generation=False):
+def build(device, save_level, tiny=False, use_pointcloud=True, generation=False, stage=None):
     from mla_amd.backbones import LLaMa2LLMBackbone
     from mla_amd.llama import LlamaConfig
     from mla_amd.mla import MLA
@@ -53,7 +53,7 @@ def build(device, save_level, tiny=False, use_pointcloud=True, generation=False)
                   use_pointcloud=use_pointcloud, use_contrastive=use_pointcloud, **gen)
         # <BOD>, <EOD> added by scripts/train.py:132-155 stay inside the 32064 rows; give final_layer a non-zero read-out
         torch.nn.init.normal_(mla.vlm.final_layer.mlp.fc2.weight, std=0.02)
-    mla.freeze_backbones("post-training" if generation else "finetune")
+    mla.freeze_backbones(stage or ("post-training" if generation else "finetune"))
     return mla
 
 
@@ -130,9 +130,10 @@ def main():
     if args.config == 4:
         args.save_level = 0                    # the config names activation checkpointing (4x the tokens of config 1)
     torch.manual_seed(42)                      # identical initial weights on every rank (scripts/train.py:76 seed)
-    mla = build(device, args.save_level, args.tiny, use_pointcloud=pc_on, generation=gen_on)
+    stage = "post-training" if gen_on else ("pretrain" if args.config == 4 else "finetune")   # config 4: the vision tokenizer trains too
+    mla = build(device, args.save_level, args.tiny, use_pointcloud=pc_on, generation=gen_on, stage=stage)
     torch.manual_seed(42 + rank)               # rank-local noise / timesteps / FPS starts, like the reference's per-rank RNG
-    strat = FSDPStrategy(mla, local_rank, stage="post-training" if gen_on else "finetune", global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
+    strat = FSDPStrategy(mla, local_rank, stage=stage, global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
                          learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
                          enable_gradient_checkpointing=False, repeated_diffusion_steps=R_DIFF)
     strat.run_setup(n_train_examples=10_000)
@@ -182,7 +183,7 @@ def main():
                                        "1024 points + 32 text tokens, per-GPU batch 8 x 4 diffusion repeats = 32 x 548 tokens" if args.config == 1 else
                                        "BASELINE.json configs[3]: MLA post-training = configs[1] + image (128 queries, 2+3 decoder layers, d=4096) and "
                                        "point-cloud (4 blocks, d=1024) generation heads, use_roi=False, dropout 0.1 active; 32 x 548 tokens" if args.config == 3 else
-                                       "BASELINE.json configs[4]: MLA pretrain shape, use_pointcloud=False, S=2048, activation checkpointing, "
+                                       "BASELINE.json configs[4]: MLA stage 'pretrain' (vision tokenizer + projector + LLM trainable), use_pointcloud=False, S=2048, activation checkpointing, "
                                        "per-GPU batch 8 x 4 diffusion repeats = 32 x 2048 tokens")
                                       + (" [TINY SMOKE MODEL - not the benchmark]" if args.tiny else ""),
                           "model": "mla-llama2-7b" if not args.tiny else "tiny", "global_batch": B_PER_GPU * world, "seq_len": S,

@@ -138,6 +138,11 @@ int mla_im2col_patch(const void* pix, int pix_fp32, void* rows, int B, int CT, i
 int mla_avgpool_tokens(const void* x, void* y, int B, int gh, int gw, int C, int cs, mla_stream_t stream);
 int mla_local_attn(const void* q, const void* kv, void* out, int B, int gh, int gw, int C, int cs, int heads, float scale,
                    mla_stream_t stream);
+/* backward of the two (stage "pretrain": models/vlm/prismatic.py:415-447 trains vision_tower_2d): window-attention gradients
+ * (dq [windows, C], dkv [tokens, 2C]; every k/v row belongs to one window) and avg-pool backward fused with a second addend */
+int mla_local_attn_bwd(const void* q, const void* kv, const void* dout, void* dq, void* dkv, int B, int gh, int gw, int C, int cs,
+                       int heads, float scale, mla_stream_t stream);
+int mla_avgpool_tokens_bwd(const void* dy, const void* other, void* dx, int B, int gh, int gw, int C, int cs, mla_stream_t stream);
 
 /* ---- batched GEMM (two-level batch: outer = sample, inner = head) for the generation heads' nn.MultiheadAttention products
  * (models/mla/generation/models.py:44,103-122: QK^T, PV and their gradients). Same operand modes as mla_gemm_bf16; batch

@@ -1,4 +1,5 @@
-// Encoder-free vision tokenizer kernels (forward only: vision_tower_2d is frozen on the SFT / post-training path).
+// Encoder-free vision tokenizer kernels: forward (vision_tower_2d is frozen on the SFT / post-training path) and the two
+// backward kernels that stage 'pretrain' needs (models/vlm/prismatic.py:415-447 trains the tower there).
 // Reference: models/mla/image/vision_tokenizer.py -- Conv2d(3->C, k = s = 14) patchify :110,122 (here: im2col +
 // the MFMA GEMM), LocalAttention :14-47 (3x3 window attention, scale = C^-0.5).  The reference loops over samples in
 // Python with a host sync each; here the whole batch is one launch per stage.
@@ -88,6 +89,74 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const bf16_t* __restric
   for (int t = 0; t < per; ++t) out[(size_t)win * C + c0 + t] = f2bf(acc[t]);
 }
 
+// backward of the window attention: one block per window (each k/v row belongs to exactly one window -> plain stores).
+//   p = softmax_n(scale * q.k_n);  dP_n = dout.v_n;  dS_n = p_n (dP_n - sum_m p_m dP_m)
+//   dq = scale * sum_n dS_n k_n;   dk_n = scale * dS_n q;   dv_n = p_n dout
+__global__ __launch_bounds__(256) void local_attn_bwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                             const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq,
+                                                             bf16_t* __restrict__ dkv, int B, int gh, int gw, int C, int cs, float scale) {
+  const int oh = gh / cs, ow = gw / cs;
+  const int win = blockIdx.x;
+  const int j = win % ow, i = (win / ow) % oh, b = win / (ow * oh);
+  const int head = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int hd = C / 8, per = hd / 32;
+  const int c0 = head * hd + l * per;
+  const int N = cs * cs;
+  float qv[8], go[8];
+  for (int t = 0; t < per; ++t) {
+    qv[t] = bf2f(q[(size_t)win * C + c0 + t]);
+    go[t] = bf2f(dout[(size_t)win * C + c0 + t]);
+  }
+  float sc[16], dp[16];
+  float m = -INFINITY;
+  for (int n = 0; n < N; ++n) {
+    const size_t row = ((size_t)b * gh + i * cs + n / cs) * gw + j * cs + n % cs;
+    float s = 0.f, d = 0.f;
+    for (int t = 0; t < per; ++t) {
+      s += qv[t] * scale * bf2f(kv[row * 2 * C + c0 + t]);
+      d += go[t] * bf2f(kv[row * 2 * C + C + c0 + t]);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); d += __shfl_xor(d, o, 64); }
+    sc[n] = s; dp[n] = d;
+    m = fmaxf(m, s);
+  }
+  float den = 0.f;
+  for (int n = 0; n < N; ++n) { sc[n] = __expf(sc[n] - m); den += sc[n]; }
+  const float inv = 1.f / den;
+  float dot = 0.f;
+  for (int n = 0; n < N; ++n) { sc[n] *= inv; dot += sc[n] * dp[n]; }
+  float dqa[8];
+  for (int t = 0; t < per; ++t) dqa[t] = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const size_t row = ((size_t)b * gh + i * cs + n / cs) * gw + j * cs + n % cs;
+    const float ds = sc[n] * (dp[n] - dot) * scale;
+    for (int t = 0; t < per; ++t) {
+      dqa[t] += ds * bf2f(kv[row * 2 * C + c0 + t]);
+      dkv[row * 2 * C + c0 + t] = f2bf(ds * qv[t]);
+      dkv[row * 2 * C + C + c0 + t] = f2bf(sc[n] * go[t]);
+    }
+  }
+  for (int t = 0; t < per; ++t) dq[(size_t)win * C + c0 + t] = f2bf(dqa[t]);
+}
+
+// dx[b, y, x, c] = dpooled[b, y/cs, x/cs, c] / cs^2 (+ other[b, y, x, c]): backward of avgpool_tokens fused with the sum of the
+// token gradient that arrives through the k/v LayerNorm
+__global__ __launch_bounds__(256) void avgpool_tokens_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ other,
+                                                                 bf16_t* __restrict__ dx, int B, int gh, int gw, int C, int cs) {
+  const int oh = gh / cs, ow = gw / cs;
+  const long long total = (long long)B * gh * gw * C;
+  const float inv = 1.f / (float)(cs * cs);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    long long r = e / C;
+    const int x = (int)(r % gw), y = (int)((r / gw) % gh), b = (int)(r / ((long long)gw * gh));
+    float v = bf2f(dy[(((size_t)b * oh + y / cs) * ow + x / cs) * C + c]) * inv;
+    if (other) v += bf2f(other[e]);
+    dx[e] = f2bf(v);
+  }
+}
+
 inline int gridn(long long items, int cap = 16384) {
   long long b = (items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -120,5 +189,22 @@ extern "C" int mla_local_attn(const void* q, const void* kv, void* out, int B, i
                 "mla_local_attn: need 8 heads, C %% 256 == 0, window <= 16");
   hipLaunchKernelGGL(local_attn_kernel, dim3(B * (gh / cs) * (gw / cs)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)kv,
                      (bf16_t*)out, B, gh, gw, C, cs, scale);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_local_attn_bwd(const void* q, const void* kv, const void* dout, void* dq, void* dkv, int B, int gh, int gw, int C,
+                                  int cs, int heads, float scale, hipStream_t stream) {
+  MLA_CHECK_ARG(q && kv && dout && dq && dkv, "mla_local_attn_bwd: null pointer");
+  MLA_CHECK_ARG(heads == 8 && C % 256 == 0 && C / 8 / 32 <= 8 && cs * cs <= 16 && gh % cs == 0 && gw % cs == 0,
+                "mla_local_attn_bwd: need 8 heads, C %% 256 == 0, window <= 16");
+  hipLaunchKernelGGL(local_attn_bwd_kernel, dim3(B * (gh / cs) * (gw / cs)), dim3(256), 0, stream, (const bf16_t*)q, (const bf16_t*)kv,
+                     (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dkv, B, gh, gw, C, cs, scale);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_avgpool_tokens_bwd(const void* dy, const void* other, void* dx, int B, int gh, int gw, int C, int cs, hipStream_t stream) {
+  MLA_CHECK_ARG(dy && dx && gh % cs == 0 && gw % cs == 0, "mla_avgpool_tokens_bwd: bad args");
+  hipLaunchKernelGGL(avgpool_tokens_bwd_kernel, dim3(gridn((long long)B * gh * gw * C)), dim3(256), 0, stream, (const bf16_t*)dy,
+                     (const bf16_t*)other, (bf16_t*)dx, B, gh, gw, C, cs);
   MLA_LAUNCH_CHECK();
 }

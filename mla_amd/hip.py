@@ -392,6 +392,8 @@ register_signatures({
     "mla_im2col_patch": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_avgpool_tokens": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_local_attn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mla_local_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mla_avgpool_tokens_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_colstats_blocks": [c_longlong],
     "mla_gather_rows_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "mla_transpose_bf16": [c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_longlong, c_void_p],
@@ -679,3 +681,18 @@ def imgloss_bwd(delta_raw, curr, nxt, ps, clip, gscale):
     call("mla_imgloss_bwd", _p(delta_raw), ld, _p(curr), _p(nxt), 1 if curr.dtype == torch.float32 else 0, _p(gscale), _p(out),
          delta_raw.shape[0], curr.shape[1], nxt.shape[1], curr.shape[2], ps, float(clip))
     return out
+
+
+def local_attn_bwd(q, kv, dout, B, gh, gw, cs, heads, scale):
+    C = q.shape[1]
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    call("mla_local_attn_bwd", _p(q), _p(kv), _p(dout), _p(dq), _p(dkv), B, gh, gw, C, cs, heads, float(scale))
+    return dq, dkv
+
+
+def avgpool_tokens_bwd(dy, other, B, gh, gw, cs):
+    C = dy.shape[1]
+    dx = torch.empty((B * gh * gw, C), dtype=torch.bfloat16, device=dy.device)
+    call("mla_avgpool_tokens_bwd", _p(dy), _p(other), _p(dx), B, gh, gw, C, cs)
+    return dx

@@ -871,3 +871,37 @@ class PaddedLinearFn(torch.autograd.Function):
         if ctx.bias is not None and ni[2]:
             db = deliver_vec_grad(ctx.bias, lambda out, acc: hip.colsum(dy2[:, :N], out, acc))
         return dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------------- vision tokenizer (stage "pretrain")
+class AvgPoolTokensFn(torch.autograd.Function):
+    """F.avg_pool2d(k = s = cs) over channel-last token rows [B*gh*gw, C] (models/mla/image/vision_tokenizer.py:28)."""
+
+    @staticmethod
+    def forward(ctx, x, B, gh, gw, cs):
+        _check_bf16_cuda(x)
+        ctx.dims = (B, gh, gw, cs)
+        return hip.avgpool_tokens(x.contiguous(), B, gh, gw, cs)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, gh, gw, cs = ctx.dims
+        return hip.avgpool_tokens_bwd(dy.contiguous(), None, B, gh, gw, cs), None, None, None, None
+
+
+class LocalAttnFn(torch.autograd.Function):
+    """3x3-window attention of LocalAttention.forward (vision_tokenizer.py:26-47): q [windows, C], kv [tokens, 2C] -> [windows, C]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, gh, gw, cs, heads, scale):
+        _check_bf16_cuda(q, kv)
+        q, kv = q.contiguous(), kv.contiguous()
+        ctx.save_for_backward(q, kv)
+        ctx.dims = (B, gh, gw, cs, heads, scale)
+        return hip.local_attn(q, kv, B, gh, gw, cs, heads, scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv = ctx.saved_tensors
+        dq, dkv = hip.local_attn_bwd(q, kv, dout.contiguous(), *ctx.dims)
+        return dq, dkv, None, None, None, None, None, None

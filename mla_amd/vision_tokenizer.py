@@ -83,8 +83,6 @@ class VisionTokenizer(nn.Module):
 
     def tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
         """[B, 4, 672, 672] (RGB + mask channel, fp32 or bf16) -> [B, 256, C] bf16 tokens (before the projector)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("trainable vision tokenizer (stage 'pretrain') is not built; SFT/post-training freeze it")
         B, CT, Hi, Wi = pixel_values.shape
         P, cs, C = self.patch_stride, self.conv_stride, self.hidden_size
         gh, gw = Hi // P, Wi // P
@@ -92,14 +90,28 @@ class VisionTokenizer(nn.Module):
         if not bool((masks == 1).all()):
             raise NotImplementedError("cropped pixel masks: only the all-ones mask yields the 256 tokens the reference's "
                                       "N_img = 256 layout needs (models/vlm/prismatic.py:932-933)")
+        kreal = 3 * P * P
+        kpad = ((kreal + 31) // 32) * 32
+        la = self.local_attention
+        trainable = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if trainable:
+            # stage "pretrain" (models/vlm/prismatic.py:415-447): the same dataflow on autograd ops -- Conv2d(k = s = 14) as a GEMM
+            # over im2col rows (its weight gradient flows back through the zero-padding of the reduction axis), LayerNorm /
+            # Linear backward, and the two dedicated backward kernels (window attention, average pooling)
+            rows = hip.im2col_patch(pixel_values.contiguous(), P, kpad)
+            w = F.pad(self.patch_embedding.weight.reshape(C, kreal), (0, kpad - kreal))
+            pe = ops.linear(rows, w)
+            red = ops.AvgPoolTokensFn.apply(pe, B, gh, gw, cs)
+            qv = ops.linear(ops.layernorm(red, la.q[0].weight, la.q[0].bias, la.q[0].eps), la.q[1].weight)
+            kv = ops.linear(ops.layernorm(pe, la.kv[0].weight, la.kv[0].bias, la.kv[0].eps), la.kv[1].weight)
+            agg = ops.LocalAttnFn.apply(qv, kv, B, gh, gw, cs, la.num_heads, la.scale)
+            tok = ops.linear(agg, la.proj.weight, la.proj.bias, residual=red)
+            return tok.view(B, (gh // cs) * (gw // cs), C)
         with torch.no_grad():
-            kreal = 3 * P * P
-            kpad = ((kreal + 31) // 32) * 32
             rows = hip.im2col_patch(pixel_values.contiguous(), P, kpad)
             w = F.pad(self.patch_embedding.weight.reshape(C, kreal), (0, kpad - kreal)).contiguous()
             pe = hip.gemm(rows, w)                                             # [B*gh*gw, C]
             red = hip.avgpool_tokens(pe, B, gh, gw, cs)                        # [B*256, C]
-            la = self.local_attention
             qv = hip.gemm(hip.layernorm_fwd(red, la.q[0].weight, la.q[0].bias, la.q[0].eps), la.q[1].weight)
             kv = hip.gemm(hip.layernorm_fwd(pe, la.kv[0].weight, la.kv[0].bias, la.kv[0].eps), la.kv[1].weight)
             agg = hip.local_attn(qv, kv, B, gh, gw, cs, la.num_heads, la.scale)

@@ -1,0 +1,84 @@
+"""Golden vectors for stage "pretrain" (trainable vision tokenizer; BASELINE configs[4] shape: use_pointcloud=False) from the REAL
+reference -- build container only.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/capture_golden_pretrain.py
+
+Tiny MLA (recipe weights), freeze_backbones("pretrain"), one forward/backward in fp32 (mode A) and bf16 autocast (mode C):
+losses and every gradient norm, plus slices of the vision-tower gradients. Writes tests/golden/mla_tiny_e2e_pretrain.npz.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import recipe, ref_import  # noqa: E402
+from oracle.capture_golden import _Draws  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SLICES = ("vlm.vision_tower_2d.patch_embedding.weight", "vlm.vision_tower_2d.local_attention.q.1.weight",
+          "vlm.vision_tower_2d.local_attention.kv.1.weight", "vlm.vision_tower_2d.local_attention.proj.weight")
+VECS = ("vlm.vision_tower_2d.local_attention.q.0.weight", "vlm.vision_tower_2d.local_attention.kv.0.bias",
+        "vlm.vision_tower_2d.local_attention.proj.bias")
+
+
+def run(mode, R=2):
+    mla = ref_import.build_reference_mla(recipe.TINY_LLAMA | {"vocab_size": recipe.TINY_LLAMA["vocab_size"] + 1}, recipe.TOKEN_SIZE,
+                                         use_pointcloud=False, use_contrastive=False)
+    shapes = {k: tuple(v.shape) for k, v in mla.state_dict().items()}
+    mla.load_state_dict(recipe.make_state_dict(shapes), strict=True)
+    mla.freeze_backbones("pretrain")
+    mla.train()
+    batch, draws = recipe.make_batch(R=R)
+    kw = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"],
+              point_cloud=None, actions=batch["actions"], proprio=batch["proprio"], action_masks=batch["action_masks"],
+              camera_name=batch["camera_name"], gripper_xyz=None, output_hidden_states=True, repeated_diffusion_steps=R, use_diff=True)
+    import builtins
+    _print = builtins.print
+    builtins.print = lambda *a, **k: None
+    try:
+        if mode == "A":
+            up = lambda m, a: tuple(x.float() if torch.is_tensor(x) and x.is_floating_point() else x for x in a)  # noqa: E731
+            mla.vlm.proprio_embedder.register_forward_pre_hook(up)
+            mla.vlm.x_embedder.register_forward_pre_hook(up)
+            with _Draws(draws, 2 * R):
+                ld, out = mla(**kw)
+        else:
+            mla.to(torch.bfloat16)
+            kw["images"] = {k: v.to(torch.bfloat16) for k, v in kw["images"].items()}
+            for k in ("actions", "proprio"):
+                kw[k] = kw[k].to(torch.bfloat16)
+            with _Draws(draws, 2 * R), torch.autocast("cpu", dtype=torch.bfloat16):
+                ld, out = mla(**kw)
+        ld["total_loss"].float().backward()
+    finally:
+        builtins.print = _print
+    grads = {k: p.grad for k, p in mla.named_parameters() if p.grad is not None}
+    return shapes, ld, grads
+
+
+def main():
+    res = {}
+    for mode in ("A", "C"):
+        shapes, ld, grads = run(mode)
+        f = lambda t: t.detach().float().numpy()  # noqa: E731
+        res[f"{mode}_total_loss"] = f(ld["total_loss"])
+        res[f"{mode}_gradnorms"] = np.array([float(grads[k].float().norm()) for k in sorted(grads)], dtype=np.float64)
+        for k in SLICES:
+            g = grads[k]
+            res[f"{mode}_grad::{k}"] = f(g.reshape(g.shape[0], -1)[:16, :64])
+        for k in VECS:
+            res[f"{mode}_grad::{k}"] = f(grads[k].reshape(-1)[:256])
+        if mode == "A":
+            res["grad_names"] = np.array(sorted(grads))
+            res["param_names"] = np.array(sorted(shapes))
+            res["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
+    np.savez_compressed(os.path.join(OUT, "mla_tiny_e2e_pretrain.npz"), **res)
+    vt = [n for n in res["grad_names"] if "vision_tower_2d" in str(n)]
+    print("mla_tiny_e2e_pretrain.npz: A loss", res["A_total_loss"], "C loss", res["C_total_loss"], "| vision-tower params with grad:", vt)
+
+
+if __name__ == "__main__":
+    main()
