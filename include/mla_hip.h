@@ -41,6 +41,11 @@ int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_1k, mla_str
 int mla_gemm_bf16(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N, int K, int lda, int ldb,
                   int ldc, int ldr, int a_mode, int b_mode, int out_fp32, int accumulate, float alpha, int force_generic,
                   mla_stream_t stream);
+/* same contract + a caller-owned scratch buffer (>= 64 MiB for full effect): the 256x256 kernel then cuts the tiles of its last,
+ * partially filled round of workgroups into K-slices (fp32 partials in the workspace, fix-up pass); deterministic */
+int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N, int K, int lda, int ldb,
+                     int ldc, int ldr, int a_mode, int b_mode, int out_fp32, int accumulate, float alpha, int force_generic,
+                     float* workspace, size_t workspace_bytes, mla_stream_t stream);
 
 /* ---- RMSNorm: LlamaRMSNorm.forward modeling_llama.py:76-90; timm RmsNorm in FinalLayer (models/diffusion/models.py:177) */
 int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int H, float eps, mla_stream_t stream);

@@ -17,24 +17,9 @@
 // blockIdx is remapped so every XCD (private L2) walks a contiguous, M-grouped range of tiles.
 #include "common.h"
 
-struct GemmArgs {
-  const bf16_t* A;
-  const bf16_t* B;
-  void* C;
-  const bf16_t* R;     // optional residual, bf16 [M, ldr]
-  const bf16_t* bias;  // optional bias, bf16 [N]
-  int M, N, K;
-  int lda, ldb, ldc, ldr;
-  int out_fp32;    // 0: C is bf16, 1: C is fp32
-  int accumulate;  // fp32 output only: C += result
-  float alpha;
-  int debug;  // experiments only (tools/)
-  // batched launches (gemm128 / generic only): z = blockIdx.y = outer * n_inner + inner, element strides per operand
-  int n_inner;
-  long long sAo, sAi, sBo, sBi, sCo, sCi;
-};
+#include "gemm_args.h"
 
-int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, hipStream_t stream);  // gemm256.hip
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream);  // gemm256.hip
 int mla_gemm_asm_dispatch(const void* args, hipStream_t stream);                           // gemm_asm.hip
 
 namespace {
@@ -294,9 +279,10 @@ int launch128(const GemmArgs& p, hipStream_t stream, int nbatch = 1) {
 
 }  // namespace
 
-extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N,
-                             int K, int lda, int ldb, int ldc, int ldr, int a_mode, int b_mode, int out_fp32,
-                             int accumulate, float alpha, int force_generic, hipStream_t stream) {
+static int gemm_bf16_impl(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N,
+                          int K, int lda, int ldb, int ldc, int ldr, int a_mode, int b_mode, int out_fp32,
+                          int accumulate, float alpha, int force_generic, float* workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
   MLA_CHECK_ARG(A && B && C, "mla_gemm_bf16: null operand");
   MLA_CHECK_ARG(M > 0 && N > 0 && K > 0, "mla_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
   MLA_CHECK_ARG((a_mode == 0 || a_mode == 1) && (b_mode == 0 || b_mode == 1), "mla_gemm_bf16: bad modes");
@@ -304,7 +290,7 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
   MLA_CHECK_ARG(!accumulate || out_fp32, "mla_gemm_bf16: accumulate needs fp32 output");
   MLA_CHECK_ARG(R == nullptr || ldr >= N, "mla_gemm_bf16: bad ldr");
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)R, (const bf16_t*)bias, M, N, K,
-             lda, ldb, ldc, ldr, out_fp32, accumulate, alpha, force_generic >> 4, 0, 0, 0, 0, 0, 0, 0};
+             lda, ldb, ldc, ldr, out_fp32, accumulate, alpha, force_generic >> 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, workspace};
   force_generic &= 15;
   bool mfma_ok = (force_generic != 1) && (K % 32 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                  (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
@@ -321,7 +307,7 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
     return mla_gemm_asm_dispatch(&p, stream);
   if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 &&
       a_mode == 0 && b_mode == 0 && (force_generic == 0 || force_generic == 3))
-    return mla_gemm256_dispatch(&p, a_mode, b_mode, stream);
+    return mla_gemm256_dispatch(&p, a_mode, b_mode, force_generic == 0 ? workspace_bytes : 0, stream);
   if (mfma_ok) {
     if (a_mode == 0 && b_mode == 0) return launch128<0, 0>(p, stream);
     if (a_mode == 0 && b_mode == 1) return launch128<0, 1>(p, stream);
@@ -331,6 +317,26 @@ extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* 
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   hipLaunchKernelGGL(gemm_generic_kernel, grid, dim3(256), 0, stream, p, a_mode, b_mode);
   MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_gemm_bf16(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N,
+                             int K, int lda, int ldb, int ldc, int ldr, int a_mode, int b_mode, int out_fp32,
+                             int accumulate, float alpha, int force_generic, hipStream_t stream) {
+  return gemm_bf16_impl(A, B, C, R, bias, M, N, K, lda, ldb, ldc, ldr, a_mode, b_mode, out_fp32, accumulate, alpha, force_generic, nullptr, 0,
+                        stream);
+}
+
+// Same, with a caller-owned scratch buffer: lets the 256x256 kernel cut the tiles of its last, partially filled round of
+// workgroups into K-slices (fp32 partials in the workspace + a fix-up pass). 64 MiB covers every split it will choose
+// (<= 256 partial tiles of 256 KiB); a smaller buffer only restricts the choice. Results differ from mla_gemm_bf16 only by
+// the fp32 summation order of the split tiles; the order is fixed, so the result is deterministic.
+extern "C" int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N,
+                                int K, int lda, int ldb, int ldc, int ldr, int a_mode, int b_mode, int out_fp32,
+                                int accumulate, float alpha, int force_generic, float* workspace, size_t workspace_bytes,
+                                hipStream_t stream) {
+  MLA_CHECK_ARG(workspace == nullptr || (((uintptr_t)workspace & 15) == 0), "mla_gemm_bf16_ws: workspace must be 16-byte aligned");
+  return gemm_bf16_impl(A, B, C, R, bias, M, N, K, lda, ldb, ldc, ldr, a_mode, b_mode, out_fp32, accumulate, alpha, force_generic, workspace,
+                        workspace_bytes, stream);
 }
 
 // Batched form (no bias / residual): for z = (outer, inner) in [0, n_outer) x [0, n_inner):
@@ -343,7 +349,7 @@ extern "C" int mla_gemm_batched_bf16(const void* A, const void* B, void* C, int 
   MLA_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && n_outer > 0 && n_inner > 0, "mla_gemm_batched_bf16: bad args");
   MLA_CHECK_ARG((long long)n_outer * n_inner <= 65535, "mla_gemm_batched_bf16: too many batches");
   GemmArgs p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, out_fp32, 0, alpha, 0,
-             n_inner, sAo, sAi, sBo, sBi, sCo, sCi};
+             n_inner, sAo, sAi, sBo, sBi, sCo, sCi, 0, 0, nullptr};
   const int nb = n_outer * n_inner;
   const bool al = ((sAo | sAi | sBo | sBi) % 8 == 0) && ((sCo | sCi) % 4 == 0);
   bool mfma_ok = al && (K % 32 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&

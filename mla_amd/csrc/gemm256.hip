@@ -18,22 +18,7 @@
 // one wave is in its ds_read/issue segment while its partner is in its MFMA segment; s_setprio(1) wraps the MFMAs.
 #include "common.h"
 
-struct GemmArgs {
-  const bf16_t* A;
-  const bf16_t* B;
-  void* C;
-  const bf16_t* R;
-  const bf16_t* bias;
-  int M, N, K;
-  int lda, ldb, ldc, ldr;
-  int out_fp32;
-  int accumulate;
-  float alpha;
-  int debug;  // experiments only (tools/)
-  // batched launches (gemm128 / generic only): z = blockIdx.y = outer * n_inner + inner, element strides per operand
-  int n_inner;
-  long long sAo, sAi, sBo, sBi, sCo, sCi;
-};
+#include "gemm_args.h"
 
 namespace {
 
@@ -88,7 +73,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int li = lane & 15, lg = lane >> 4;
 
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
-  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  // Split-K tail: workgroups [0, sk_full) compute whole tiles (XCD-remapped among themselves); workgroup sk_full + u computes
+  // K-slice u % sk_split of tile sk_full + u / sk_split and leaves a raw fp32 partial tile in the workspace.
+  int pid, kt0 = 0, nt = p.K / 64;
+  float* part = nullptr;
+  if (p.sk_split <= 1) {
+    pid = xcd_remap(blockIdx.x, gridDim.x);
+  } else if ((int)blockIdx.x < p.sk_full) {
+    pid = xcd_remap(blockIdx.x, p.sk_full);
+  } else {
+    const int u = blockIdx.x - p.sk_full;
+    const int slice = u % p.sk_split;
+    pid = p.sk_full + u / p.sk_split;
+    kt0 = (int)((long long)slice * nt / p.sk_split);
+    nt = (int)((long long)(slice + 1) * nt / p.sk_split) - kt0;
+    part = p.sk_ws + (size_t)u * 65536;
+  }
   const int in_group = GROUP_M * num_n;
   const int group_id = pid / in_group;
   const int first_m = group_id * GROUP_M;
@@ -96,7 +96,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int pid_m = first_m + (pid % in_group) % gsz;
   const int pid_n = (pid % in_group) / gsz;
   const int m0 = pid_m * 256, n0 = pid_n * 256;
-  const int nt = p.K / 64;
 
   // ---- staging pointers: [slot][it]; each advances one K-tile per use
   const size_t stepA = (dbg & 2) ? 64 : (AMODE == 0 ? 64 : (size_t)64 * p.lda);
@@ -116,7 +115,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     pB0[it] = stage_src<BMODE, false>(p.B, p.ldb, n0, p.N, 0, wave * 2 + it, lane);
     pB1[it] = stage_src<BMODE, false>(p.B, p.ldb, n0, p.N, 1, wave * 2 + it, lane);
   }
-  int tA0 = 0, tA1 = 0, tB0 = 0, tB1 = 0;  // next K-tile index each slot stages (wave-uniform)
+  if (kt0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      pA0[it] += (size_t)kt0 * stepA; pA1[it] += (size_t)kt0 * stepA;
+      pB0[it] += (size_t)kt0 * stepB; pB1[it] += (size_t)kt0 * stepB;
+    }
+  }
+  int tA0 = 0, tA1 = 0, tB0 = 0, tB1 = 0;  // next K-tile index (relative to kt0) each slot stages (wave-uniform)
 
 #define STAGE(PTR, TCNT, STEP, SLOTOFF)                                                           \
   do {                                                                                            \
@@ -261,6 +267,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the dummy tail loads before the wave retires
 
   // ---- epilogue (operands were passed swapped: lane holds C[m][n..n+3])
+  if (part) {      // K-slice of a tail tile: raw accumulators, tile-local [256][256] fp32; the fix-up kernel finishes the job
+#pragma unroll
+    for (int ri = 0; ri < 8; ++ri) {
+      const int ml = (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const int nl = (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
+        *(f32x4_t*)(part + ml * 256 + nl) = acc[ri][ci];
+      }
+    }
+    return;
+  }
   const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0);
 #pragma unroll
   for (int ri = 0; ri < 8; ++ri) {
@@ -315,6 +333,72 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef MMA
 }
 
+// Fix-up of the split-K tail: one thread per 4 consecutive outputs of a tail tile; sums the sk_split fp32 partials (fixed order:
+// deterministic) and applies the same epilogue as the main kernel.
+__global__ __launch_bounds__(256) void gemm256_fixup_kernel(GemmArgs p) {
+  const int GROUP_M = 4;
+  const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
+  const int tile = blockIdx.x >> 6;                       // 64 blocks of 256 threads x 4 outputs per tile
+  const int pid = p.sk_full + tile;
+  const int in_group = GROUP_M * num_n;
+  const int group_id = pid / in_group;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = (num_m - first_m) < GROUP_M ? (num_m - first_m) : GROUP_M;
+  const int pid_m = first_m + (pid % in_group) % gsz, pid_n = (pid % in_group) / gsz;
+  const int e = ((blockIdx.x & 63) * 256 + threadIdx.x) * 4;
+  const int ml = e >> 8, nl = e & 255;
+  const int m = pid_m * 256 + ml, n = pid_n * 256 + nl;
+  if (m >= p.M || n >= p.N) return;
+  const float* src = p.sk_ws + (size_t)tile * p.sk_split * 65536 + ml * 256 + nl;
+  f32x4_t a = *(const f32x4_t*)src;
+  for (int sl = 1; sl < p.sk_split; ++sl) a += *(const f32x4_t*)(src + (size_t)sl * 65536);
+  float v[4] = {a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha};
+  const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0) && (n + 3 < p.N);
+  for (int r = 0; r < 4 && n + r < p.N; ++r) {
+    if (p.bias) v[r] += bf2f(p.bias[n + r]);
+    if (p.R) v[r] += bf2f(p.R[(size_t)m * p.ldr + n + r]);
+  }
+  if (vec_ok) {
+    if (p.out_fp32) {
+      float* c = (float*)p.C + (size_t)m * p.ldc + n;
+      f32x4_t o = {v[0], v[1], v[2], v[3]};
+      if (p.accumulate) o += *(const f32x4_t*)c;
+      *(f32x4_t*)c = o;
+    } else {
+      u32x2_t o;
+      o[0] = pack2bf(v[0], v[1]);
+      o[1] = pack2bf(v[2], v[3]);
+      *(u32x2_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+    }
+  } else {
+    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+      if (p.out_fp32) {
+        float* c = (float*)p.C + (size_t)m * p.ldc + n + r;
+        *c = p.accumulate ? (*c + v[r]) : v[r];
+      } else {
+        ((bf16_t*)p.C)[(size_t)m * p.ldc + n + r] = f2bf(v[r]);
+      }
+    }
+  }
+}
+
+// Chooses the split of the tail: with T tiles on NCU compute units, T = q * NCU + r. The r tail tiles would occupy a whole
+// round at r / NCU utilisation; cut into s K-slices they take ceil(r * s / NCU) / s of a round (+ the fix-up pass).
+inline int choose_split(int tiles, int ncu, int nt, size_t ws_bytes, int* full_out) {
+  const int r = tiles % ncu;
+  *full_out = tiles - r;
+  if (r == 0) return 1;
+  int best = 1;
+  double best_cost = 1.0;
+  for (int s = 2; s <= 8; ++s) {
+    if (nt / s < 8) break;                                            // keep >= 8 K-tiles per slice (pipeline fill / drain)
+    if ((size_t)r * s * 65536 * sizeof(float) > ws_bytes) break;
+    const double cost = (double)((r * s + ncu - 1) / ncu) / s + 0.04 + 0.01 * s;   // rounds; fix-up ~ 4-12 % of a round
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
 template <int AM, int BM_>
 int launch256(const GemmArgs& p, hipStream_t stream) {
   static bool attr_set = false;
@@ -323,7 +407,13 @@ int launch256(const GemmArgs& p, hipStream_t stream) {
     attr_set = true;
   }
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
-  hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
+  if (p.sk_split > 1) {
+    const int tail = num_m * num_n - p.sk_full;
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(p.sk_full + tail * p.sk_split), dim3(512), 2 * BUF, stream, p);
+    hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     mla_set_error("gemm256 launch failed: %s", hipGetErrorString(e));
@@ -336,10 +426,26 @@ int launch256(const GemmArgs& p, hipStream_t stream) {
 
 // called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>
 // instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.
-int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, hipStream_t stream) {
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream) {
   if (a_mode != 0 || b_mode != 0) {
     mla_set_error("gemm256: k-contiguous operands only");
     return -1;
   }
-  return launch256<0, 0>(*(const GemmArgs*)args, stream);
+  GemmArgs p = *(const GemmArgs*)args;
+  p.sk_split = 1;
+  p.sk_full = 0;
+  if (p.sk_ws && ws_bytes) {
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (ncu <= 0) ncu = 256;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    int full = 0;
+    const int s = choose_split(tiles, ncu, p.K / 64, ws_bytes, &full);
+    if (s > 1 && full % 8 == 0) { p.sk_split = s; p.sk_full = full; }
+  }
+  return launch256<0, 0>(p, stream);
 }

@@ -1,0 +1,24 @@
+// Argument block shared by the GEMM kernels (gemm.hip, gemm256.hip, gemm_asm.hip).
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const bf16_t* R;     // optional residual, bf16 [M, ldr]
+  const bf16_t* bias;  // optional bias, bf16 [N]
+  int M, N, K;
+  int lda, ldb, ldc, ldr;
+  int out_fp32;    // 0: C is bf16, 1: C is fp32
+  int accumulate;  // fp32 output only: C += result
+  float alpha;
+  int debug;  // experiments only (tools/)
+  // batched launches (gemm128 / generic only): z = blockIdx.y = outer * n_inner + inner, element strides per operand
+  int n_inner;
+  long long sAo, sAi, sBo, sBi, sCo, sCi;
+  // split-K tail of gemm256 (see gemm256.hip): tiles [0, sk_full) are computed whole; each of the remaining tiles is cut into
+  // sk_split K-slices whose fp32 partial tiles go to sk_ws [unit][256][256]; a fix-up kernel sums them and applies the epilogue
+  int sk_full, sk_split;
+  float* sk_ws;
+};

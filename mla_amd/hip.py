@@ -18,6 +18,10 @@ _lib = None
 
 ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 
+# split-K tail of the 256x256 GEMM (mla_gemm_bf16_ws): on by default; MLA_GEMM_SPLITK=0 turns it off for A/B measurements
+SPLITK = os.environ.get("MLA_GEMM_SPLITK", "1") != "0"
+SPLITK_WS_BYTES = 64 << 20
+
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream (roofline.achieved)
 GEMM_PROFILE = None
 
@@ -27,6 +31,8 @@ _SIGNATURES = {
     "mla_selftest": [c_void_p, c_void_p, c_void_p, c_void_p],
     "mla_gemm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
+    "mla_gemm_bf16_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p],
     "mla_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "mla_rmsnorm_bwd_blocks": [c_int],
     "mla_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
@@ -181,8 +187,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()   # torch's current stream == the stream the kernel is launched on (see _stream())
-    call("mla_gemm_bf16", _p(a), _p(b), _p(out), _p(residual), _p(bias), M, N, K, lda, ldb, ldc, ldr or 0, a_mode, b_mode,
-         out_fp32, 1 if accumulate else 0, float(alpha), int(force_generic))
+    if SPLITK and force_generic == 0 and a_mode == 0 and b_mode == 0 and M >= 256 and N >= 256:
+        ws = workspace(SPLITK_WS_BYTES, a.device)      # per (device, stream) scratch owned by torch
+        call("mla_gemm_bf16_ws", _p(a), _p(b), _p(out), _p(residual), _p(bias), M, N, K, lda, ldb, ldc, ldr or 0, a_mode, b_mode,
+             out_fp32, 1 if accumulate else 0, float(alpha), 0, _p(ws), SPLITK_WS_BYTES)
+    else:
+        call("mla_gemm_bf16", _p(a), _p(b), _p(out), _p(residual), _p(bias), M, N, K, lda, ldb, ldc, ldr or 0, a_mode, b_mode,
+             out_fp32, 1 if accumulate else 0, float(alpha), int(force_generic))
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (a_mode, b_mode, M, N, K)))

@@ -317,3 +317,23 @@ def test_gemm_asm_kernel(dev, M, N, K):
     hip.gemm(a, b, out=acc, accumulate=True, force_generic=4)
     assert fro_rel(acc, ref + 1.0) < 2e-4
     assert torch.equal(hip.gemm(a, b, force_generic=4), hip.gemm(a, b, force_generic=3))
+
+
+@pytest.mark.parametrize("M,N,K", [(17536, 4096, 1024), (2200, 7424, 2048), (4096, 2048, 4096), (17536, 11008, 512)])
+def test_gemm256_splitk_tail(dev, M, N, K):
+    """mla_gemm_bf16_ws: the tiles of the last partial round of workgroups are cut into K-slices (fp32 partials + fix-up kernel).
+    Same results as the unsplit kernel up to fp32 summation order; epilogue variants go through the fix-up path."""
+    from mla_amd import hip
+    assert hip.SPLITK
+    a, b = bfr(M, K, seed=1).to(dev), bfr(N, K, seed=2).to(dev)
+    plain32 = hip.gemm(a, b, out_dtype=torch.float32, force_generic=3)
+    sk32 = hip.gemm(a, b, out_dtype=torch.float32)
+    assert fro_rel(sk32, plain32.cpu()) < 1e-6 and max_rel(sk32, plain32.cpu()) < 1e-4
+    bias, res = bfr(N, seed=3).to(dev), bfr(M, N, seed=4).to(dev)
+    got = hip.gemm(a, b, bias=bias, residual=res, alpha=0.5)
+    want = hip.gemm(a, b, bias=bias, residual=res, alpha=0.5, force_generic=3)
+    assert fro_rel(got, want.float().cpu()) < 2e-3
+    acc = torch.ones((M, N), dtype=torch.float32, device=dev)
+    hip.gemm(a, b, out=acc, accumulate=True)
+    assert fro_rel(acc, (plain32 + 1.0).cpu()) < 1e-6
+    assert torch.equal(hip.gemm(a, b), hip.gemm(a, b))          # deterministic
