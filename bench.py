@@ -172,9 +172,18 @@ def main():
             tsum = sum(t for t, _, _ in big) * 1e-3
             fsum = sum(fl for _, fl, _ in big)
             ach = fsum / tsum / 1e12
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes over this same command (PMC collection perturbs timing,
+            # so it is not done inline): profiles/r1_gemm256_hbm_traffic.json, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r1_gemm256_hbm_traffic.json")
+            if os.path.exists(tpath) and args.config == 1 and not args.tiny:
+                with open(tpath) as fh:
+                    traffic = round(json.load(fh)["hbm_bytes_per_launch"])
+            abytes = sum(2.0 * (k[2] * k[4] + k[3] * k[4]) + 2.0 * k[2] * k[3] for _, _, k in big) / len(big)
             roof = {"bound": "mfma", "kernel": "gemm256_kernel<0,0> (+ gemm128_kernel for small shapes): bf16 MFMA GEMM launches >= 0.1 TFLOP",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
+                    "traffic": traffic, "traffic_unit": "HBM+MALL bytes per launch (fabric-side counters), avg over the same launches",
+                    "algorithmic_bytes_per_launch_2B_outputs": round(abytes), "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
                     "gemm_ms_per_step": round(tsum / args.steps * 1e3, 1)}
         out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
