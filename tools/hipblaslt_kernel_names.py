@@ -1,3 +1,5 @@
+"""Runs torch.matmul (hipBLASLt) on the 7B GEMM shapes so that `rocprofv3 --kernel-trace --stats` shows which library kernel serves them
+(round 1: a stream-K custom kernel, ..._SK3_..._MT256x256x64_MI16x16x1_...). Usage: rocprofv3 --kernel-trace --stats -- python tools/hipblaslt_kernel_names.py"""
 import torch
 T=17536
 dev=torch.device("cuda:0")
