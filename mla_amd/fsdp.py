@@ -208,6 +208,14 @@ class ShardedModel:
         self._coef = torch.ones(1, dtype=torch.float32, device=device)
         self._norm = torch.zeros(1, dtype=torch.float32, device=device)
         self.comm_stream = self.ops.stream(device) if self.coll else None
+        # all-gather consumption: a unit's forward waits for ITS gather only (issued right after that unit's optimizer update on
+        # the side stream), so the gathers of later layers keep streaming in behind the forward pass instead of being waited
+        # for up front; units without a module (root) are waited for in begin_step
+        if self.coll and self.device.type == "cuda":
+            for u in self.units:
+                mod = getattr(u, "module", None)
+                if mod is not None:
+                    mod.register_forward_pre_hook(lambda m, inp, uu=u: self.wait_unit(uu))
         # reduce-scatter launch hooks on the decoder layers (fires when the layer's backward has been enqueued)
         for u in self.units:
             mod = getattr(u, "module", None)
@@ -267,11 +275,11 @@ class ShardedModel:
         for u in self.units:
             u.begin_step()
             u.rs_event = None
-        # the bf16 all-gathers of the previous optimizer step were issued in forward order on the side stream; make the
-        # compute stream wait for all of them here (layer-granular waits are not needed: 14 GB arrive in ~15-45 ms while
-        # the encoders run) -- per-unit waiting is available through wait_unit() for callers that interleave.
+        # the bf16 all-gathers of the previous optimizer step were issued in unit order on the side stream; units that own a
+        # module wait in their forward pre-hook, the rest (root unit: embeddings, heads) here
         for u in self.units:
-            self.wait_unit(u)
+            if getattr(u, "module", None) is None or self.device.type != "cuda":
+                self.wait_unit(u)
 
     def finish_backward(self):
         for u in self.units:
