@@ -135,8 +135,9 @@ class CoordinateAwareContrastiveLoss(nn.Module):
 
 
 class TactileContrastiveLoss(nn.Module):
-    """contrastive.py:219-258. Parameters are always constructed (the reference builds the module even when tactile
-    is off, modeling_llama.py:1148-1156); forward is only reached with use_tactile, which no BASELINE config sets."""
+    """contrastive.py:219-258: tactile tokens against ALL 256 point-cloud tokens and ALL 256 image tokens of their sample; the
+    positives are the point centre nearest to the gripper and the image patch it projects to. Parameters are always
+    constructed (the reference builds the module even when tactile is off, modeling_llama.py:1148-1156)."""
 
     def __init__(self, feature_dim, projection_dim=256, temperature=0.07):
         super().__init__()
@@ -146,4 +147,14 @@ class TactileContrastiveLoss(nn.Module):
         self.image_projection_head = _head(feature_dim, projection_dim)
 
     def forward(self, tac_features, pc_features, img_features, positive_pc_indices, linear_positive_img_indices):
-        raise NotImplementedError("tactile contrastive loss: use_tactile is outside BASELINE configs 0-4 (SURVEY 8a-17)")
+        if tac_features.shape[0] == 0:
+            return torch.tensor(0.0, device=tac_features.device, requires_grad=True)
+        tac = ops.l2_normalize(_run_head(self.tactile_projection_head, tac_features.contiguous()))
+        pc = ops.l2_normalize(_run_head(self.pointcloud_projection_head, pc_features.contiguous()))
+        img = ops.l2_normalize(_run_head(self.image_projection_head, img_features.contiguous()))
+        inv_t = 1.0 / self.temperature
+        logits_pc = ops.BmmNTFn.apply(tac, pc, inv_t)                     # [B, n_arms, 256] fp32
+        logits_img = ops.BmmNTFn.apply(tac, img, inv_t)
+        loss_pc = ops.cross_entropy(logits_pc.reshape(-1, pc.shape[1]), positive_pc_indices.reshape(-1))
+        loss_img = ops.cross_entropy(logits_img.reshape(-1, img.shape[1]), linear_positive_img_indices.reshape(-1))
+        return (loss_pc + loss_img) / 2

@@ -12,7 +12,8 @@ Scope notes
   is not built: scripts/post_rlbench.sh:26 ships USE_ROI=false, for which every patch is inside the ROI, the warp / alpha /
   offset branches are dead and the generated patch is ``0.05 * current + 5 * tanh(delta)``. The image head therefore returns
   the raw delta logits and the loss kernel fuses tanh, the blend, images_to_patches addressing and the three reductions.
-* TactileGenerationModule (models.py:389-430) is outside BASELINE configs 0-4 (GEN_TAC=false, no tactile in the simulator).
+* TactileGenerationModule (models.py:389-430) is built although no BASELINE config enables it (GEN_TAC=false: no tactile sensor in
+  the simulator); its single-query attention runs on the SIMT GEMM fallback.
 """
 from __future__ import annotations
 
@@ -37,7 +38,7 @@ def _self_attention(mha: nn.MultiheadAttention, x: torch.Tensor, training: bool)
     E = mha.embed_dim
     qkv = ops.linear(x, mha.in_proj_weight, mha.in_proj_bias)                                   # [B, S, 3E]
     o = ops.mha_core(qkv, None, mha.num_heads, x.shape[1], mha.dropout, training)
-    assert x.shape[1] % 8 == 0 and E % mha.num_heads == 0
+    assert E % mha.num_heads == 0       # sequence lengths that break the MFMA alignment (the 1-query tactile head) use the SIMT GEMM
     return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
 
@@ -242,6 +243,27 @@ class PointCloudGenerationModule(nn.Module):
         return {"pointcloud_coord_generation": pts.reshape(B, G * M, 3)}
 
 
+class TactileGenerationModule(nn.Module):
+    """models/mla/generation/models.py:389-430: one learned query cross-attends to the (projected) LLM states through a 2-layer
+    post-norm decoder; a linear head predicts the next tactile reading."""
+
+    def __init__(self, token_size: int = 4096, tactile_dim: int = 128, decoder_layers: int = 2, decoder_heads: int = 4):
+        super().__init__()
+        self.token_size, self.tactile_dim = token_size, tactile_dim
+        self.feature_projector = nn.Linear(token_size, token_size)
+        self.tactile_query = nn.Parameter(torch.zeros(1, 1, token_size))
+        nn.init.normal_(self.tactile_query, std=0.02)
+        self.decoder = _decoder(token_size, decoder_heads, token_size * 2, decoder_layers)
+        self.output_head = nn.Linear(token_size, tactile_dim)
+
+    def forward(self, llm_hidden_states):
+        B = llm_hidden_states.shape[0]
+        query = self.tactile_query.to(llm_hidden_states.dtype).expand(B, -1, -1).contiguous()
+        memory = ops.linear(llm_hidden_states, self.feature_projector.weight, self.feature_projector.bias)
+        decoded = self.decoder(query, memory)                                                          # [B, 1, H]
+        return {"tactile_generation": ops.linear(decoded.squeeze(1), self.output_head.weight, self.output_head.bias)}
+
+
 class MultimodalGenerationManager(nn.Module):
     """models/mla/generation/models.py:433-539."""
 
@@ -254,8 +276,6 @@ class MultimodalGenerationManager(nn.Module):
         super().__init__()
         self.use_image_generation, self.use_pointcloud_generation = use_image_generation, use_pointcloud_generation
         self.use_tactile_generation = use_tactile_generation
-        if use_tactile_generation:
-            raise NotImplementedError("TactileGenerationModule (models.py:389-430): GEN_TAC=false in every BASELINE config")
         if use_image_generation:
             self.image_gen_module = ImageGenerationModule(
                 token_size=token_size, num_gen_queries=num_image_gen_queries, decoder_layers=image_decoder_layers,
@@ -266,6 +286,9 @@ class MultimodalGenerationManager(nn.Module):
                 prismatic_hidden_dim=token_size, trans_dim=pointcloud_trans_dim, decoder_depth=pointcloud_decoder_layers,
                 decoder_num_heads=pointcloud_decoder_heads, group_size=pointcloud_group_size, num_groups=pointcloud_num_groups,
                 loss="cdl2", use_geometric_prior=True)
+        if use_tactile_generation:
+            self.tactile_gen_module = TactileGenerationModule(token_size=token_size, tactile_dim=tactile_dim,
+                                                              decoder_layers=tactile_decoder_layers, decoder_heads=tactile_decoder_heads)
 
     def forward(self, llm_hidden_states, current_image_features=None, current_images_patches=None, current_point_cloud=None,
                 roi_mask_2d=None) -> Dict[str, torch.Tensor]:
@@ -275,6 +298,8 @@ class MultimodalGenerationManager(nn.Module):
                                              current_images_patches=current_images_patches, roi_mask_2d=roi_mask_2d))
         if self.use_pointcloud_generation:
             out.update(self.pointcloud_gen_module(last_hidden=llm_hidden_states, current_pointcloud=current_point_cloud))
+        if self.use_tactile_generation:
+            out.update(self.tactile_gen_module(llm_hidden_states=llm_hidden_states))
         return out
 
     def get_module_keys(self) -> list:
@@ -283,6 +308,8 @@ class MultimodalGenerationManager(nn.Module):
             keys.append("image_gen_module")
         if self.use_pointcloud_generation:
             keys.append("pointcloud_gen_module")
+        if self.use_tactile_generation:
+            keys.append("tactile_gen_module")
         return keys
 
 

@@ -78,12 +78,15 @@ class MLA(nn.Module):
         load("llm_backbone", vlm.llm_backbone, strict=False)
         if "proprio_embedder" in sd and sd["proprio_embedder"]["mlp.fc1.weight"].shape[-1] == action_dim:
             load("proprio_embedder", vlm.proprio_embedder)
+        tactile_dim = 24 if action_dim == 14 else 12                                         # model_mla.py:405-409
+        if use_tactile and "tactile_embedder" in sd and sd["tactile_embedder"]["mlp.fc1.weight"].shape[-1] == tactile_dim:
+            load("tactile_embedder", vlm.tactile_embedder)
         if use_diff and all(k in sd for k in ("x_embedder", "t_embedder", "final_layer")):
             if sd["x_embedder"]["mlp.fc1.weight"].shape[-1] == action_dim:
                 for k in ("x_embedder", "t_embedder", "final_layer"):
                     load(k, getattr(vlm, k))
         if use_generation and "generation_manager" in sd:
-            for flag, sub in ((gen_image, "image_gen_module"), (gen_pointcloud, "pointcloud_gen_module")):
+            for flag, sub in ((gen_image, "image_gen_module"), (gen_pointcloud, "pointcloud_gen_module"), (gen_tactile, "tactile_gen_module")):
                 part = {k[len(sub) + 1:]: v for k, v in sd["generation_manager"].items() if k.startswith(sub + ".")}
                 if flag and part:
                     getattr(vlm.generation_manager, sub).load_state_dict(part)
@@ -140,6 +143,10 @@ class MLA(nn.Module):
             point_cloud = rep(point_cloud)
         if self.use_pointcloud and self.use_generation and self.gen_pointcloud:
             next_point_cloud = rep(next_point_cloud)
+        if self.use_tactile:                                              # model_mla.py:172-176
+            tactile, gripper_xyz = rep(tactile), rep(gripper_xyz)
+        if self.use_generation and self.gen_tactile:                     # (the reference tiles it only when use_tactile is set too)
+            next_tactile = rep(next_tactile)
         if noise is None:
             noise = torch.randn_like(actions_future)
         if timestep is None:
@@ -169,9 +176,15 @@ class MLA(nn.Module):
         if self.use_generation and self.gen_pointcloud:
             loss_dict["point_cloud_gen_loss"] = generation_losses["point_cloud_gen_loss"]
             total = total + generation_losses["point_cloud_gen_loss"].float()
+        if self.use_generation and self.gen_tactile:
+            loss_dict["tactile_gen_loss"] = generation_losses["tactile_gen_loss"]
+            total = total + generation_losses["tactile_gen_loss"].float()
         if self.use_contrastive:
             loss_dict["img_pc_contrastive_loss"] = output.img_pc_contrastive_loss
             total = total + output.img_pc_contrastive_loss.float()
+            if self.use_tactile:
+                loss_dict["tactile_contrastive_loss"] = output.tactile_contrastive_loss
+                total = total + output.tactile_contrastive_loss.float()
         # the reference's `total_loss` and `diff_loss` are one tensor mutated in place (model_mla.py:215-229), so the
         # reported diff_loss equals total_loss; the true diffusion MSE is kept in self.last_diff_mse
         loss_dict["total_loss"] = total

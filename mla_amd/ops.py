@@ -905,3 +905,37 @@ class LocalAttnFn(torch.autograd.Function):
         q, kv = ctx.saved_tensors
         dq, dkv = hip.local_attn_bwd(q, kv, dout.contiguous(), *ctx.dims)
         return dq, dkv, None, None, None, None, None, None
+
+
+class BmmNTFn(torch.autograd.Function):
+    """C[b] = alpha * A[b] @ B[b]^T for bf16 [nb, M, K] x [nb, N, K] -> fp32 [nb, M, N] (torch.bmm(a, b.transpose(1, 2)) / T of
+    TactileContrastiveLoss, models/mla/fuser/contrastive.py:248,253). Tiny M (one row per arm): the batched GEMM falls back to
+    its SIMT path where the MFMA alignment rules do not hold."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        _check_bf16_cuda(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        nb, M, K = a.shape
+        N = b.shape[1]
+        out = torch.empty((nb, M, N), dtype=torch.float32, device=a.device)
+        hip.gemm_batched(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=alpha, n_outer=nb, n_inner=1, sA=(M * K, 0), sB=(N * K, 0),
+                         sC=(M * N, 0))
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        nb, M, K = a.shape
+        N = b.shape[1]
+        dcb = dc.to(BF16).contiguous()
+        da = torch.empty_like(a)
+        db = torch.empty_like(b)
+        # dA = alpha * dC B   (B stored [N(k)][K(n)] -> reduction-major)     dB = alpha * dC^T A  (both reduction-major)
+        hip.gemm_batched(dcb, b, da, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, b_mode=1, alpha=ctx.alpha, n_outer=nb, n_inner=1, sA=(M * N, 0),
+                         sB=(N * K, 0), sC=(M * K, 0))
+        hip.gemm_batched(dcb, a, db, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_mode=1, b_mode=1, alpha=ctx.alpha, n_outer=nb, n_inner=1,
+                         sA=(M * N, 0), sB=(M * K, 0), sC=(N * K, 0))
+        return da, db, None

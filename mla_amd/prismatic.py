@@ -80,10 +80,8 @@ class PrismaticVLM(nn.Module):
         self.use_roi = use_roi
         self.gen_pointcloud = gen_pointcloud and use_generation
         self.gen_tactile = gen_tactile and use_generation
-        if self.gen_tactile:
-            raise NotImplementedError("tactile generation head: GEN_TAC=false in every BASELINE config (no tactile in the simulator)")
-        if use_tactile:
-            raise NotImplementedError("tactile inputs are outside BASELINE configs 0-4")
+        if use_tactile and not use_pointcloud:
+            raise ValueError("use_tactile needs use_pointcloud: the tactile positives are picked among the point-cloud centres (prismatic.py:745-752)")
         self.string2idx = {}
         for trigger in ["True", "False", "Yes", "No"] + [chr(ord("A") + i) for i in range(26)]:
             ids = self.llm_backbone.tokenizer.encode(trigger, add_special_tokens=False)
@@ -99,6 +97,8 @@ class PrismaticVLM(nn.Module):
         if self.use_pointcloud:
             self.vision_tower_3d = PointTokenizer(in_channels=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True)
             self.projector_3d = MLPProjector(self.vision_tower_3d.embed_dim, token_size)
+        if self.use_tactile:                                                   # prismatic.py:234-236
+            self.tactile_embedder = ActionEmbedder(action_size=self.tactile_dim, hidden_size=token_size)
         self.proprio_embedder = ActionEmbedder(action_size=action_dim, hidden_size=token_size)
         if self.use_diff:
             self.x_embedder = ActionEmbedder(action_size=action_dim, hidden_size=token_size)
@@ -113,7 +113,7 @@ class PrismaticVLM(nn.Module):
                 use_roi=use_roi, roi_dilation_kernel_size=roi_dilation_kernel_size, use_pointcloud_generation=self.gen_pointcloud,
                 pointcloud_trans_dim=pointcloud_trans_dim, pointcloud_decoder_layers=pointcloud_decoder_layers,
                 pointcloud_decoder_heads=pointcloud_decoder_heads, pointcloud_group_size=pointcloud_group_size,
-                pointcloud_num_groups=pointcloud_num_groups, use_tactile_generation=False, tactile_dim=self.tactile_dim,
+                pointcloud_num_groups=pointcloud_num_groups, use_tactile_generation=self.gen_tactile, tactile_dim=self.tactile_dim,
                 tactile_decoder_layers=tactile_decoder_layers, tactile_decoder_heads=tactile_decoder_heads)
 
         self.all_module_keys = ["vision_tower_2d", "projector_2d", "llm_backbone", "proprio_embedder"]
@@ -121,6 +121,8 @@ class PrismaticVLM(nn.Module):
             self.all_module_keys.extend(["x_embedder", "t_embedder", "final_layer"])
         if self.use_pointcloud:
             self.all_module_keys.extend(["vision_tower_3d", "projector_3d"])
+        if self.use_tactile:
+            self.all_module_keys.extend(["tactile_embedder"])
         if self.use_generation:
             self.all_module_keys.append("generation_manager")
         self.trainable_module_keys: List[str] = []
@@ -199,6 +201,11 @@ class PrismaticVLM(nn.Module):
             self.vision_backbone_requires_grad = False
         else:
             raise ValueError(f"Stage `{stage}` is not supported! Try < pretrain | finetune | post-training >")
+        if self.use_tactile:                                              # every stage trains the tactile embedder (:441, :468, :499)
+            self.tactile_embedder.requires_grad_(True)
+            pos = self.trainable_module_keys.index("generation_manager") if "generation_manager" in self.trainable_module_keys \
+                else len(self.trainable_module_keys)
+            self.trainable_module_keys.insert(pos, "tactile_embedder")
 
     def get_fsdp_wrapping_policy(self):
         """prismatic.py:560-596: union of {VisionTokenizer, PointTokenizer}, the LLM's decoder-layer policy and
@@ -210,8 +217,6 @@ class PrismaticVLM(nn.Module):
     # ------------------------------------------------------------------------------------------ fused tokens
     def get_fused_tokens(self, images, pointcloud, tactile, gripper_xyz, camera_name):
         """prismatic.py:598-769 -> (fused [B, 513, H], patch_indices [B, 256, 2], valid_mask [B, 256], None, None, None)."""
-        if self.use_tactile and tactile is not None:
-            raise NotImplementedError("tactile tokens")
         get_camera_params(camera_name)  # raises on unknown names, like camera.py:54-56
         views: Dict[str, torch.Tensor] = images if isinstance(images, dict) else {"front_image": images}
         assert "front_image" in views, "front_image must be present in multi-view images"
@@ -233,6 +238,27 @@ class PrismaticVLM(nn.Module):
             if key != "front_image":
                 extra, _ = self.encode_images(views[key])
                 parts.append(torch.stack(extra, dim=0))
+        if self.use_tactile and tactile is not None:
+            # prismatic.py:706-750: one token per arm from tactile_embedder; positives = the point centre nearest to each gripper
+            # and the image patch that centre projects to (index arithmetic on [B, n_arms] tensors: torch)
+            if not (self.use_pointcloud and pointcloud is not None):
+                raise ValueError("tactile tokens need the point-cloud centres (prismatic.py:745)")
+            last_dim = gripper_xyz.shape[-1]
+            if last_dim % 3 != 0:
+                raise ValueError(f"gripper_xyz last dimension ({last_dim}) is not divisible by 3")
+            n_arms = last_dim // 3
+            t_flat = tactile.reshape(tactile.shape[0], -1)
+            if t_flat.shape[-1] != self.tactile_dim * n_arms:
+                raise ValueError(f"Unexpected tactile shape {tuple(tactile.shape)}. Expect (B, {self.tactile_dim * n_arms}).")
+            tac = torch.cat([self.tactile_embedder(ts.to(front.dtype)).unsqueeze(1) for ts in torch.chunk(t_flat, n_arms, dim=-1)], dim=1)
+            parts.append(tac)                                                                   # [B, n_arms, H]
+            g = gripper_xyz.reshape(B, n_arms, 3).to(centers.dtype)
+            dist = torch.cdist(g, centers)
+            _, pos_pc = torch.topk(dist, k=1, dim=2, largest=False)                            # [B, n_arms, 1]
+            patch_w = int(front.shape[1] ** 0.5)
+            idx2d = torch.gather(patch_indices.unsqueeze(1).expand(-1, n_arms, -1, -1), 2, pos_pc.unsqueeze(-1).expand(-1, -1, -1, 2))
+            lin_img = idx2d[..., 0] * patch_w + idx2d[..., 1]                                   # [B, n_arms, 1]
+            return parts, patch_indices, valid_mask, pos_pc, lin_img, centers
         parts.append(torch.zeros((B, 1, self.token_size), dtype=front.dtype, device=front.device))  # zero tactile slot (:752-763)
         return parts, patch_indices, valid_mask, None, None, None
 
@@ -261,6 +287,12 @@ class PrismaticVLM(nn.Module):
             pc_loss = chamfer_distance_l2(generation_outputs["pointcloud_coord_generation"], next_point_cloud)
             losses["point_cloud_gen_loss"] = pc_loss
             total = total + pc_loss
+        if self.gen_tactile and next_tactile is not None and "tactile_generation" in generation_outputs:
+            # F.mse_loss over [B, tactile_dim] (prismatic.py:827-835): a few hundred elements, evaluated with torch on the device
+            pred = generation_outputs["tactile_generation"].float()
+            tac_loss = ((pred - next_tactile.reshape(pred.shape).float()) ** 2).mean()
+            losses["tactile_gen_loss"] = tac_loss
+            total = total + tac_loss
         losses["total_generation_loss"] = total
         return losses
 
@@ -281,11 +313,13 @@ class PrismaticVLM(nn.Module):
         t = t.to(bf16) if t is not None else None
         tag_0 = 2 if self.training else 29871                              # :882-887
 
-        parts, patch_indices, valid_mask, _, _, _ = self.get_fused_tokens(images, point_cloud, tactile, gripper_xyz, camera_name)
+        parts, patch_indices, valid_mask, pos_pc_tac, lin_img_tac, _ = self.get_fused_tokens(images, point_cloud, tactile, gripper_xyz,
+                                                                                        camera_name)
         n_fused = sum(p.shape[1] for p in parts)
         N_pc = N_img = 256
         pc_idx = (1, 1 + N_pc)
         img_idx = (pc_idx[1], pc_idx[1] + N_img)
+        tac_idx = (img_idx[1], img_idx[1] + self.action_dim // 7) if self.use_tactile else None      # prismatic.py:941-944
 
         text_emb = self.llm_backbone.embed_input_ids(input_ids)             # [B, L, H]
         proprio_e = self.proprio_embedder(proprio)                          # [B, 1, H]
@@ -307,16 +341,17 @@ class PrismaticVLM(nn.Module):
             input_ids=None, attention_mask=fused_attention_mask, position_ids=None, past_key_values=None,
             inputs_embeds=fused_embeddings, labels=fused_labels, use_cache=use_cache, output_attentions=output_attentions,
             output_hidden_states=True, return_dict=True, pc_token_indices=pc_idx, img_token_indices=img_idx,
-            tac_token_indices=None, patch_correspondence_indices=patch_indices, correspondence_valid_mask=valid_mask,
-            positive_pc_indices_for_tac=None, linear_positive_img_indices_for_tac=None,
-            compute_token_contrastive_loss=self.use_contrastive, compute_tactile_contrastive_loss=False)
+            tac_token_indices=tac_idx, patch_correspondence_indices=patch_indices, correspondence_valid_mask=valid_mask,
+            positive_pc_indices_for_tac=pos_pc_tac, linear_positive_img_indices_for_tac=lin_img_tac,
+            compute_token_contrastive_loss=self.use_contrastive,
+            compute_tactile_contrastive_loss=(self.use_contrastive and self.use_tactile))
 
         last_hidden = output.hidden_states[-1]
         # ---- generation heads (:1071-1113). current_point_cloud=None is what the reference passes (:1098), so the FPS prior of
         # the point head never runs; the per-step visualisation (:1129-1135, hard-coded path) is deliberately not reproduced.
         generation_outputs: Dict[str, torch.Tensor] = {}
         generation_losses: Dict[str, torch.Tensor] = {}
-        if self.use_generation and (self.gen_image or self.gen_pointcloud) and self.training:
+        if self.use_generation and (self.gen_image or self.gen_pointcloud or self.gen_tactile) and self.training:
             front = (images["front_image"] if isinstance(images, dict) else images)
             generation_outputs = self.generation_manager(
                 llm_hidden_states=last_hidden, current_image_features=parts[1], current_images_patches=None,
@@ -326,6 +361,8 @@ class PrismaticVLM(nn.Module):
                 generation_outputs["current_front_image"] = front
             if self.gen_pointcloud:
                 assert next_point_cloud is not None
+            if self.gen_tactile:
+                assert next_tactile is not None
             generation_losses = self.compute_generation_losses(generation_outputs, next_images=next_images,
                                                                next_point_cloud=next_point_cloud, next_tactile=next_tactile)
 

@@ -38,7 +38,8 @@ def point_weights(sd, pfx="vlm.vision_tower_3d."):
 
 
 def mla_forward(sd: dict, batch: dict, draws: dict, n_layers: int, n_heads: int, eps: float, R: int, use_pointcloud=True,
-                use_contrastive=True, tap: int = 8, zero_pad_rows: bool = True, gen_cfg: dict = None):
+                use_contrastive=True, tap: int = 8, zero_pad_rows: bool = True, gen_cfg: dict = None,
+                use_tactile: bool = False, gen_tactile: bool = False):
     """zero_pad_rows=True: flash/varlen semantics (pad query rows give zero attention output -- what the GPU reference
     path and the HIP kernels do); False: eager semantics (what the CPU-imported reference does, used to pin this oracle
     against tests/golden). Valid rows and all losses/gradients are identical either way.
@@ -67,7 +68,21 @@ def mla_forward(sd: dict, batch: dict, draws: dict, n_layers: int, n_heads: int,
         pc_tok = torch.zeros(B, 256, H)
         patch_idx = torch.zeros(B, 256, 2, dtype=torch.long)
         valid = torch.zeros(B, 256, dtype=torch.bool)
-    fused = torch.cat([pc_tok, img_tok, torch.zeros(B, 1, H)], dim=1)
+    pos_pc = lin_img = None
+    if use_tactile:
+        # prismatic.py:706-750 (one arm): tactile token from tactile_embedder; positives = nearest point centre to the gripper and
+        # the image patch that centre projects to
+        tact = rep(batch["tactile"]).float()          # not hard-cast by the reference (only proprio / x / t are, prismatic.py:873-880)
+        pt = "tactile_embedder"
+        tac_tok = O.mlp_gelu_tanh(tact, sd[P + pt + ".mlp.fc1.weight"], sd[P + pt + ".mlp.fc1.bias"], sd[P + pt + ".mlp.fc2.weight"],
+                                  sd[P + pt + ".mlp.fc2.bias"]).unsqueeze(1)
+        grip = rep(batch["gripper_xyz"]).float().view(B, 1, 3)
+        pos_pc = torch.cdist(grip, centers).argmin(dim=2, keepdim=True)                     # [B, 1, 1]
+        idx2d = torch.gather(patch_idx.unsqueeze(1), 2, pos_pc.unsqueeze(-1).expand(-1, -1, -1, 2))
+        lin_img = idx2d[..., 0] * 16 + idx2d[..., 1]
+        fused = torch.cat([pc_tok, img_tok, tac_tok], dim=1)
+    else:
+        fused = torch.cat([pc_tok, img_tok, torch.zeros(B, 1, H)], dim=1)
     L_ = "vlm.llm_backbone.llm."
     emb = sd[L_ + "model.embed_tokens.weight"][ids]
     z = torch.cat([emb[:, :1], fused, emb[:, 1:]], dim=1)
@@ -114,6 +129,31 @@ def mla_forward(sd: dict, batch: dict, draws: dict, n_layers: int, n_heads: int,
     diff = ((noise_pred - noise) ** 2).mean()
     total = diff
     extra = {}
+    tac_con = torch.tensor(0.0)
+    if use_tactile and use_contrastive:
+        # TactileContrastiveLoss models/mla/fuser/contrastive.py:241-258 on hidden_states[tap]
+        c = L_ + "tactile_contrastive_loss_module."
+        head = lambda m, v: F.linear(F.relu(F.linear(v, sd[f"{c}{m}_projection_head.0.weight"], sd[f"{c}{m}_projection_head.0.bias"])),  # noqa: E731
+                                     sd[f"{c}{m}_projection_head.2.weight"], sd[f"{c}{m}_projection_head.2.bias"])
+        tp = hidden[tap]
+        tacp = F.normalize(head("tactile", tp[:, 513:514]), p=2, dim=-1)
+        pcp = F.normalize(head("pointcloud", tp[:, 1:257]), p=2, dim=-1)
+        imp = F.normalize(head("image", tp[:, 257:513]), p=2, dim=-1)
+        l_pc = F.cross_entropy((tacp @ pcp.transpose(1, 2) / 0.07).view(-1, 256), pos_pc.view(-1))
+        l_im = F.cross_entropy((tacp @ imp.transpose(1, 2) / 0.07).view(-1, 256), lin_img.view(-1))
+        tac_con = (l_pc + l_im) / 2
+        extra["tactile_contrastive"] = tac_con
+    if gen_tactile:
+        # TactileGenerationModule models/mla/generation/models.py:418-430 + F.mse_loss (prismatic.py:827-835); joins the total before
+        # the contrastive terms (model_mla.py:224-226)
+        from oracle import gen_oracle as G
+        g = P + "generation_manager.tactile_gen_module."
+        mem = F.linear(hn, sd[g + "feature_projector.weight"], sd[g + "feature_projector.bias"])
+        dec = G.transformer_decoder(sd[g + "tactile_query"].expand(B, -1, -1), mem, sd, g + "decoder.", 2, 4)
+        pred = F.linear(dec.squeeze(1), sd[g + "output_head.weight"], sd[g + "output_head.bias"])
+        tgl = F.mse_loss(pred, rep(batch["next_tactile"]).float())
+        total = total + tgl
+        extra["tactile_gen_loss"] = tgl
     if gen_cfg is not None:
         # post-training heads read the normed last hidden state of ALL positions, padding included (prismatic.py:1077, no
         # memory_key_padding_mask); next frames / clouds are tiled R times (model_mla.py:165-170); losses join before the
@@ -123,5 +163,5 @@ def mla_forward(sd: dict, batch: dict, draws: dict, n_layers: int, n_heads: int,
                                                     pfx=P + "generation_manager.")
         total = total + img_loss + pc_loss
         extra = dict(image_gen_loss=img_loss, point_cloud_gen_loss=pc_loss, gen=gx)
-    return dict(total_loss=total + con, diff_mse=diff, contrastive=con, ce=ce, noise_pred=noise_pred, logits=logits,
+    return dict(total_loss=total + con + tac_con, diff_mse=diff, contrastive=con, ce=ce, noise_pred=noise_pred, logits=logits,
                 hidden_states=hidden, patch_indices=patch_idx, valid=valid, mask=mask, labels=flabels, ks=ks, **extra)

@@ -53,7 +53,7 @@ def make_state_dict(shapes: dict, seed: int = 0) -> dict:
 
 
 def make_batch(B: int = 2, L: int = 16, R: int = 2, ragged: bool = True, seed: int = 0, vocab: int = 512, n_points: int = 1024,
-               img: int = 672, with_next: bool = False):
+               img: int = 672, with_next: bool = False, with_tactile: bool = False):
     """Synthetic batch with the collator's schema (util/data_utils.py:179-193) + the random draws of one step."""
     g = _gen("batch", seed)
     rgb = torch.randn(B, 3, img, img, generator=g)
@@ -81,6 +81,11 @@ def make_batch(B: int = 2, L: int = 16, R: int = 2, ragged: bool = True, seed: i
                  fps_start1=torch.randint(0, n_points // 2, (Bp,), generator=g))
     batch = dict(input_ids=ids, attention_mask=attention_mask, labels=labels, images={"front_image": images}, point_cloud=pc,
                  actions=actions, proprio=proprio, action_masks=torch.ones(B, 1, dtype=torch.bool), camera_name="rlbench_front")
+    if with_tactile:      # one arm: 12 tactile channels, gripper position inside the workspace box, next reading for the generation head
+        gt = _gen("tactile", seed)
+        batch["tactile"] = torch.rand(B, 12, generator=gt) * 2 - 1
+        batch["gripper_xyz"] = lo + (hi - lo) * torch.rand(B, 3, generator=gt)
+        batch["next_tactile"] = torch.rand(B, 12, generator=gt) * 2 - 1
     if with_next:
         batch["next_images"] = torch.randn(B, 3, img, img, generator=_gen("next_images", seed))
         batch["next_point_cloud"] = lo + (hi - lo) * torch.rand(B, n_points, 3, generator=_gen("next_pc", seed))

@@ -55,7 +55,7 @@ def setup():
 
 
 def build_reference_mla(cfg_kwargs: dict, token_size: int, use_pointcloud=True, use_contrastive=True, future_action_window_size=0,
-                        generation=None):
+                        generation=None, use_tactile=False):
     """Tiny reference MLA: real PrismaticVLM/MLA/LlamaForCausalLM classes, eager attention, fake tokenizer."""
     setup()
     import torch
@@ -99,8 +99,8 @@ def build_reference_mla(cfg_kwargs: dict, token_size: int, use_pointcloud=True, 
         # USE_GEN=true with USE_TAC=false (scripts/post_rlbench.sh) raises AttributeError; a class-level default lets it build
         PrismaticVLM.tactile_dim = 12
     vlm = PrismaticVLM("tiny", bb, token_size=token_size, action_dim=7, use_diff=True, use_pointcloud=use_pointcloud,
-                       use_contrastive=use_contrastive, future_action_window_size=future_action_window_size, **gen)
+                       use_contrastive=use_contrastive, use_tactile=use_tactile, future_action_window_size=future_action_window_size, **gen)
     flags = {k: gen[k] for k in ("use_generation", "gen_image", "use_roi", "gen_pointcloud", "gen_tactile") if k in gen}
     mla = MLA(vlm, None, token_size=token_size, action_dim=7, future_action_window_size=future_action_window_size, use_diff=True,
-              use_pointcloud=use_pointcloud, use_contrastive=use_contrastive, **flags)
+              use_pointcloud=use_pointcloud, use_contrastive=use_contrastive, use_tactile=use_tactile, **flags)
     return mla

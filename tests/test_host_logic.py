@@ -88,8 +88,13 @@ def test_module_surface_and_state_dict_names():
     assert sum("layers." in u for u in units) == 9 and "vlm.vision_tower_2d" in units and "vlm.projector_3d" in units
     with pytest.raises(ValueError):
         m.freeze_backbones("align")
-    with pytest.raises(NotImplementedError):
-        PrismaticVLM("x", bb, token_size=recipe.TOKEN_SIZE, use_diff=True)                # use_generation defaults to True
+    # the reference's defaults (use_generation=True, gen_pointcloud=True, gen_tactile=True, prismatic.py:167-177) build the generation
+    # manager with the point and tactile heads; use_tactile needs the point cloud
+    full = PrismaticVLM("x", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, pointcloud_trans_dim=64, pointcloud_num_groups=4)
+    assert full.generation_manager.get_module_keys() == ["pointcloud_gen_module", "tactile_gen_module"]
+    assert "generation_manager" in full.all_module_keys and "tactile_embedder" not in full.all_module_keys
+    with pytest.raises(ValueError):
+        PrismaticVLM("x", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_generation=False, use_tactile=True, use_pointcloud=False)
 
 
 def test_lr_schedule_and_camera_constants():

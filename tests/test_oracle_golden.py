@@ -240,3 +240,26 @@ def test_mla_e2e_pretrain_stage_matches_reference():
             g, ref = sd[n].grad, gold[key]
             got = (g.reshape(g.shape[0], -1)[:16, :64] if ref.ndim == 2 else g.reshape(-1)[:256]).numpy()
             assert np.abs(got - ref).max() <= 3e-3 * np.abs(ref).max() + 1e-8, n
+
+
+def test_mla_e2e_tactile_path_matches_reference():
+    """Tactile tokens + TactileContrastiveLoss + TactileGenerationModule (use_tactile, gen_tactile), fp32."""
+    gold = np.load(os.path.join(G, "mla_tiny_e2e_tactile.npz"), allow_pickle=True)
+    sd = {str(n): recipe.det_weight(str(n), eval(str(s))) for n, s in zip(gold["param_names"], gold["param_shapes"])}
+    names = [str(n) for n in gold["grad_names"]]
+    for n in names:
+        sd[n].requires_grad_(True)
+    batch, draws = recipe.make_batch(R=2, with_tactile=True)
+    out = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, zero_pad_rows=False, use_tactile=True, gen_tactile=True)
+    assert abs(float(out["tactile_contrastive"]) - float(gold["A_tactile_contrastive_loss"])) < 5e-5
+    assert abs(float(out["tactile_gen_loss"]) - float(gold["A_tactile_gen_loss"])) < 5e-5
+    assert abs(float(out["contrastive"]) - float(gold["A_img_pc_contrastive_loss"])) < 5e-5
+    assert abs(float(out["total_loss"]) - float(gold["A_total_loss"])) < 1e-4
+    out["total_loss"].backward()
+    norms = np.array([0.0 if sd[n].grad is None else float(sd[n].grad.norm()) for n in names])
+    assert np.allclose(norms, gold["A_gradnorms"], rtol=3e-3, atol=1e-7)
+    for key in gold.files:
+        if key.startswith("A_grad::"):
+            n = key[len("A_grad::"):]
+            g, ref = sd[n].grad, gold[key]
+            assert np.abs(g.reshape(g.shape[0], -1)[:16, :64].numpy() - ref).max() <= 3e-3 * np.abs(ref).max() + 1e-8, n
