@@ -187,6 +187,15 @@ int mla_chamfer_bwd(const float* pred, const float* gt, const float* d1, const i
                     const float* gscale, float* dpred, int B, int N, int M, mla_stream_t stream);
 int mla_imgloss_fwd(const void* delta_raw, int ld, const void* curr, const void* next, int img_fp32, float* sums, int B, int CT_curr,
                     int CT_next, int HW, int ps, float clip, float* workspace, size_t workspace_bytes, mla_stream_t stream);
+/* partial ROI (use_roi = True): per patch either the ROI rule or warp (bilinear translation, border clamp) + alpha blend
+ * (models.py:243-283), with the ROI / background / delta-reward sums of prismatic.py:786-816; backward also yields the alpha / offset
+ * head gradients (one block per patch) */
+int mla_imgroi_fwd(const void* delta_raw, int ld, const void* a_raw, int lda, const void* o_raw, int ldo, const unsigned char* roi,
+                   const void* curr, const void* next, int img_fp32, float* sums, int B, int CT_curr, int CT_next, int HW, int ps,
+                   float clip, float shift, float* workspace, size_t workspace_bytes, mla_stream_t stream);
+int mla_imgroi_bwd(const void* delta_raw, int ld, const void* a_raw, int lda, const void* o_raw, int ldo, const unsigned char* roi,
+                   const void* curr, const void* next, int img_fp32, const float* coef, void* ddelta_raw, float* dalpha_raw,
+                   float* doff_raw, int B, int CT_curr, int CT_next, int HW, int ps, float clip, float shift, mla_stream_t stream);
 int mla_imgloss_bwd(const void* delta_raw, int ld, const void* curr, const void* next, int img_fp32, const float* gscale,
                     void* ddelta_raw, int B, int CT_curr, int CT_next, int HW, int ps, float clip, mla_stream_t stream);
 

@@ -365,6 +365,106 @@ __global__ __launch_bounds__(256) void imgloss_bwd_kernel(const bf16_t* __restri
     ddraw[r * ld + e] = f2bf(g * (2.f * diff + 0.5f * sg - 0.1f * sd) * clip * (1.f - th * th));
   }
 }
+// ---- image generation with a partial ROI (use_roi = True): ImageGenerationModule._generate_generated_patches models.py:226-286
+// + the three image loss terms of compute_generation_losses prismatic.py:780-816. One block per patch (b, p):
+//   ROI patch:     pred = 0.05 * curr + delta                                   -> MSE + 0.5 L1 over ROI elements
+//   other patches: pred = alpha * (warp(curr; tx, ty) + delta) + (1 - alpha) * curr -> 0.01 * L1 over background elements
+//   all patches:   -0.1 * mean |delta|
+// delta = clip * tanh(draw), alpha = sigmoid(a_raw), (tx, ty) = shift * tanh(o_raw); warp = bilinear sample of the 42x42 patch at
+// (x + tx, y + ty) with border clamp (affine_grid + grid_sample(align_corners = True, padding_mode = 'border') of a pure translation).
+// partial[blk][0..4] = { sum diff^2 (ROI), sum |diff| (ROI), sum |diff| (bg), sum |delta|, 0 }
+template <typename TI>
+__device__ __forceinline__ float patch_px(const TI* img, int CT, int HW, int b, int c, int y, int x) {
+  const size_t off = (((size_t)b * CT + c) * HW + y) * HW + x;
+  return sizeof(TI) == 4 ? ((const float*)img)[off] : bf2f(((const bf16_t*)img)[off]);
+}
+// bilinear sample inside the patch whose top-left pixel is (y0, x0); returns value and d/dx, d/dy (zero where the border clamp acts)
+template <typename TI>
+__device__ __forceinline__ float warp_sample(const TI* img, int CT, int HW, int ps, int b, int c, int y0, int x0, float sy, float sx,
+                                             float& ddx, float& ddy) {
+  const float mx = (float)(ps - 1);
+  const bool cx = sx < 0.f || sx > mx, cy = sy < 0.f || sy > mx;
+  sx = fminf(fmaxf(sx, 0.f), mx);
+  sy = fminf(fmaxf(sy, 0.f), mx);
+  int xi = (int)floorf(sx), yi = (int)floorf(sy);
+  const float wx = sx - (float)xi, wy = sy - (float)yi;
+  const int xj = xi + 1 < ps ? xi + 1 : ps - 1, yj = yi + 1 < ps ? yi + 1 : ps - 1;
+  const float p00 = patch_px<TI>(img, CT, HW, b, c, y0 + yi, x0 + xi), p01 = patch_px<TI>(img, CT, HW, b, c, y0 + yi, x0 + xj);
+  const float p10 = patch_px<TI>(img, CT, HW, b, c, y0 + yj, x0 + xi), p11 = patch_px<TI>(img, CT, HW, b, c, y0 + yj, x0 + xj);
+  ddx = cx ? 0.f : ((1.f - wy) * (p01 - p00) + wy * (p11 - p10));
+  ddy = cy ? 0.f : ((1.f - wx) * (p10 - p00) + wx * (p11 - p01));
+  return (1.f - wy) * ((1.f - wx) * p00 + wx * p01) + wy * ((1.f - wx) * p10 + wx * p11);
+}
+// MODE 0: forward partial sums; MODE 1: backward (ddraw per element, d a_raw / d o_raw per patch)
+template <typename TI, int MODE>
+__global__ __launch_bounds__(256) void imgroi_kernel(const bf16_t* __restrict__ draw, int ld, const bf16_t* __restrict__ araw, int lda_,
+                                                     const bf16_t* __restrict__ oraw, int ldo, const unsigned char* __restrict__ roi,
+                                                     const TI* __restrict__ curr, const TI* __restrict__ next, float* __restrict__ partial,
+                                                     const float* __restrict__ coef, bf16_t* __restrict__ ddraw,
+                                                     float* __restrict__ dalpha_raw, float* __restrict__ doff_raw, int CTc, int CTn, int HW,
+                                                     int ps, int npatch, float clip, float shift) {
+  __shared__ float scratch[16];
+  const int bp = blockIdx.x, b = bp / npatch, patch = bp % npatch;
+  const int g = HW / ps, py = patch / g, px = patch % g, y0 = py * ps, x0 = px * ps;
+  const bool in_roi = roi[bp] != 0;
+  const float alpha = 1.f / (1.f + __expf(-bf2f(araw[(size_t)bp * lda_])));
+  const float ttx = tanhf(bf2f(oraw[(size_t)bp * ldo])), tty = tanhf(bf2f(oraw[(size_t)bp * ldo + 1]));
+  const float tx = shift * ttx, ty = shift * tty;
+  const int pd = 3 * ps * ps;
+  // coef (MODE 1) = { g / n_roi, g / n_bg * 0.01, g * (-0.1) / n_all } -- zero where a term is absent
+  const float k_roi = MODE ? coef[0] : 0.f, k_bg = MODE ? coef[1] : 0.f, k_dl = MODE ? coef[2] : 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, ga = 0.f, gx = 0.f, gy = 0.f;
+  for (int e = threadIdx.x; e < pd; e += 256) {
+    const int c = e / (ps * ps), rem = e % (ps * ps), yy = rem / ps, xx = rem % ps;
+    const float th = tanhf(bf2f(draw[(size_t)bp * ld + e]));
+    const float delta = clip * th;
+    const float cv = patch_px<TI>(curr, CTc, HW, b, c, y0 + yy, x0 + xx);
+    const float nv = patch_px<TI>(next, CTn, HW, b, c, y0 + yy, x0 + xx);
+    float gdelta;
+    if (in_roi) {
+      const float diff = 0.05f * cv + delta - nv;
+      s0 += diff * diff; s1 += fabsf(diff);
+      gdelta = k_roi * (2.f * diff + 0.5f * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)));
+    } else {
+      float ddx, ddy;
+      const float wv = warp_sample<TI>(curr, CTc, HW, ps, b, c, y0, x0, (float)yy + ty, (float)xx + tx, ddx, ddy);
+      const float diff = alpha * (wv + delta) + (1.f - alpha) * cv - nv;
+      s2 += fabsf(diff);
+      const float gp = k_bg * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+      gdelta = gp * alpha;
+      ga += gp * (wv + delta - cv);
+      gx += gp * alpha * ddx;
+      gy += gp * alpha * ddy;
+    }
+    s3 += fabsf(delta);
+    if (MODE) {
+      gdelta += k_dl * (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f));
+      ddraw[(size_t)bp * ld + e] = f2bf(gdelta * clip * (1.f - th * th));
+    }
+  }
+  if (MODE == 0) {
+    s0 = block_sum(s0, scratch); s1 = block_sum(s1, scratch); s2 = block_sum(s2, scratch); s3 = block_sum(s3, scratch);
+    if (threadIdx.x == 0) { float* o = partial + (size_t)bp * 4; o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; }
+  } else {
+    ga = block_sum(ga, scratch); gx = block_sum(gx, scratch); gy = block_sum(gy, scratch);
+    if (threadIdx.x == 0) {
+      dalpha_raw[bp] = ga * alpha * (1.f - alpha);
+      doff_raw[(size_t)bp * 2] = gx * shift * (1.f - ttx * ttx);
+      doff_raw[(size_t)bp * 2 + 1] = gy * shift * (1.f - tty * tty);
+    }
+    for (int e = pd + threadIdx.x; e < ld; e += 256) ddraw[(size_t)bp * ld + e] = 0;      // padding columns
+  }
+}
+__global__ __launch_bounds__(256) void sum4_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int P) {
+  __shared__ float scratch[16];
+  for (int k = 0; k < 4; ++k) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < P; i += 256) s += partial[(size_t)i * 4 + k];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void sum3_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int P) {
   __shared__ float scratch[16];
   for (int k = 0; k < 3; ++k) {
@@ -514,5 +614,46 @@ extern "C" int mla_imgloss_bwd(const void* delta_raw, int ld, const void* curr, 
   else
     hipLaunchKernelGGL(imgloss_bwd_kernel<bf16_t>, dim3(gridn(n)), dim3(256), 0, stream, (const bf16_t*)delta_raw, (const bf16_t*)curr,
                        (const bf16_t*)next, gscale, (bf16_t*)ddelta_raw, B, CT_curr, CT_next, HW, ps, npatch, clip, ld);
+  MLA_LAUNCH_CHECK();
+}
+
+// sums[4] = { sum diff^2 over ROI elements, sum |diff| over ROI, sum |diff| over background, sum |delta| over all };
+// roi [B * npatch] bytes (non-zero = patch inside the dilated ROI); a_raw / o_raw are the alpha / offset head outputs (row pitches
+// lda / ldo elements, columns 0 and 0..1 used); workspace >= B * npatch * 4 floats
+extern "C" int mla_imgroi_fwd(const void* delta_raw, int ld, const void* a_raw, int lda, const void* o_raw, int ldo,
+                              const unsigned char* roi, const void* curr, const void* next, int img_fp32, float* sums, int B, int CT_curr,
+                              int CT_next, int HW, int ps, float clip, float shift, float* workspace, size_t workspace_bytes,
+                              hipStream_t stream) {
+  MLA_CHECK_ARG(delta_raw && a_raw && o_raw && roi && curr && next && sums && workspace && HW % ps == 0 && ld >= 3 * ps * ps && ldo >= 2,
+                "mla_imgroi_fwd: bad args");
+  const int npatch = (HW / ps) * (HW / ps);
+  MLA_CHECK_ARG(workspace_bytes >= (size_t)B * npatch * 4 * sizeof(float), "mla_imgroi_fwd: workspace too small");
+  if (img_fp32)
+    hipLaunchKernelGGL((imgroi_kernel<float, 0>), dim3(B * npatch), dim3(256), 0, stream, (const bf16_t*)delta_raw, ld, (const bf16_t*)a_raw, lda,
+                       (const bf16_t*)o_raw, ldo, roi, (const float*)curr, (const float*)next, workspace, nullptr, nullptr, nullptr, nullptr,
+                       CT_curr, CT_next, HW, ps, npatch, clip, shift);
+  else
+    hipLaunchKernelGGL((imgroi_kernel<bf16_t, 0>), dim3(B * npatch), dim3(256), 0, stream, (const bf16_t*)delta_raw, ld, (const bf16_t*)a_raw, lda,
+                       (const bf16_t*)o_raw, ldo, roi, (const bf16_t*)curr, (const bf16_t*)next, workspace, nullptr, nullptr, nullptr, nullptr,
+                       CT_curr, CT_next, HW, ps, npatch, clip, shift);
+  hipLaunchKernelGGL(sum4_final_kernel, dim3(1), dim3(256), 0, stream, workspace, sums, B * npatch);
+  MLA_LAUNCH_CHECK();
+}
+// coef[3] (device) = { g / n_roi_elems, 0.01 * g / n_bg_elems, -0.1 * g / n_all_elems } (zero where a term is absent);
+// outputs: ddelta_raw [B, npatch, ld] bf16 (padding columns zeroed), dalpha_raw [B * npatch] fp32, doff_raw [B * npatch, 2] fp32
+extern "C" int mla_imgroi_bwd(const void* delta_raw, int ld, const void* a_raw, int lda, const void* o_raw, int ldo,
+                              const unsigned char* roi, const void* curr, const void* next, int img_fp32, const float* coef,
+                              void* ddelta_raw, float* dalpha_raw, float* doff_raw, int B, int CT_curr, int CT_next, int HW, int ps,
+                              float clip, float shift, hipStream_t stream) {
+  MLA_CHECK_ARG(delta_raw && a_raw && o_raw && roi && curr && next && coef && ddelta_raw && dalpha_raw && doff_raw, "mla_imgroi_bwd: null pointer");
+  const int npatch = (HW / ps) * (HW / ps);
+  if (img_fp32)
+    hipLaunchKernelGGL((imgroi_kernel<float, 1>), dim3(B * npatch), dim3(256), 0, stream, (const bf16_t*)delta_raw, ld, (const bf16_t*)a_raw, lda,
+                       (const bf16_t*)o_raw, ldo, roi, (const float*)curr, (const float*)next, nullptr, coef, (bf16_t*)ddelta_raw, dalpha_raw,
+                       doff_raw, CT_curr, CT_next, HW, ps, npatch, clip, shift);
+  else
+    hipLaunchKernelGGL((imgroi_kernel<bf16_t, 1>), dim3(B * npatch), dim3(256), 0, stream, (const bf16_t*)delta_raw, ld, (const bf16_t*)a_raw, lda,
+                       (const bf16_t*)o_raw, ldo, roi, (const bf16_t*)curr, (const bf16_t*)next, nullptr, coef, (bf16_t*)ddelta_raw, dalpha_raw,
+                       doff_raw, CT_curr, CT_next, HW, ps, npatch, clip, shift);
   MLA_LAUNCH_CHECK();
 }

@@ -8,10 +8,11 @@ re-implemented on the HIP kernels: MFMA GEMMs for the projections, batched MFMA 
 the attention products, LayerNorm / BatchNorm / dropout / chamfer / image-loss kernels from csrc/gen.hip.
 
 Scope notes
-* ``use_roi=True`` (patch warp via affine_grid/grid_sample, models.py:243-262, and the background loss prismatic.py:798-806)
-  is not built: scripts/post_rlbench.sh:26 ships USE_ROI=false, for which every patch is inside the ROI, the warp / alpha /
-  offset branches are dead and the generated patch is ``0.05 * current + 5 * tanh(delta)``. The image head therefore returns
-  the raw delta logits and the loss kernel fuses tanh, the blend, images_to_patches addressing and the three reductions.
+* scripts/post_rlbench.sh:26 ships USE_ROI=false: every patch is inside the ROI, the warp / alpha / offset branches are dead and the
+  generated patch is ``0.05 * current + 5 * tanh(delta)``; the image head returns the raw delta logits and one loss kernel fuses
+  tanh, the blend, images_to_patches addressing and the three reductions (mla_imgloss_*). ``use_roi=True`` (dilated ROI from the
+  projected point centres, translation warp via affine_grid/grid_sample, alpha blend, background loss) runs through a second pair
+  of kernels (mla_imgroi_*: one block per patch, bilinear sample with border clamp, gradients for delta / alpha / offsets).
 * TactileGenerationModule (models.py:389-430) is built although no BASELINE config enables it (GEN_TAC=false: no tactile sensor in
   the simulator); its single-query attention runs on the SIMT GEMM fallback.
 """
@@ -149,22 +150,34 @@ class ImageGenerationModule(nn.Module):
         nn.init.constant_(self.mae_offset_head.bias, 0.0)
 
     def forward(self, llm_hidden_states, current_image_features=None, current_images_patches=None, roi_mask_2d=None):
-        if self.use_roi:
-            raise NotImplementedError("use_roi=True (dilated ROI + patch warp, models.py:172-174,243-262): scripts/post_rlbench.sh "
-                                      "ships USE_ROI=false; only the all-true ROI is built")
         B = llm_hidden_states.shape[0]
         dt = llm_hidden_states.dtype
         intent = self.intent_decoder(self.image_gen_queries.to(dt).expand(B, -1, -1).contiguous(), llm_hidden_states)
-        # every patch is inside the ROI -> every decoder input token is the mask token (+ position), models.py:183-186
-        tokens = (self.mae_mask_token + self.mae_pos_embed).to(dt).expand(B, -1, -1).contiguous()
+        out = {}
+        if self.use_roi:
+            # models.py:172-186: dilate the ROI (3x3 max-pool on the 16x16 patch grid), put the mask token on ROI positions and keep
+            # the current image features elsewhere (those keep their gradient path). [B, 256]-sized mask logic: torch.
+            pad = (self.roi_dilation_kernel_size - 1) // 2
+            roi = (F.max_pool2d(roi_mask_2d.float().unsqueeze(1), self.roi_dilation_kernel_size, 1, pad) > 0).view(B, -1)
+            tokens = torch.where(roi.unsqueeze(-1), self.mae_mask_token.to(dt), current_image_features.to(dt)) + self.mae_pos_embed.to(dt)
+            tokens = tokens.contiguous()
+        else:
+            # every patch is inside the ROI -> every decoder input token is the mask token (+ position), models.py:183-186
+            roi = torch.ones((B, self.image_num_patches), dtype=torch.bool, device=llm_hidden_states.device)
+            tokens = (self.mae_mask_token + self.mae_pos_embed).to(dt).expand(B, -1, -1).contiguous()
         feats = self.mae_decoder(tokens, intent)
         fn = ops.layernorm(feats, self.mae_patch_norm.weight, self.mae_patch_norm.bias, self.mae_patch_norm.eps)
         # [B, 256, ld]: 3*ps*ps = 5292 valid columns, padded to ld = 5312 so every GEMM of the head stays on the MFMA path
-        delta_raw = ops.PaddedLinearFn.apply(fn, self.mae_delta_head.weight, self.mae_delta_head.bias)
-        roi = torch.ones((B, self.image_num_patches), dtype=torch.bool, device=delta_raw.device)
-        # alpha / offset heads (models.py:199-200) only act outside the ROI: with the all-true mask they feed nothing, get no
-        # gradient in the reference either, and are not evaluated here.
-        return {"delta_raw": delta_raw, "generation_roi_mask": roi, "norm_features": fn}
+        out["delta_raw"] = ops.PaddedLinearFn.apply(fn, self.mae_delta_head.weight, self.mae_delta_head.bias)
+        if self.use_roi:
+            # alpha / offset heads (1 and 2 outputs, models.py:199-200) act on the non-ROI patches; padded to 64 columns like the delta head
+            out["alpha_raw"] = ops.PaddedLinearFn.apply(fn, self.mae_alpha_head.weight, self.mae_alpha_head.bias)
+            out["offset_raw"] = ops.PaddedLinearFn.apply(fn, self.mae_offset_head.weight, self.mae_offset_head.bias)
+        # with the all-true mask (use_roi False) the alpha / offset heads feed nothing, get no gradient in the reference either,
+        # and are not evaluated
+        out["generation_roi_mask"] = roi
+        out["norm_features"] = fn
+        return out
 
     @torch.no_grad()
     def materialize(self, outputs: Dict[str, torch.Tensor], current_images_patches: torch.Tensor) -> Dict[str, torch.Tensor]:

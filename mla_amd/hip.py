@@ -557,6 +557,10 @@ register_signatures({
     "mla_chamfer_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mla_imgloss_fwd": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                         c_size_t, c_void_p],
+    "mla_imgroi_fwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                       c_int, c_int, c_float, c_float, c_void_p, c_size_t, c_void_p],
+    "mla_imgroi_bwd": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p],
     "mla_imgloss_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                         c_void_p],
 })
@@ -707,3 +711,28 @@ def avgpool_tokens_bwd(dy, other, B, gh, gw, cs):
     dx = torch.empty((B * gh * gw, C), dtype=torch.bfloat16, device=dy.device)
     call("mla_avgpool_tokens_bwd", _p(dy), _p(other), _p(dx), B, gh, gw, C, cs)
     return dx
+
+
+def imgroi_fwd(delta_raw, a_raw, o_raw, roi_u8, curr, nxt, ps, clip, shift):
+    """sums[4] = ROI sum diff^2, ROI sum |diff|, background sum |diff|, sum |delta| (see mla_imgroi_fwd)."""
+    B, npatch, ld = delta_raw.shape
+    if curr.dtype != nxt.dtype or curr.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("imgroi: curr/next images must both be fp32 or both bf16")
+    sums = torch.empty(4, dtype=torch.float32, device=delta_raw.device)
+    ws = workspace(B * npatch * 16, delta_raw.device)
+    call("mla_imgroi_fwd", _p(delta_raw), ld, _p(a_raw), a_raw.stride(0), _p(o_raw), o_raw.stride(0), _p(roi_u8), _p(curr), _p(nxt),
+         1 if curr.dtype == torch.float32 else 0, _p(sums), B, curr.shape[1], nxt.shape[1], curr.shape[2], ps, float(clip), float(shift), _p(ws),
+         ws.numel())
+    return sums
+
+
+def imgroi_bwd(delta_raw, a_raw, o_raw, roi_u8, curr, nxt, ps, clip, shift, coef):
+    B, npatch, ld = delta_raw.shape
+    dev = delta_raw.device
+    dd = torch.empty_like(delta_raw)
+    da = torch.empty(B * npatch, dtype=torch.float32, device=dev)
+    do = torch.empty((B * npatch, 2), dtype=torch.float32, device=dev)
+    call("mla_imgroi_bwd", _p(delta_raw), ld, _p(a_raw), a_raw.stride(0), _p(o_raw), o_raw.stride(0), _p(roi_u8), _p(curr), _p(nxt),
+         1 if curr.dtype == torch.float32 else 0, _p(coef), _p(dd), _p(da), _p(do), B, curr.shape[1], nxt.shape[1], curr.shape[2], ps,
+         float(clip), float(shift))
+    return dd, da, do

@@ -939,3 +939,43 @@ class BmmNTFn(torch.autograd.Function):
         hip.gemm_batched(dcb, a, db, M=N, N=K, K=M, lda=N, ldb=K, ldc=K, a_mode=1, b_mode=1, alpha=ctx.alpha, n_outer=nb, n_inner=1,
                          sA=(M * N, 0), sB=(M * K, 0), sC=(N * K, 0))
         return da, db, None
+
+
+class ImageGenRoiLossFn(torch.autograd.Function):
+    """Image generation with a partial ROI (use_roi=True): ROI patches follow `0.05 * current + delta`, the others are the
+    alpha-blend of the current patch with its translated (warped) copy + delta (models/mla/generation/models.py:226-286); loss =
+    MSE + 0.5 L1 on ROI elements + 0.01 L1 on background elements - 0.1 mean|delta| (models/vlm/prismatic.py:786-816; a term whose
+    set is empty is dropped). Returns (loss, parts = [roi mse, roi l1, bg l1, mean|delta|])."""
+
+    @staticmethod
+    def forward(ctx, delta_raw, a_raw, o_raw, roi_mask, curr_img, next_img, ps, clip, shift):
+        _check_bf16_cuda(delta_raw, a_raw, o_raw)
+        delta_raw, a_raw, o_raw = delta_raw.contiguous(), a_raw.contiguous(), o_raw.contiguous()
+        B, npatch = delta_raw.shape[0], delta_raw.shape[1]
+        pd = 3 * ps * ps
+        roi = roi_mask.reshape(B * npatch).to(torch.uint8).contiguous()
+        a2, o2 = a_raw.reshape(B * npatch, -1), o_raw.reshape(B * npatch, -1)
+        sums = hip.imgroi_fwd(delta_raw, a2, o2, roi, curr_img, next_img, ps, clip, shift)
+        n_roi = roi.sum().to(torch.float32) * pd
+        n_all = float(B * npatch * pd)
+        n_bg = n_all - n_roi
+        inv_roi = torch.where(n_roi > 0, 1.0 / n_roi.clamp(min=1.0), torch.zeros_like(n_roi))
+        inv_bg = torch.where(n_bg > 0, 1.0 / n_bg.clamp(min=1.0), torch.zeros_like(n_bg))
+        parts = torch.stack([sums[0] * inv_roi, sums[1] * inv_roi, sums[2] * inv_bg, sums[3] / n_all])
+        loss = parts[0] + 0.5 * parts[1] + 0.01 * parts[2] - 0.1 * parts[3]
+        ctx.save_for_backward(delta_raw, a2, o2, roi, curr_img, next_img, torch.stack([inv_roi, 0.01 * inv_bg, inv_roi.new_tensor(-0.1 / n_all)]))
+        ctx.meta = (ps, clip, shift, a_raw.shape, o_raw.shape)
+        ctx.mark_non_differentiable(parts)
+        return loss, parts
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        delta_raw, a2, o2, roi, curr_img, next_img, k = ctx.saved_tensors
+        ps, clip, shift, ashape, oshape = ctx.meta
+        coef = (k * g.to(torch.float32)).contiguous()
+        dd, da, do = hip.imgroi_bwd(delta_raw, a2, o2, roi, curr_img, next_img, ps, clip, shift, coef)
+        da_full = torch.zeros(a2.shape, dtype=BF16, device=a2.device)
+        da_full[:, 0] = da.to(BF16)
+        do_full = torch.zeros(o2.shape, dtype=BF16, device=o2.device)
+        do_full[:, :2] = do.to(BF16)
+        return dd, da_full.view(ashape), do_full.view(oshape), None, None, None, None, None, None

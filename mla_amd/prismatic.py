@@ -276,10 +276,19 @@ class PrismaticVLM(nn.Module):
             assert cur.shape[-1] == cur.shape[-2] == 672 and nxt.shape[1] == 3, "Expected 672x672 RGB frames"   # utils.py:10-11
             if cur.dtype != nxt.dtype:
                 nxt = nxt.to(cur.dtype)
-            loss, parts = ops.ImageGenLossFn.apply(generation_outputs["delta_raw"], cur.contiguous(), nxt.contiguous(),
-                                                   mod.image_patch_size, float(mod.gen_delta_clip))
-            losses["image_roi_generation_loss"] = (parts[0] + 0.5 * parts[1]).detach()
-            losses["delta_magnitude_reward"] = (-0.1 * parts[2]).detach()
+            if mod.use_roi:
+                loss, parts = ops.ImageGenRoiLossFn.apply(generation_outputs["delta_raw"], generation_outputs["alpha_raw"],
+                                                          generation_outputs["offset_raw"], generation_outputs["generation_roi_mask"],
+                                                          cur.contiguous(), nxt.contiguous(), mod.image_patch_size,
+                                                          float(mod.gen_delta_clip), float(mod.max_patch_shift_pixels))
+                losses["image_roi_generation_loss"] = (parts[0] + 0.5 * parts[1]).detach()
+                losses["bg_consistency_loss"] = (0.01 * parts[2]).detach()
+                losses["delta_magnitude_reward"] = (-0.1 * parts[3]).detach()
+            else:
+                loss, parts = ops.ImageGenLossFn.apply(generation_outputs["delta_raw"], cur.contiguous(), nxt.contiguous(),
+                                                       mod.image_patch_size, float(mod.gen_delta_clip))
+                losses["image_roi_generation_loss"] = (parts[0] + 0.5 * parts[1]).detach()
+                losses["delta_magnitude_reward"] = (-0.1 * parts[2]).detach()
             losses["image_gen_loss"] = loss
             total = total + loss
         if self.gen_pointcloud and next_point_cloud is not None and "pointcloud_coord_generation" in generation_outputs:
@@ -353,9 +362,15 @@ class PrismaticVLM(nn.Module):
         generation_losses: Dict[str, torch.Tensor] = {}
         if self.use_generation and (self.gen_image or self.gen_pointcloud or self.gen_tactile) and self.training:
             front = (images["front_image"] if isinstance(images, dict) else images)
+            roi_mask_2d = None
+            if self.gen_image and self.use_roi:
+                # create_roi_mask_from_indices models/mla/generation/utils.py:46-64: the patches the point centres project to
+                roi_mask_2d = torch.zeros((patch_indices.shape[0], 16, 16), dtype=torch.bool, device=patch_indices.device)
+                bidx = torch.arange(patch_indices.shape[0], device=patch_indices.device).view(-1, 1)
+                roi_mask_2d[bidx, patch_indices[..., 0], patch_indices[..., 1]] = True
             generation_outputs = self.generation_manager(
                 llm_hidden_states=last_hidden, current_image_features=parts[1], current_images_patches=None,
-                current_point_cloud=None, roi_mask_2d=None)
+                current_point_cloud=None, roi_mask_2d=roi_mask_2d)
             if self.gen_image:
                 assert next_images is not None
                 generation_outputs["current_front_image"] = front

@@ -132,3 +132,54 @@ def generation_losses(hidden, curr_images, next_images, next_pc, sd: Dict[str, t
                                 cfg["pc_group_size"])
     pc_loss = chamfer_distance_l2(pts.float(), next_pc.float())
     return img_loss, pc_loss, dict(delta_all=delta, points=pts, **parts)
+
+
+def image_generation_roi(hidden, image_features, roi_mask_2d, sd, pfx, nheads, n_intent_layers=2, n_mae_layers=3, clip=5.0, shift=8.0,
+                         dilation=3):
+    """ImageGenerationModule.forward models.py:158-224 with use_roi=True: dilated ROI (utils.py:35-44), mask tokens on ROI positions,
+    delta / alpha / offset heads. Returns (delta_all, alpha_all, offset_all, roi_flat)."""
+    B = hidden.shape[0]
+    intent = transformer_decoder(sd[pfx + "image_gen_queries"].expand(B, -1, -1), hidden, sd, pfx + "intent_decoder.", n_intent_layers, nheads)
+    pad = (dilation - 1) // 2
+    roi = (F.max_pool2d(roi_mask_2d.float().unsqueeze(1), dilation, 1, pad) > 0).view(B, -1)
+    tokens = torch.where(roi.unsqueeze(-1), sd[pfx + "mae_mask_token"].view(1, 1, -1), image_features) + sd[pfx + "mae_pos_embed"]
+    feats = transformer_decoder(tokens, intent, sd, pfx + "mae_decoder.", n_mae_layers, nheads)
+    fn = _ln(feats, sd, pfx + "mae_patch_norm.")
+    delta = torch.tanh(F.linear(fn, sd[pfx + "mae_delta_head.weight"], sd[pfx + "mae_delta_head.bias"])) * clip
+    alpha = torch.sigmoid(F.linear(fn, sd[pfx + "mae_alpha_head.weight"], sd[pfx + "mae_alpha_head.bias"]).squeeze(-1))
+    offset = torch.tanh(F.linear(fn, sd[pfx + "mae_offset_head.weight"], sd[pfx + "mae_offset_head.bias"])) * shift
+    return delta, alpha, offset, roi
+
+
+def image_generation_roi_loss(delta, alpha, offset, roi, curr_images, next_images, ps=42):
+    """_generate_generated_patches models.py:226-286 (translation warp through affine_grid / grid_sample, align_corners=True,
+    border padding) + the image terms of compute_generation_losses prismatic.py:780-816."""
+    curr = images_to_patches(curr_images[:, :3], ps)
+    nxt = images_to_patches(next_images, ps)
+    B, P, _ = curr.shape
+    cimg = curr.reshape(B * P, 3, ps, ps)
+    off = offset.reshape(B * P, 2)
+    theta = torch.zeros(B * P, 2, 3)
+    theta[:, 0, 0] = 1.0
+    theta[:, 1, 1] = 1.0
+    theta[:, 0, 2] = 2.0 * off[:, 0] / float(ps - 1)
+    theta[:, 1, 2] = 2.0 * off[:, 1] / float(ps - 1)
+    grid = F.affine_grid(theta, size=(B * P, 3, ps, ps), align_corners=True)
+    warped = F.grid_sample(cimg.float(), grid, mode="bilinear", padding_mode="border", align_corners=True)
+    dimg = delta.reshape(B * P, 3, ps, ps)
+    roi_pred = 0.05 * (cimg + dimg) + 0.95 * dimg
+    non_roi = warped + dimg
+    m = roi.reshape(B * P, 1, 1, 1)
+    pred = torch.where(m, roi_pred, non_roi)
+    a = torch.where(roi, torch.ones_like(alpha), alpha).reshape(B * P, 1, 1, 1)
+    gen = (a * pred + (1.0 - a) * cimg).reshape(B, P, -1)
+    total = 0.0
+    parts = {}
+    if roi.any():
+        parts["roi"] = F.mse_loss(gen[roi], nxt[roi]) + 0.5 * F.l1_loss(gen[roi], nxt[roi])
+        total = total + parts["roi"]
+    if (~roi).any():
+        parts["bg"] = 0.01 * F.l1_loss(gen[~roi], nxt[~roi])
+        total = total + parts["bg"]
+    parts["delta"] = -0.1 * delta.abs().mean()
+    return total + parts["delta"], parts

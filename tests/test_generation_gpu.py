@@ -379,3 +379,88 @@ def test_post_training_step_through_fsdp(dev):
     l2 = strat.train_step(b)
     for k in ("total_loss", "image_gen_loss", "point_cloud_gen_loss"):
         assert math.isfinite(float(l1[k])) and math.isfinite(float(l2[k]))
+
+
+# ------------------------------------------------------------------------------------------------- use_roi = True
+def _roi_inputs(B=4):
+    g = recipe._gen("gen.roi")
+    feats = recipe.det_randn("gen.img_feats", (B, 256, recipe.TOKEN_SIZE))
+    idx = torch.randint(3, 12, (B, 24, 2), generator=g)
+    m = torch.zeros(B, 16, 16, dtype=torch.bool)
+    m[torch.arange(B).view(-1, 1), idx[..., 0], idx[..., 1]] = True
+    return feats, m
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF])
+def test_image_roi_loss_kernels_vs_oracle_autograd(dev, dtype):
+    """mla_imgroi_fwd / bwd (warp + blend + three loss terms) against autograd through the oracle's affine_grid / grid_sample form."""
+    from mla_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    draw = bfr(B, 256, 5312, seed=1)
+    araw = (torch.randn(B, 256, 64, generator=g)).to(BF)
+    oraw = (torch.randn(B, 256, 64, generator=g) * 0.3).to(BF)
+    roi = torch.rand(B, 256, generator=g) < 0.35
+    curr = torch.randn(B, 4, 672, 672, generator=g).to(dtype)
+    nxt = torch.randn(B, 3, 672, 672, generator=g).to(dtype)
+    dr, ar, orr = draw.float().requires_grad_(), araw.float().requires_grad_(), oraw.float().requires_grad_()
+    ref, parts = gen_oracle.image_generation_roi_loss(torch.tanh(dr[..., :5292]) * 5.0, torch.sigmoid(ar[..., 0]), torch.tanh(orr[..., :2]) * 8.0,
+                                                      roi, curr.float(), nxt.float())
+    ref.backward()
+    dd, ad, od = draw.to(dev).requires_grad_(), araw.to(dev).requires_grad_(), oraw.to(dev).requires_grad_()
+    loss, p = ops.ImageGenRoiLossFn.apply(dd, ad, od, roi.to(dev), curr.to(dev), nxt.to(dev), 42, 5.0, 8.0)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 2e-4 * abs(float(ref))
+    assert abs(float(p[0] + 0.5 * p[1]) - float(parts["roi"])) < 2e-4 * float(parts["roi"])
+    assert abs(float(0.01 * p[2]) - float(parts["bg"])) < 2e-4 * float(parts["bg"])
+    assert fro_rel(dd.grad[..., :5292], dr.grad[..., :5292]) < 8e-3 and float(dd.grad[..., 5292:].float().abs().max()) == 0.0
+    assert fro_rel(ad.grad[..., 0], ar.grad[..., 0]) < 1e-2 and float(ad.grad[..., 1:].float().abs().max()) == 0.0
+    assert fro_rel(od.grad[..., :2], orr.grad[..., :2]) < 2e-2
+    # all-ROI and no-ROI extremes: the absent term is dropped, not NaN
+    for mask in (torch.ones(B, 256, dtype=torch.bool), torch.zeros(B, 256, dtype=torch.bool)):
+        l2, _ = ops.ImageGenRoiLossFn.apply(dd.detach(), ad.detach(), od.detach(), mask.to(dev), curr.to(dev), nxt.to(dev), 42, 5.0, 8.0)
+        r2, _ = gen_oracle.image_generation_roi_loss(torch.tanh(draw.float()[..., :5292]) * 5.0, torch.sigmoid(araw.float()[..., 0]),
+                                                     torch.tanh(oraw.float()[..., :2]) * 8.0, mask, curr.float(), nxt.float())
+        assert abs(float(l2) - float(r2)) < 2e-4 * abs(float(r2))
+
+
+def test_image_generation_with_roi_against_reference_golden(dev):
+    from mla_amd import ops
+    from mla_amd.generation import ImageGenerationModule
+    gold = np.load(os.path.join(G, "generation_roi.npz"), allow_pickle=True)
+    pfx = "vlm.generation_manager.image_gen_module."
+    g = recipe.GEN_TINY
+    mod = ImageGenerationModule(token_size=recipe.TOKEN_SIZE, num_gen_queries=g["num_image_gen_queries"], decoder_layers=g["image_decoder_layers"],
+                                decoder_heads=g["image_decoder_heads"], image_patch_size=42, use_roi=True, roi_dilation_kernel_size=3)
+    sd = {k: recipe.det_weight(pfx + k, v.shape) for k, v in mod.state_dict().items()}
+    sd["mae_alpha_head.bias"] = torch.zeros(1)
+    mod.load_state_dict(sd, strict=True)
+    _zero_dropout(mod)
+    mod.train().to(dev)
+    for p in mod.parameters():
+        p.data = p.data.to(BF)
+    hidden, curr, nxt, _ = _gen_inputs()
+    feats, roi2d = _roi_inputs()
+    hd, fd = hidden.to(dev, BF).requires_grad_(), feats.to(dev, BF).requires_grad_()
+    outs = mod(hd, current_image_features=fd, roi_mask_2d=roi2d.to(dev))
+    assert np.array_equal(outs["generation_roi_mask"].cpu().numpy(), gold["A_roi_mask"])
+    loss, parts = ops.ImageGenRoiLossFn.apply(outs["delta_raw"], outs["alpha_raw"], outs["offset_raw"], outs["generation_roi_mask"],
+                                              curr.to(dev, BF), nxt.to(dev, BF), 42, 5.0, 8.0)
+    loss.backward()
+
+    def err(a, ref):
+        return float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
+    A, C = float(gold["A_image_gen_loss"]), float(gold["C_image_gen_loss"])
+    assert abs(float(loss) - A) < 2 * abs(C - A) + 2e-2
+    assert abs(float(0.01 * parts[2]) - float(gold["A_bg_consistency_loss"])) < 2 * abs(float(gold["C_bg_consistency_loss"]) - float(gold["A_bg_consistency_loss"])) + 5e-4
+    alpha = torch.sigmoid(outs["alpha_raw"][..., 0].float()).detach().cpu().numpy()
+    assert err(alpha, gold["A_alpha"]) < 2 * err(gold["C_alpha"], gold["A_alpha"]) + 1e-2
+    assert err(hd.grad.float().cpu().numpy(), gold["A_hidden_grad"]) < 2 * err(gold["C_hidden_grad"], gold["A_hidden_grad"]) + 3e-2
+    assert err(fd.grad.float().cpu().numpy(), gold["A_feats_grad"]) < 2 * err(gold["C_feats_grad"], gold["A_feats_grad"]) + 3e-2
+    grads = {k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+    names = [str(n)[len("image_gen_module."):] for n in gold["grad_names"]]
+    Ag, Cg = gold["A_gradnorms"], gold["C_gradnorms"]
+    gn = np.array([float(grads[k].float().norm()) if k in grads else 0.0 for k in names])
+    relA, relC = np.abs(gn - Ag) / (Ag + 1e-12), np.abs(Cg - Ag) / (Ag + 1e-12)
+    assert np.median(relA) < 2 * np.median(relC) + 5e-3, (np.median(relA), np.median(relC))
+    assert (relA < 2 * relC + 6e-2).mean() > 0.95, [(n, a, c) for n, a, c in zip(names, relA, relC) if a >= 2 * c + 6e-2][:6]

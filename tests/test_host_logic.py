@@ -150,11 +150,9 @@ def test_post_training_model_keys_and_freeze():
     trainable = {n for n, p in m.named_parameters() if p.requires_grad}
     assert set(str(n) for n in gold["grad_names"]) <= trainable
     assert not any(n.startswith("vlm.vision_tower_2d") or n.startswith("vlm.vision_tower_3d") for n in trainable)
-    import pytest
-    with pytest.raises(NotImplementedError):
-        PrismaticVLM("tiny", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_generation=True, gen_image=True, use_roi=True,
-                     gen_pointcloud=False, gen_tactile=False, **recipe.GEN_TINY).generation_manager.image_gen_module(
-            torch.zeros(1, 8, recipe.TOKEN_SIZE))
+    roi_vlm = PrismaticVLM("tiny", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_generation=True, gen_image=True, use_roi=True,
+                           gen_pointcloud=False, gen_tactile=False, **recipe.GEN_TINY)
+    assert roi_vlm.generation_manager.image_gen_module.use_roi and roi_vlm.use_roi
 
 
 def test_hf_llama_weight_files_load_into_backbone(tmp_path):

@@ -263,3 +263,49 @@ def test_mla_e2e_tactile_path_matches_reference():
             n = key[len("A_grad::"):]
             g, ref = sd[n].grad, gold[key]
             assert np.abs(g.reshape(g.shape[0], -1)[:16, :64].numpy() - ref).max() <= 3e-3 * np.abs(ref).max() + 1e-8, n
+
+
+def roi_inputs(B=4):
+    """Same recipe as oracle/capture_golden_roi.py:roi_inputs."""
+    g = recipe._gen("gen.roi")
+    feats = recipe.det_randn("gen.img_feats", (B, 256, recipe.TOKEN_SIZE))
+    idx = torch.randint(3, 12, (B, 24, 2), generator=g)
+    return feats, idx
+
+
+def roi_mask_from_indices(idx):
+    """create_roi_mask_from_indices models/mla/generation/utils.py:46-64."""
+    m = torch.zeros(idx.shape[0], 16, 16, dtype=torch.bool)
+    m[torch.arange(idx.shape[0]).view(-1, 1), idx[..., 0], idx[..., 1]] = True
+    return m
+
+
+def test_image_generation_with_roi_matches_reference():
+    """use_roi=True: ROI dilation, mask tokens only on ROI positions, translation warp + alpha blend elsewhere, ROI / background losses."""
+    from oracle import gen_oracle
+    gold = np.load(os.path.join(G, "generation_roi.npz"), allow_pickle=True)
+    pfx = "vlm.generation_manager."
+    sd = gen_state_dict(gold)
+    sd[pfx + "image_gen_module.mae_alpha_head.bias"] = torch.zeros(1)
+    names = [str(n) for n in gold["grad_names"]]
+    for n in names:
+        sd[pfx + n].requires_grad_(True)
+    hidden, curr, nxt, _ = gen_inputs()
+    feats, idx = roi_inputs()
+    hidden.requires_grad_(True)
+    feats.requires_grad_(True)
+    ip = pfx + "image_gen_module."
+    delta, alpha, offset, roi = gen_oracle.image_generation_roi(hidden, feats, roi_mask_from_indices(idx), sd, ip, GEN_CFG["image_heads"], 2,
+                                                                GEN_CFG["image_layers"])
+    assert np.array_equal(roi.numpy(), gold["A_roi_mask"])
+    assert np.allclose(alpha.detach().numpy(), gold["A_alpha"], rtol=1e-3, atol=1e-5)
+    assert np.allclose(offset.detach().numpy(), gold["A_offset"], rtol=1e-3, atol=1e-4)
+    loss, parts = gen_oracle.image_generation_roi_loss(delta, alpha, offset, roi, curr, nxt)
+    assert abs(float(loss) - float(gold["A_image_gen_loss"])) < 2e-5
+    assert abs(float(parts["roi"]) - float(gold["A_image_roi_generation_loss"])) < 2e-5
+    assert abs(float(parts["bg"]) - float(gold["A_bg_consistency_loss"])) < 1e-6
+    loss.backward()
+    assert np.abs(hidden.grad.numpy() - gold["A_hidden_grad"]).max() <= 3e-3 * np.abs(gold["A_hidden_grad"]).max()
+    assert np.abs(feats.grad.numpy() - gold["A_feats_grad"]).max() <= 3e-3 * np.abs(gold["A_feats_grad"]).max()
+    norms = np.array([0.0 if sd[pfx + n].grad is None else float(sd[pfx + n].grad.norm()) for n in names])
+    assert np.allclose(norms, gold["A_gradnorms"], rtol=3e-3, atol=1e-7)
