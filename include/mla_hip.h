@@ -147,6 +147,12 @@ int mla_local_attn(const void* q, const void* kv, void* out, int B, int gh, int 
  * (dq [windows, C], dkv [tokens, 2C]; every k/v row belongs to one window) and avg-pool backward fused with a second addend */
 int mla_local_attn_bwd(const void* q, const void* kv, const void* dout, void* dq, void* dkv, int B, int gh, int gw, int C, int cs,
                        int heads, float scale, mla_stream_t stream);
+/* CLIP-style preprocessing of uint8 HWC frames on the GPU (the reference runs CLIPImageProcessor on the CPU per frame,
+ * vla/datasets/datasets.py:52-69): PIL-exact 8-bit separable bicubic resize (host-built 2^22 fixed-point taps), 1/255 rescale,
+ * mean/std normalisation, optional all-ones mask channel; mean3 / std3 are HOST pointers */
+int mla_clip_preprocess(const unsigned char* img, int B, int Hin, int Win, const int* bounds_h, const int* coef_h, int ks_h,
+                        const int* bounds_v, const int* coef_v, int ks_v, void* out, int out_fp32, int OH, int OW, const float* mean3,
+                        const float* std3, int mask_channel, mla_stream_t stream);
 int mla_avgpool_tokens_bwd(const void* dy, const void* other, void* dx, int B, int gh, int gw, int C, int cs, mla_stream_t stream);
 
 /* ---- batched GEMM (two-level batch: outer = sample, inner = head) for the generation heads' nn.MultiheadAttention products

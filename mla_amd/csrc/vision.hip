@@ -157,6 +157,50 @@ __global__ __launch_bounds__(256) void avgpool_tokens_bwd_kernel(const bf16_t* _
   }
 }
 
+// CLIP-style preprocessing of uint8 HWC frames (vision_tokenizer.py:98-105 = CLIPImageProcessor(size 672, crop 672, rescale 1/255,
+// normalise); called per frame on the CPU by the reference's dataset, vla/datasets/datasets.py:52-69): PIL's separable bicubic resize in
+// 8-bit fixed point -- horizontal pass, round to uint8, vertical pass, round to uint8 (libImaging/Resample.c; the coefficient tables
+// are built on the host exactly like precompute_coeffs / normalize_coeffs_8bpc) -- then float32((double)u8 / 255 ... ) - mean) / std and
+// an all-ones mask channel. One thread per output pixel; <= 5 x 5 taps.
+__device__ __forceinline__ int clip8_fx(int v) { v >>= 22; return v < 0 ? 0 : (v > 255 ? 255 : v); }
+template <typename TO>
+__global__ __launch_bounds__(256) void clip_preprocess_kernel(const unsigned char* __restrict__ img, const int* __restrict__ bh,
+                                                              const int* __restrict__ kh, const int* __restrict__ bv,
+                                                              const int* __restrict__ kv, TO* __restrict__ out, int B, int Hin, int Win,
+                                                              int OH, int OW, int ksh, int ksv, float m0, float m1, float m2, float s0,
+                                                              float s1, float s2, int mask_channel) {
+  const long long total = (long long)B * OH * OW;
+  const int CT = 3 + (mask_channel ? 1 : 0);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int xx = (int)(e % OW), yy = (int)((e / OW) % OH), b = (int)(e / ((long long)OW * OH));
+    const int xmin = bh[xx * 2], xn = bh[xx * 2 + 1], ymin = bv[yy * 2], yn = bv[yy * 2 + 1];
+    int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+    for (int y = 0; y < yn; ++y) {
+      const unsigned char* row = img + ((size_t)b * Hin + (ymin + y)) * Win * 3;
+      int h[3] = {1 << 21, 1 << 21, 1 << 21};
+      for (int x = 0; x < xn; ++x) {
+        const int k = kh[xx * ksh + x];
+        const unsigned char* px = row + (size_t)(xmin + x) * 3;
+        h[0] += px[0] * k; h[1] += px[1] * k; h[2] += px[2] * k;
+      }
+      const int k = kv[yy * ksv + y];
+      acc[0] += clip8_fx(h[0]) * k; acc[1] += clip8_fx(h[1]) * k; acc[2] += clip8_fx(h[2]) * k;
+    }
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = (float)((double)clip8_fx(acc[c]) * 0.00392156862745098);          // uint8 * (1/255) in double, then float32
+      const float n = __fdiv_rn(__fsub_rn(v, mean[c]), sd[c]);
+      const size_t o = (((size_t)b * CT + c) * OH + yy) * OW + xx;
+      if (sizeof(TO) == 4) ((float*)out)[o] = n; else ((bf16_t*)out)[o] = f2bf(n);
+    }
+    if (mask_channel) {
+      const size_t o = (((size_t)b * CT + 3) * OH + yy) * OW + xx;
+      if (sizeof(TO) == 4) ((float*)out)[o] = 1.0f; else ((bf16_t*)out)[o] = f2bf(1.0f);
+    }
+  }
+}
+
 inline int gridn(long long items, int cap = 16384) {
   long long b = (items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -206,5 +250,21 @@ extern "C" int mla_avgpool_tokens_bwd(const void* dy, const void* other, void* d
   MLA_CHECK_ARG(dy && dx && gh % cs == 0 && gw % cs == 0, "mla_avgpool_tokens_bwd: bad args");
   hipLaunchKernelGGL(avgpool_tokens_bwd_kernel, dim3(gridn((long long)B * gh * gw * C)), dim3(256), 0, stream, (const bf16_t*)dy,
                      (const bf16_t*)other, (bf16_t*)dx, B, gh, gw, C, cs);
+  MLA_LAUNCH_CHECK();
+}
+
+// img: uint8 [B, Hin, Win, 3]; bounds_* int32 [O, 2] = (first tap, tap count), coef_* int32 [O, ks] fixed-point (2^22) taps of the
+// horizontal / vertical pass; out [B, 3 (+1 mask), OH, OW] float32 or bf16
+extern "C" int mla_clip_preprocess(const unsigned char* img, int B, int Hin, int Win, const int* bounds_h, const int* coef_h, int ks_h,
+                                   const int* bounds_v, const int* coef_v, int ks_v, void* out, int out_fp32, int OH, int OW,
+                                   const float* mean3, const float* std3, int mask_channel, hipStream_t stream) {
+  MLA_CHECK_ARG(img && bounds_h && coef_h && bounds_v && coef_v && out && mean3 && std3 && B > 0, "mla_clip_preprocess: bad args");
+  const long long total = (long long)B * OH * OW;
+  if (out_fp32)
+    hipLaunchKernelGGL(clip_preprocess_kernel<float>, dim3(gridn(total)), dim3(256), 0, stream, img, bounds_h, coef_h, bounds_v, coef_v,
+                       (float*)out, B, Hin, Win, OH, OW, ks_h, ks_v, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], mask_channel);
+  else
+    hipLaunchKernelGGL(clip_preprocess_kernel<bf16_t>, dim3(gridn(total)), dim3(256), 0, stream, img, bounds_h, coef_h, bounds_v, coef_v,
+                       (bf16_t*)out, B, Hin, Win, OH, OW, ks_h, ks_v, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], mask_channel);
   MLA_LAUNCH_CHECK();
 }

@@ -404,6 +404,8 @@ register_signatures({
     "mla_avgpool_tokens": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_local_attn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "mla_local_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mla_clip_preprocess": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                            c_int, c_void_p, c_void_p, c_int, c_void_p],
     "mla_avgpool_tokens_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_colstats_blocks": [c_longlong],
     "mla_gather_rows_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
@@ -736,3 +738,16 @@ def imgroi_bwd(delta_raw, a_raw, o_raw, roi_u8, curr, nxt, ps, clip, shift, coef
          1 if curr.dtype == torch.float32 else 0, _p(coef), _p(dd), _p(da), _p(do), B, curr.shape[1], nxt.shape[1], curr.shape[2], ps,
          float(clip), float(shift))
     return dd, da, do
+
+
+def clip_preprocess(img_u8, bounds_h, coef_h, bounds_v, coef_v, OH, OW, mean, std, out_dtype=torch.float32, mask_channel=True):
+    """img_u8 [B, H, W, 3] uint8 on the GPU -> [B, 3 (+1), OH, OW]; tables from mla_amd.vision_tokenizer.pil_resample_tables."""
+    if img_u8.dtype != torch.uint8 or not img_u8.is_cuda:
+        raise TypeError("clip_preprocess: uint8 CUDA tensor [B, H, W, 3] expected")
+    B, H, W, _ = img_u8.shape
+    out = torch.empty((B, 4 if mask_channel else 3, OH, OW), dtype=out_dtype, device=img_u8.device)
+    m = (c_float * 3)(*[float(v) for v in mean])
+    sd = (c_float * 3)(*[float(v) for v in std])
+    call("mla_clip_preprocess", _p(img_u8.contiguous()), B, H, W, _p(bounds_h), _p(coef_h), coef_h.shape[1], _p(bounds_v), _p(coef_v),
+         coef_v.shape[1], _p(out), 1 if out_dtype == torch.float32 else 0, OH, OW, m, sd, 1 if mask_channel else 0)
+    return out

@@ -240,9 +240,9 @@ class MLA(nn.Module):
                             action_dim: int = 7, *, input_ids: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
                             camera_name: str = "rlbench_front", **kwargs) -> np.ndarray:
         """model_mla.py:592-775: 8-step DDIM (eta = 0) over the action chunk with the VLM as the epsilon model, then
-        un-normalisation. The model side is complete; the two data adapters around it are SURVEY 8f rank 4 and not built, so
-        * ``image`` is the already pre-processed frame (float tensor [3|4, 672, 672], CLIP-normalised; a ones mask channel is
-          appended when missing, :657-660) -- not a PIL image;
+        un-normalisation. The model side and the image adapter are complete; prompt construction needs the Llama tokenizer (not in this image), so
+        * ``image`` is a PIL image / uint8 HWC frame (pre-processed here like the reference does, :656-660) or an already
+          pre-processed float tensor [3|4, 672, 672]; a ones mask channel is appended when missing;
         * the prompt arrives tokenised as ``input_ids`` [1, L] (the reference builds it from ``instruction`` with the Llama
           tokenizer and appends [29871, 32001, 32002, 29871], then drops the last three ids, :629-645, :711-713); pass the ids in
           either form: if the last id is not 29871 the tail is appended here.
@@ -256,8 +256,9 @@ class MLA(nn.Module):
                                       "pass input_ids")
         if cfg_scale > 1.0:
             raise NotImplementedError("classifier-free guidance (forward_with_cfg) is not used by the shipped evaluation (cfg_scale=0)")
-        if not torch.is_tensor(image):
-            raise NotImplementedError("PIL pre-processing (CLIPImageProcessor) is a data adapter (SURVEY 8f rank 4): pass a tensor")
+        if not (torch.is_tensor(image) and image.is_floating_point()):
+            # PIL image / uint8 HWC frame: the reference's CLIPImageProcessor step (:656-657), PIL-exact on the GPU
+            image = self.vlm.get_vision_tower_2d().image_processor.preprocess(image, return_tensors="pt")["pixel_values"][0]
         input_ids = input_ids.to(device)
         if not bool(torch.all(input_ids[:, -1] == 29871)):
             tail = torch.tensor([[29871, 32001, 32002, 29871]], dtype=torch.long, device=device)

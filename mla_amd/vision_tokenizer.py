@@ -6,8 +6,6 @@ local_attention.{q,kv,proj}, global_attention.{q,kv,proj}); GlobalAttention's ou
 """
 from __future__ import annotations
 
-from types import SimpleNamespace
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -55,16 +53,88 @@ class MLP_GELU(nn.Module):
         return x
 
 
+def pil_resample_tables(in_size: int, out_size: int):
+    """Taps of PIL's bicubic resize for one axis, as PIL computes them for 8-bit images (libImaging/Resample.c precompute_coeffs +
+    normalize_coeffs_8bpc): bounds [out, 2] = (first input index, tap count), coef [out, ksize] int32 in 2^22 fixed point."""
+    import math
+    import numpy as np
+
+    def bicubic(x, a=-0.5):
+        x = abs(x)
+        if x < 1.0:
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+        if x < 2.0:
+            return (((x - 5) * x + 8) * x - 4) * a
+        return 0.0
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coef = np.zeros((out_size, ksize), dtype=np.int32)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = max(int(center - support + 0.5), 0)               # C (int) cast: truncation toward zero
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        k = [bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = sum(k)
+        if ww != 0.0:
+            k = [v / ww for v in k]
+        for x, v in enumerate(k):
+            coef[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coef
+
+
+class ClipImagePreprocessor:
+    """Stand-in for the reference's CLIPImageProcessor(size=672, crop_size=672, rescale, normalise) (vision_tokenizer.py:98-105) with
+    the HF calling convention ``preprocess(image, return_tensors='pt')['pixel_values']``: uint8 frames are resized with PIL-exact
+    8-bit bicubic resampling, rescaled and normalised by one HIP kernel (hip.clip_preprocess). Square inputs only (the RLDS pipeline
+    delivers 224 x 224): shortest-edge resize to 672 then makes the centre crop the identity."""
+
+    def __init__(self, size=672, device="cuda"):
+        self.size = self.crop_size = size
+        self.do_resize = self.do_center_crop = self.do_normalize = self.do_rescale = True
+        self.image_mean = [0.48145466, 0.4578275, 0.40821073]
+        self.image_std = [0.26862954, 0.26130258, 0.27577711]
+        self.device = torch.device(device)
+        self._tables = {}
+
+    def tables(self, in_size):
+        if in_size not in self._tables:
+            b, c = pil_resample_tables(in_size, self.size)
+            self._tables[in_size] = (torch.from_numpy(b).to(self.device), torch.from_numpy(c).to(self.device))
+        return self._tables[in_size]
+
+    def preprocess(self, images, return_tensors="pt", mask_channel=False, out_dtype=torch.float32, **kwargs):
+        """images: PIL image / HWC uint8 array / uint8 tensor [H, W, 3] or a batch [B, H, W, 3]. Returns {"pixel_values": [B, 3(+1), 672, 672]}."""
+        import numpy as np
+        if not torch.is_tensor(images):
+            arr = np.asarray(images)
+            images = torch.from_numpy(np.ascontiguousarray(arr))
+        if images.dim() == 3:
+            images = images.unsqueeze(0)
+        if images.dtype != torch.uint8 or images.shape[-1] != 3:
+            raise TypeError("ClipImagePreprocessor expects uint8 RGB frames in HWC layout")
+        if images.shape[1] != images.shape[2]:
+            raise NotImplementedError("non-square frames (shortest-edge resize + centre crop): the RLDS pipeline delivers 224 x 224")
+        bt, ct = self.tables(int(images.shape[1]))
+        out = hip.clip_preprocess(images.to(self.device), bt, ct, bt, ct, self.size, self.size, self.image_mean, self.image_std,
+                                  out_dtype=out_dtype, mask_channel=mask_channel)
+        return {"pixel_values": out}
+
+    __call__ = preprocess
+
+
 class VisionTokenizer(nn.Module):
     def __init__(self, input_size):
         super().__init__()
         self.is_loaded = True
         self.hidden_size = input_size
-        # the reference holds a CLIPImageProcessor(size=672, crop 672, rescale, normalise) here (:98-105); image
-        # preprocessing is the data side of the boundary -- only its settings are kept.
-        self.image_processor = SimpleNamespace(size=672, crop_size=672, do_resize=True, do_center_crop=True, do_normalize=True,
-                                               do_rescale=True, image_mean=[0.48145466, 0.4578275, 0.40821073],
-                                               image_std=[0.26862954, 0.26130258, 0.27577711])
+        # the reference holds a CLIPImageProcessor(size=672, crop 672, rescale, normalise) here (:98-105); same settings, PIL-exact
+        # arithmetic, on the GPU
+        self.image_processor = ClipImagePreprocessor(672)
         self.patch_stride = 14
         self.conv_stride = 3
         self.patch_embedding = nn.Conv2d(3, input_size, kernel_size=14, stride=14, bias=False)

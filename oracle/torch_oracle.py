@@ -433,3 +433,48 @@ def splice_sequence(input_ids, attention_mask, labels, n_fused: int, n_action: i
         masks.append(m)
         labs.append(lb)
     return torch.tensor(ks), torch.stack(masks), torch.stack(labs)
+
+
+# ------------------------------------------------------------------------------------------------- image preprocessing (8f-4)
+def pil_bicubic_resize_u8(img: np.ndarray, out_size: int) -> np.ndarray:
+    """PIL.Image.resize(..., BICUBIC) for uint8 HWC images, restated from Pillow's libImaging/Resample.c (third-party dependency of the
+    reference's CLIPImageProcessor; the reference preprocesses every frame with it, vision_tokenizer.py:98-105, datasets.py:52-69):
+    per axis, taps of the a = -0.5 cubic around centre (xx + 0.5) * in / out over support 2 (no filter scaling when up-sampling),
+    normalised, quantised to 2^22 fixed point; horizontal pass then vertical pass, each rounded to uint8."""
+    def taps(n_in, n_out):
+        scale = n_in / n_out
+        fs = max(scale, 1.0)
+        sup = 2.0 * fs
+        out = []
+        for xx in range(n_out):
+            c = (xx + 0.5) * scale
+            lo = max(int(c - sup + 0.5), 0)
+            hi = min(int(c + sup + 0.5), n_in)
+            w = []
+            for x in range(lo, hi):
+                t = abs((x - c + 0.5) / fs)
+                w.append(((1.5 * t - 2.5) * t * t + 1) if t < 1 else ((((t - 5) * t + 8) * t - 4) * -0.5 if t < 2 else 0.0))
+            tot = sum(w)
+            w = [v / tot for v in w] if tot != 0.0 else w
+            out.append((lo, np.array([int(-0.5 + v * 4194304) if v < 0 else int(0.5 + v * 4194304) for v in w], dtype=np.int64)))
+        return out
+    H, W, _ = img.shape
+    tmp = np.zeros((H, out_size, 3), dtype=np.uint8)
+    for xx, (lo, k) in enumerate(taps(W, out_size)):
+        acc = (img[:, lo:lo + len(k), :].astype(np.int64) * k[None, :, None]).sum(1) + (1 << 21)
+        tmp[:, xx, :] = np.clip(acc >> 22, 0, 255)
+    out = np.zeros((out_size, out_size, 3), dtype=np.uint8)
+    for yy, (lo, k) in enumerate(taps(H, out_size)):
+        acc = (tmp[lo:lo + len(k)].astype(np.int64) * k[:, None, None]).sum(0) + (1 << 21)
+        out[yy] = np.clip(acc >> 22, 0, 255)
+    return out
+
+
+def clip_preprocess(img_u8: np.ndarray, size: int = 672) -> np.ndarray:
+    """CLIPImageProcessor.preprocess for a square uint8 frame: resize (bicubic), rescale by 1/255 (float64 product, then float32),
+    normalise in float32 (transformers/image_transforms.py:92-125, 347-400), channels first."""
+    r = pil_bicubic_resize_u8(img_u8, size)
+    v = (r * 0.00392156862745098).astype(np.float32)
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    return ((v - mean) / std).transpose(2, 0, 1)

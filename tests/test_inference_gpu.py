@@ -102,3 +102,14 @@ def test_unnormalisation_and_latency(dev, model):
         print(f"tiny-model 8-step DDIM latency: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms")
     finally:
         m.norm_stats = None
+
+
+def test_predict_action_diff_from_uint8_frame(dev, model):
+    """A raw 224x224 uint8 frame goes through the PIL-exact GPU preprocessing (CLIPImageProcessor step of model_mla.py:656-660)."""
+    m, _ = model
+    ids, _, pc, proprio, noise, _ = infer_inputs()
+    frame = np.random.RandomState(3).randint(0, 256, (224, 224, 3)).astype(np.uint8)
+    a1 = m.predict_action_diff(image=frame, pointcloud=pc[0], cur_robot_state=proprio[0, 0].numpy(), input_ids=ids, noise=noise)
+    pv = m.vlm.get_vision_tower_2d().image_processor.preprocess(frame)["pixel_values"][0]
+    a2 = m.predict_action_diff(image=pv, pointcloud=pc[0], cur_robot_state=proprio[0, 0].numpy(), input_ids=ids, noise=noise)
+    assert a1.shape == (4, 7) and np.allclose(a1, a2, rtol=1e-5, atol=1e-6)
