@@ -19,6 +19,9 @@ namespace {
 
 constexpr int D = 128;
 constexpr int TROWS = 64;
+#ifndef MLA_ATTN_ABL
+#define MLA_ATTN_ABL 0      // timing experiments only: 1 = no V^T fragment reads, 2 = no softmax arithmetic, 3 = no K fragment reads
+#endif
 #ifndef MLA_ATTN_RB
 #define MLA_ATTN_RB 2
 #endif
@@ -212,12 +215,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int rb = 0; rb < RB; ++rb) st[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+#if MLA_ATTN_ABL == 3
+        const bf16x8_t kf = qf[0][ks];
+#else
         const bf16x8_t kf = frag_rows<0>(kt_, f, ks, lane);
+#endif
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) st[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][f], 0, 0, 0);
       }
     }
     bf16x8_t pf[RB][2];
+#if MLA_ATTN_ABL == 2
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { pf[rb][0] = pack_frag(st[rb][0], st[rb][1]); pf[rb][1] = pack_frag(st[rb][2], st[rb][3]); }
+#else
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       float mx = -INFINITY;
@@ -231,12 +242,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sv = st[rb][f][r] * sc2;
-          st[rb][f][r] = sv;
-          mx = fmaxf(mx, sv);
-        }
-      mx = group_max(mx);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[rb][f][r]);      // max of the RAW scores: the scale is positive
+      mx = group_max(mx) * sc2;
       const float mnew = fmaxf(m[rb], mx);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
       const float alpha = __builtin_amdgcn_exp2f(m[rb] - msafe);
@@ -245,23 +252,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(st[rb][f][r] - msafe);
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[rb][f][r], sc2, -msafe));   // scale folded into the exponent's fma
           st[rb][f][r] = e;
           rs += e;
         }
       rs = group_sum(rs);
       l[rb] = l[rb] * alpha + rs;
       m[rb] = mnew;
+      // lazy rescale: once the running maximum has settled (most tiles of a causal row block) alpha == 1 in every lane of the
+      // wave and the 64 output accumulators need no multiply -- wave-uniform test, skips 32 packed multiplies per row block
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ot[rb][i] *= alpha;
+        for (int i = 0; i < 8; ++i) ot[rb][i] *= alpha;
+      }
       pf[rb][0] = pack_frag(st[rb][0], st[rb][1]);
       pf[rb][1] = pack_frag(st[rb][2], st[rb][3]);
     }
+#endif
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd)
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
+#if MLA_ATTN_ABL == 1
+        const bf16x8_t vf = qf[0][ks2];
+#else
         const bf16x8_t vf = frag_tr<1>(vt_, fd, ks2, lane);
+#endif
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) ot[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[rb][ks2], ot[rb][fd], 0, 0, 0);
       }

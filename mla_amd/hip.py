@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmla_hip.so")
+_LIB_PATH = os.environ.get("MLA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmla_hip.so")   # override: A/B experiments
 _lib = None
 
 ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_SILU = 0, 1, 2, 3
