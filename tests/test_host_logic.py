@@ -253,3 +253,47 @@ def test_action_unnormalisation_rules():
     with pytest.raises(AssertionError):
         m.get_action_stats(None)
     assert m.get_action_dim("b") == 7
+
+
+def test_padded_collator_matches_reference_semantics():
+    """PaddedCollatorForActionPrediction (util/data_utils.py:88-196): padding / truncation / mask / optional fields; cross-checked against
+    the reference's own class when it is importable (build container)."""
+    from mla_amd.data_utils import IGNORE_INDEX, PaddedCollatorForActionPrediction
+    g = torch.Generator().manual_seed(0)
+
+    def inst(n, tactile):
+        d = dict(input_ids=torch.randint(3, 100, (n,), generator=g), labels=torch.randint(3, 100, (n,), generator=g),
+                 images={"front_image": torch.randn(4, 8, 8, generator=g)}, next_images={"front_image": torch.randn(3, 8, 8, generator=g)},
+                 point_cloud=torch.randn(16, 3, generator=g), next_point_cloud=torch.randn(16, 3, generator=g),
+                 actions=torch.randn(1, 7, generator=g), action_masks=torch.ones(1, dtype=torch.bool), proprio=torch.randn(1, 7, generator=g),
+                 dataset_name="rlbench")
+        if tactile:
+            d.update(tactile=torch.randn(12, generator=g), gripper_xyz=torch.randn(3, generator=g), next_tactile=torch.randn(12, generator=g))
+        return d
+    for tactile in (False, True):
+        batch = [inst(9, tactile), inst(14, tactile), inst(5, tactile)]
+        out = PaddedCollatorForActionPrediction(model_max_length=12, pad_token_id=512)(batch)
+        assert out["input_ids"].shape == (3, 12) and out["labels"].shape == (3, 12)
+        assert torch.equal(out["input_ids"][0, :9], batch[0]["input_ids"]) and bool((out["input_ids"][0, 9:] == 512).all())
+        assert torch.equal(out["input_ids"][1], batch[1]["input_ids"][:12])                       # truncated
+        assert bool((out["labels"][2, 5:] == IGNORE_INDEX).all()) and torch.equal(out["attention_mask"], out["input_ids"] != 512)
+        assert out["images"]["front_image"].shape == (3, 4, 8, 8) and out["point_cloud"].shape == (3, 16, 3)
+        assert (out["tactile"] is None) == (not tactile) and (out["gripper_xyz"] is None) == (not tactile)
+        assert out["dataset_names"] == ["rlbench"] * 3
+        try:
+            from oracle import ref_import
+            if not ref_import.available():
+                raise ImportError
+            ref_import.setup()
+            from util.data_utils import PaddedCollatorForActionPrediction as Ref
+        except Exception:
+            continue
+        ref = Ref(model_max_length=12, pad_token_id=512)(batch)
+        assert set(ref) == set(out)
+        for k, v in ref.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v, out[k]), k
+            elif isinstance(v, dict):
+                assert all(torch.equal(v[kk], out[k][kk]) for kk in v), k
+            else:
+                assert v == out[k], k
