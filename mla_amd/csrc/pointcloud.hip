@@ -177,6 +177,46 @@ __global__ __launch_bounds__(256) void lga_prep_kernel(const float* __restrict__
   }
 }
 
+// backward of lga_prep w.r.t. the point features (coordinates carry no gradient: the positional embedding is a constant):
+//   dfeats[b][knn[b,g,k]][c] += drows[(b,g,k)][c]        dfeats[b][centre(b,g)][c] += sum_k drows[(b,g,k)][C + c]
+// fp32 atomics into a zero-initialised [B, N, C] buffer (a point is the neighbour of many groups)
+__global__ __launch_bounds__(256) void lga_prep_bwd_kernel(const bf16_t* __restrict__ drows, const long long* __restrict__ fps_idx,
+                                                           const int* __restrict__ knn, float* __restrict__ dfeats, int N, int G, int K,
+                                                           int C) {
+  const int bg = blockIdx.x, b = bg / G, tid = threadIdx.x;
+  const int ci = (int)fps_idx[bg];
+  const int OD = 2 * C;
+  float* fb = dfeats + (size_t)b * N * C;
+  for (int e = tid; e < K * C; e += 256) {
+    const int kk = e / C, ch = e % C;
+    atomicAdd(fb + (size_t)knn[(size_t)bg * K + kk] * C + ch, bf2f(drows[((size_t)bg * K + kk) * OD + ch]));
+  }
+  for (int ch = tid; ch < C; ch += 256) {
+    float s = 0.f;
+    for (int kk = 0; kk < K; ++kk) s += bf2f(drows[((size_t)bg * K + kk) * OD + C + ch]);
+    atomicAdd(fb + (size_t)ci * C + ch, s);
+  }
+}
+
+// backward of the max over the K neighbours: the gradient goes to the first neighbour that attains the maximum
+__global__ __launch_bounds__(256) void maxpool_k_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                            bf16_t* __restrict__ dx, long long groups, int K, int C) {
+  const long long total = groups * C;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long g = e / C;
+    const int c = (int)(e % C);
+    const bf16_t* col = x + (size_t)g * K * C + c;
+    float best = bf2f(col[0]);
+    int bi = 0;
+    for (int k = 1; k < K; ++k) {
+      const float v = bf2f(col[(size_t)k * C]);
+      if (v > best) { best = v; bi = k; }
+    }
+    const bf16_t gy = dy[e];
+    for (int k = 0; k < K; ++k) dx[((size_t)g * K + k) * C + c] = (k == bi) ? gy : (bf16_t)0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm (train)
 // partial[(blockIdx.y*2 + {0,1}) * C + c] = sum / sum of squares over this block's row slice
 __global__ __launch_bounds__(256) void colstats_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
@@ -327,5 +367,19 @@ extern "C" int mla_gather_rows_f32(const float* src, const long long* idx, float
                                    hipStream_t stream) {
   MLA_CHECK_ARG(src && idx && out, "mla_gather_rows_f32: null pointer");
   hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(gridn((long long)B * G * W)), dim3(256), 0, stream, src, idx, out, B, N, G, W);
+  MLA_LAUNCH_CHECK();
+}
+
+// backward kernels of the point tokenizer (stage "pretrain" with use_pointcloud: Point_PN.py:115-158 LGA, :166-169 Pooling)
+extern "C" int mla_lga_prep_bwd(const void* drows, const long long* fps_idx, const int* knn, float* dfeats_zeroed, int B, int N, int G,
+                                int K, int C, hipStream_t stream) {
+  MLA_CHECK_ARG(drows && fps_idx && knn && dfeats_zeroed, "mla_lga_prep_bwd: null pointer");
+  hipLaunchKernelGGL(lga_prep_bwd_kernel, dim3(B * G), dim3(256), 0, stream, (const bf16_t*)drows, fps_idx, knn, dfeats_zeroed, N, G, K, C);
+  MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_maxpool_k_bwd(const void* x, const void* dy, void* dx, long long groups, int K, int C, hipStream_t stream) {
+  MLA_CHECK_ARG(x && dy && dx, "mla_maxpool_k_bwd: null pointer");
+  hipLaunchKernelGGL(maxpool_k_bwd_kernel, dim3(gridn(groups * C)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx,
+                     groups, K, C);
   MLA_LAUNCH_CHECK();
 }

@@ -404,6 +404,8 @@ register_signatures({
     "mla_avgpool_tokens": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_local_attn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "mla_local_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mla_lga_prep_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mla_maxpool_k_bwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "mla_clip_preprocess": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                             c_int, c_void_p, c_void_p, c_int, c_void_p],
     "mla_avgpool_tokens_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -751,3 +753,16 @@ def clip_preprocess(img_u8, bounds_h, coef_h, bounds_v, coef_v, OH, OW, mean, st
     call("mla_clip_preprocess", _p(img_u8.contiguous()), B, H, W, _p(bounds_h), _p(coef_h), coef_h.shape[1], _p(bounds_v), _p(coef_v),
          coef_v.shape[1], _p(out), 1 if out_dtype == torch.float32 else 0, OH, OW, m, sd, 1 if mask_channel else 0)
     return out
+
+
+def lga_prep_bwd(drows, fps_idx, knn_idx, B, N, C):
+    G, K = knn_idx.shape[1], knn_idx.shape[2]
+    dfeats = torch.zeros((B, N, C), dtype=torch.float32, device=drows.device)
+    call("mla_lga_prep_bwd", _p(drows), _p(fps_idx), _p(knn_idx), _p(dfeats), B, N, G, K, C)
+    return dfeats
+
+
+def maxpool_k_bwd(x2d, dy, groups, K):
+    dx = torch.empty_like(x2d)
+    call("mla_maxpool_k_bwd", _p(x2d), _p(dy), _p(dx), groups, K, x2d.shape[1])
+    return dx

@@ -979,3 +979,41 @@ class ImageGenRoiLossFn(torch.autograd.Function):
         do_full = torch.zeros(o2.shape, dtype=BF16, device=o2.device)
         do_full[:, :2] = do.to(BF16)
         return dd, da_full.view(ashape), do_full.view(oshape), None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------- point tokenizer (stage "pretrain")
+class LgaPrepFn(torch.autograd.Function):
+    """Neighbour / centre feature gather + positional embedding of LGA.forward (Point_PN.py:115-158): differentiable in the point
+    features only (coordinates and the sin/cos embedding are constants)."""
+
+    @staticmethod
+    def forward(ctx, xyz, feats, fps_idx, knn_idx, alpha, beta):
+        feats = feats.contiguous()
+        rows, lc_xyz = hip.lga_prep(xyz, feats, fps_idx, knn_idx, alpha, beta)
+        ctx.save_for_backward(fps_idx, knn_idx)
+        ctx.shape = feats.shape
+        ctx.mark_non_differentiable(lc_xyz)
+        return rows, lc_xyz
+
+    @staticmethod
+    def backward(ctx, drows, _dl):
+        fps_idx, knn_idx = ctx.saved_tensors
+        B, N, C = ctx.shape
+        d32 = hip.lga_prep_bwd(drows.contiguous(), fps_idx, knn_idx, B, N, C)
+        return None, hip.cast_f32_to_bf16(d32), None, None, None, None
+
+
+class MaxPoolKFn(torch.autograd.Function):
+    """max over the K neighbours of every group (Pooling.forward Point_PN.py:166-169)."""
+
+    @staticmethod
+    def forward(ctx, rows, groups, K):
+        rows = rows.contiguous()
+        ctx.save_for_backward(rows)
+        ctx.dims = (groups, K)
+        return hip.maxpool_k(rows, groups, K)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rows,) = ctx.saved_tensors
+        return hip.maxpool_k_bwd(rows, dy.contiguous(), *ctx.dims), None, None

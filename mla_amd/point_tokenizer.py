@@ -2,10 +2,10 @@
 
 Same module tree / state-dict names as the reference (patch_embed.EncP.raw_point_embed.net.{0,1}, patch_embed.EncP.
 LGA_list.{i}.linear2.{j}.net{1,2}.{0,1}, proj, cls_token, pos_embed, norm); the forward pass is a fixed pipeline of HIP
-kernels (FPS, kNN, gather + positional embedding, 1x1-conv GEMMs, train-mode BatchNorm, max-pool). Forward only: the
-tower is frozen on the SFT / post-training path, yet -- exactly like the reference, which leaves it in train() mode
+kernels (FPS, kNN, gather + positional embedding, 1x1-conv GEMMs, train-mode BatchNorm, max-pool). The tower is frozen on
+the SFT / post-training path, yet -- exactly like the reference, which leaves it in train() mode
 (training/strategies/base_strategy_mla.py:291) -- BatchNorm normalises with batch statistics and keeps updating its
-running statistics.
+running statistics. Stage "pretrain" trains it: `_forward_trainable` is the same pipeline through autograd ops.
 """
 from __future__ import annotations
 
@@ -118,7 +118,7 @@ class PointTokenizer(nn.Module):
 
     def forward(self, p, x=None, **kwargs):
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
-            raise NotImplementedError("trainable point tokenizer (stage 'pretrain') is not built; SFT/post-training freeze it")
+            return self._forward_trainable(p)     # stage "pretrain" (base_strategy_mla.py / prismatic.py freeze_backbones)
         enc = self.patch_embed.EncP
         xyz = p.float().contiguous()                      # pointvit.py:66-74 forces fp32 coordinates
         B, N, _ = xyz.shape
@@ -129,13 +129,7 @@ class PointTokenizer(nn.Module):
             feats = _bn_train(x0, bn, relu=True).view(B, N, -1)
             for i in range(enc.num_stages):
                 G, K = enc.group_nums[i], enc.k_neighbors
-                if self.fps_starts_override is not None:
-                    start = self.fps_starts_override[i].to(xyz.device)
-                else:
-                    start = torch.randint(0, xyz.shape[1], (B,), dtype=torch.long, device=xyz.device)  # Point_PN.py:10
-                fps_idx = hip.fps(xyz, start.contiguous(), G)
-                centers = hip.gather_rows_f32(xyz, fps_idx)
-                knn_idx = hip.knn(xyz, centers, K)
+                fps_idx, knn_idx = self._group(xyz, i, G, K)
                 idx_dbg.append((fps_idx, knn_idx))
                 lga = enc.LGA_list[i]
                 rows, lc_xyz = hip.lga_prep(xyz, feats.contiguous(), fps_idx, knn_idx, lga.alpha, lga.beta)
@@ -148,5 +142,58 @@ class PointTokenizer(nn.Module):
                 feats = hip.maxpool_k(rows, B * G, K).view(B, G, -1)
                 xyz = lc_xyz
             tokens = hip.gemm(feats.reshape(B * xyz.shape[1], -1), self.proj.weight, bias=self.proj.bias).view(B, xyz.shape[1], -1)
+        self.last_indices = idx_dbg
+        return tokens, xyz
+
+    def _group(self, xyz, stage, G, K):
+        """Farthest-point centres + their K nearest neighbours (index work, no gradient): Point_PN.py:8-27, :49-74."""
+        with torch.no_grad():
+            if self.fps_starts_override is not None:
+                start = self.fps_starts_override[stage].to(xyz.device)
+            else:
+                start = torch.randint(0, xyz.shape[1], (xyz.shape[0],), dtype=torch.long, device=xyz.device)  # Point_PN.py:10
+            fps_idx = hip.fps(xyz, start.contiguous(), G)
+            centers = hip.gather_rows_f32(xyz, fps_idx)
+            knn_idx = hip.knn(xyz, centers, K)
+        return fps_idx, knn_idx
+
+    def _forward_trainable(self, p):
+        """The same pipeline with autograd: 1x1 convolutions as GEMMs with weight-gradient delivery, train-mode BatchNorm
+        backward, gather / max-pool backward. Coordinates, FPS / kNN indices and the sin/cos embedding carry no gradient."""
+        from . import ops
+        enc = self.patch_embed.EncP
+        xyz = p.float().contiguous()
+        B, N, _ = xyz.shape
+        idx_dbg = []
+
+        def bn_rows(x2, bn, relu):
+            y, mean, var = ops.BatchNormTrainFn.apply(x2, bn.weight, bn.bias, bn.eps, relu)
+            if bn.track_running_stats and bn.running_mean is not None:
+                with torch.no_grad():
+                    n, m = x2.shape[0], (bn.momentum if bn.momentum is not None else 0.1)
+                    bn.running_mean.mul_(1 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
+                    bn.running_var.mul_(1 - m).add_((var * (n / max(n - 1, 1))).to(bn.running_var.dtype), alpha=m)
+                    bn.num_batches_tracked += 1
+            return y
+
+        conv, bn = enc.raw_point_embed.net[0], enc.raw_point_embed.net[1]
+        x0 = ops.linear(xyz.reshape(B * N, 3).to(torch.bfloat16), ops.param_view(conv.weight, shape=(conv.out_channels, 3)))
+        feats = bn_rows(x0, bn, True).view(B, N, -1)
+        for i in range(enc.num_stages):
+            G, K = enc.group_nums[i], enc.k_neighbors
+            fps_idx, knn_idx = self._group(xyz, i, G, K)
+            idx_dbg.append((fps_idx, knn_idx))
+            lga = enc.LGA_list[i]
+            rows, lc_xyz = ops.LgaPrepFn.apply(xyz, feats, fps_idx, knn_idx, lga.alpha, lga.beta)
+            for blk in lga.linear2:
+                c1, b1, c2, b2 = blk.net1[0], blk.net1[1], blk.net2[0], blk.net2[1]
+                y = ops.linear(rows, ops.param_view(c1.weight, shape=(c1.out_channels, c1.in_channels)), c1.bias)
+                y = bn_rows(y, b1, True)
+                y = ops.linear(y, ops.param_view(c2.weight, shape=(c2.out_channels, c2.in_channels)), c2.bias)
+                y = bn_rows(y, b2, False)
+                rows = ops.act(ops.dropout_add(y, rows, 0.0, False), hip.ACT_RELU)       # act(net2(net1(x)) + x), Point_PN.py:218
+            feats = ops.MaxPoolKFn.apply(rows, B * G, K).view(B, G, -1)
+            xyz = lc_xyz
+        tokens = ops.linear(feats.reshape(B * xyz.shape[1], -1), self.proj.weight, self.proj.bias).view(B, xyz.shape[1], -1)
         self.last_indices = idx_dbg
         return tokens, xyz

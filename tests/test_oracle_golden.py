@@ -221,25 +221,31 @@ def test_ddim_sampler_oracle_and_product_match_reference():
     assert np.allclose(got.numpy(), gold["toy_ddpm100"], rtol=1e-4, atol=1e-5)
 
 
-def test_mla_e2e_pretrain_stage_matches_reference():
-    """Stage "pretrain" (trainable vision tokenizer, use_pointcloud=False -- BASELINE configs[4] shape): loss and every gradient norm."""
-    gold = np.load(os.path.join(G, "mla_tiny_e2e_pretrain.npz"), allow_pickle=True)
+@pytest.mark.parametrize("pc", [False, True])
+def test_mla_e2e_pretrain_stage_matches_reference(pc):
+    """Stage "pretrain" (trainable vision tokenizer; use_pointcloud=False is BASELINE configs[4]'s shape, True also trains the point
+    tower and the contrastive head): loss and every gradient norm."""
+    gold = np.load(os.path.join(G, "mla_tiny_e2e_pretrain_pc.npz" if pc else "mla_tiny_e2e_pretrain.npz"), allow_pickle=True)
     sd = {str(n): recipe.det_weight(str(n), eval(str(s))) for n, s in zip(gold["param_names"], gold["param_shapes"])}
     names = [str(n) for n in gold["grad_names"]]
     for n in names:
         sd[n].requires_grad_(True)
     batch, draws = recipe.make_batch(R=2)
-    out = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, use_pointcloud=False, use_contrastive=False, zero_pad_rows=False)
-    assert abs(float(out["total_loss"]) - float(gold["A_total_loss"])) < 2e-5
+    out = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, use_pointcloud=pc, use_contrastive=pc, zero_pad_rows=False)
+    assert abs(float(out["total_loss"]) - float(gold["A_total_loss"])) < (1e-4 if pc else 2e-5)
     out["total_loss"].backward()
     norms = np.array([0.0 if sd[n].grad is None else float(sd[n].grad.norm()) for n in names])
-    assert np.allclose(norms, gold["A_gradnorms"], rtol=3e-3, atol=1e-7)
+    # a convolution bias in front of a train-mode BatchNorm has an exactly-zero gradient: the 1e-7 the reference holds there is rounding
+    assert np.allclose(norms, gold["A_gradnorms"], rtol=3e-3, atol=2e-6 if pc else 1e-7)
     for key in gold.files:
         if key.startswith("A_grad::"):
             n = key[len("A_grad::"):]
+            if n.endswith(".0.bias") and "EncP" in n:
+                continue
             g, ref = sd[n].grad, gold[key]
             got = (g.reshape(g.shape[0], -1)[:16, :64] if ref.ndim == 2 else g.reshape(-1)[:256]).numpy()
-            assert np.abs(got - ref).max() <= 3e-3 * np.abs(ref).max() + 1e-8, n
+            # point tower: BatchNorm backward reduces over 165888 rows in fp32, summation order shows at the 4e-3 level
+            assert np.abs(got - ref).max() <= (8e-3 if "tower_3d" in n else 3e-3) * np.abs(ref).max() + 1e-8, n
 
 
 def test_mla_e2e_tactile_path_matches_reference():
