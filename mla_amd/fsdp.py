@@ -128,19 +128,24 @@ class FlatUnit:
             if p.requires_grad:
                 p._mg_touched = False
 
+    def collect_autograd_grads(self):
+        """Gradients delivered by autograd into ``.grad`` (small broadcast parameters: queries, mask token, position tables) move
+        into main_grad; called after every backward so that accumulation over micro-batches happens in fp32."""
+        for _, p, _ in self.params:
+            if p.requires_grad and p.grad is not None:
+                if p._mg_touched:
+                    p.main_grad.add_(p.grad.to(torch.float32))
+                else:
+                    p.main_grad.copy_(p.grad)
+                p._mg_touched = True
+                p.grad = None
+
     def finish_backward(self):
         """Parameters that received no gradient this step but hold a stale one from an earlier step are zeroed
         (torch FSDP with use_orig_params presents zero gradients for them, and AdamW still applies to them)."""
+        self.collect_autograd_grads()
         for _, p, _ in self.params:
             if p.requires_grad:
-                if p.grad is not None:
-                    # gradient delivered by autograd (small broadcast parameters: queries, mask token, position tables)
-                    if p._mg_touched:
-                        p.main_grad.add_(p.grad.to(torch.float32))
-                    else:
-                        p.main_grad.copy_(p.grad)
-                    p._mg_touched = True
-                    p.grad = None
                 if not p._mg_touched and p._mg_dirty:
                     p.main_grad.zero_()
                     p._mg_dirty = False
@@ -204,6 +209,7 @@ class ShardedModel:
         for b in model.buffers():
             b.data = b.data.to(device)
         self.step_count = 0
+        self.defer_reduce = False     # gradient accumulation: micro-batches before the last one only add into main_grad
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
         self._coef = torch.ones(1, dtype=torch.float32, device=device)
         self._norm = torch.zeros(1, dtype=torch.float32, device=device)
@@ -231,7 +237,7 @@ class ShardedModel:
 
     # ------------------------------------------------------------------------------------------ collectives
     def _launch_reduce_scatter(self, u: FlatUnit):
-        if not self.coll or not u.trainable or u.rs_event is not None:
+        if not self.coll or not u.trainable or u.rs_event is not None or self.defer_reduce:
             return
         cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if cur is not None:
@@ -280,6 +286,12 @@ class ShardedModel:
         for u in self.units:
             if getattr(u, "module", None) is None or self.device.type != "cuda":
                 self.wait_unit(u)
+
+    def finish_micro_backward(self):
+        """End of a backward that is not the last of its accumulation window: no reduction, no optimizer."""
+        for u in self.units:
+            if u.trainable:
+                u.collect_autograd_grads()
 
     def finish_backward(self):
         for u in self.units:

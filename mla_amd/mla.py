@@ -255,7 +255,8 @@ class MLA(nn.Module):
             raise NotImplementedError("prompt construction / tokenisation of `instruction` is a data adapter (SURVEY 8f rank 4): "
                                       "pass input_ids")
         if cfg_scale > 1.0:
-            raise NotImplementedError("classifier-free guidance (forward_with_cfg) is not used by the shipped evaluation (cfg_scale=0)")
+            raise NotImplementedError("classifier-free guidance: the reference calls self.vlm.forward_with_cfg (model_mla.py:718-729), which "
+                                      "PrismaticVLM does not define -- cfg_scale > 1 raises there too; the shipped evaluation uses cfg_scale=0")
         if not (torch.is_tensor(image) and image.is_floating_point()):
             # PIL image / uint8 HWC frame: the reference's CLIPImageProcessor step (:656-657), PIL-exact on the GPU
             image = self.vlm.get_vision_tower_2d().image_processor.preprocess(image, return_tensors="pt")["pixel_values"][0]

@@ -39,10 +39,27 @@ def cat_view(tensors: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
     return torch.as_strided(t0, (total, K), (K, 1))
 
 
+def _is_touched(w) -> bool:
+    """Whether main_grad (of a parameter, or of the region a param_view covers) already holds a contribution from this
+    accumulation window. The state of a view lives on its parent parameter: views are re-created every forward."""
+    region = getattr(w, "_mg_region", None)
+    if region is not None:
+        return bool(region[0]._mg_regions.get(region[1], False))
+    return bool(getattr(w, "_mg_touched", False))
+
+
+def _mark_touched(w) -> None:
+    region = getattr(w, "_mg_region", None)
+    if region is not None:
+        region[0]._mg_regions[region[1]] = True
+    else:
+        w._mg_touched = True
+
+
 def _touch(param) -> bool:
-    """Returns whether main_grad already holds a contribution from this step (then accumulate) and marks it."""
-    acc = bool(getattr(param, "_mg_touched", False))
-    param._mg_touched = True
+    """Returns whether main_grad already holds a contribution from this window (then accumulate) and marks it."""
+    acc = _is_touched(param)
+    _mark_touched(param)
     return acc
 
 
@@ -52,12 +69,12 @@ def deliver_wgrad(weights: Sequence[torch.Tensor], dy2: torch.Tensor, x2: torch.
     mgs = [getattr(w, "main_grad", None) for w in weights]
     if all(m is not None for m in mgs) and all(needs):
         mcat = cat_view(mgs)
-        states = {bool(getattr(w, "_mg_touched", False)) for w in weights}
+        states = {_is_touched(w) for w in weights}
         if mcat is not None and len(states) == 1:
             acc = states.pop()
             hip.gemm(dy2, x2, out=mcat, a_mode=1, b_mode=1, accumulate=acc)
             for w in weights:
-                w._mg_touched = True
+                _mark_touched(w)
             return grads
     off = 0
     for i, w in enumerate(weights):
@@ -79,11 +96,11 @@ def deliver_wgrad_nt(weights: Sequence[torch.Tensor], dyT: torch.Tensor, xT: tor
     mgs = [getattr(w, "main_grad", None) for w in weights]
     if all(m is not None for m in mgs) and all(needs):
         mcat = cat_view(mgs)
-        states = {bool(getattr(w, "_mg_touched", False)) for w in weights}
+        states = {_is_touched(w) for w in weights}
         if mcat is not None and len(states) == 1:
             hip.gemm(dyT, xT, out=mcat, accumulate=states.pop())
             for w in weights:
-                w._mg_touched = True
+                _mark_touched(w)
             return grads
     off = 0
     for i, w in enumerate(weights):
@@ -613,7 +630,9 @@ def param_view(param: torch.Tensor, lo: Optional[int] = None, hi: Optional[int] 
     if mg is not None:
         g = mg if lo is None else mg[lo:hi]
         v.main_grad = g.view(shape) if shape is not None else g
-        v._mg_touched = False
+        if not hasattr(param, "_mg_regions") or not getattr(param, "_mg_touched", False):
+            param._mg_regions = {}    # first view of this accumulation window (FlatUnit.begin_step cleared _mg_touched)
+        v._mg_region = (param, (lo, hi))
         param._mg_touched = True      # every region of the parameter is written each step by its views
     return v
 

@@ -1,8 +1,9 @@
 """Training strategy counterpart (reference: training/strategies/base_strategy_mla.py:251-404 run_vla_training and
 training/strategies/fsdp.py:176-310 run_setup / clip_grad_norm), driving mla_amd.fsdp.ShardedModel.
 
-One call to ``train_step(batch)`` = one micro-step of the reference's hot loop with grad_accumulation_steps == 1:
-forward (bf16), backward, global grad-norm clip, AdamW step, LR-scheduler step. Logging / W&B / checkpoint I/O of the
+One call to ``train_step(batch)`` = one micro-step of the reference's hot loop: forward (bf16), backward and -- on the last
+micro-batch of an accumulation window (every call when grad_accumulation_steps == 1, the shipped setting) -- global grad-norm
+clip, AdamW step, LR-scheduler step. Logging / W&B / checkpoint I/O of the
 reference's loop are out of scope; the loss dict keys are the reference's (base_strategy_mla.py:326-334).
 """
 from __future__ import annotations
@@ -47,9 +48,8 @@ class FSDPStrategy:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         assert self.global_batch_size % (self.per_device_batch_size * self.world) == 0
         self.grad_accumulation_steps = self.global_batch_size // self.per_device_batch_size // self.world
-        if self.grad_accumulation_steps != 1:
-            raise NotImplementedError("gradient accumulation > 1 (every shipped script uses global = per-device x world)")
-        self.step = 0
+        self.step = 0               # optimizer steps taken
+        self._micro = 0             # micro-batches seen inside the current accumulation window
         self.num_training_steps = self.num_warmup_steps = 0
 
     def run_setup(self, n_train_examples: int = 0, run_dir=None) -> None:
@@ -86,8 +86,16 @@ class FSDPStrategy:
         return {k: c(v) for k, v in batch.items()}
 
     def train_step(self, batch: Dict) -> Dict[str, torch.Tensor]:
+        """One micro-batch of the hot loop (base_strategy_mla.py:296-377). With grad_accumulation_steps == 1 (every shipped
+        script) that is one optimizer step; otherwise the loss is divided by the window length (:365), gradients add up in the
+        fp32 main_grad buffers, and only the last micro-batch of the window reduce-scatters, clips and steps (:370-377). The
+        reference's FSDP reduces after every micro-batch; reducing the fp32 sum once is the same sum with fewer collectives."""
         sm = self.sharded
-        sm.begin_step()
+        acc = self.grad_accumulation_steps
+        last = self._micro == acc - 1
+        if self._micro == 0:
+            sm.begin_step()
+        sm.defer_reduce = not last
         self.vlm.train()
         b = self._cast_inputs(batch)
         loss_dict, _output = self.vlm(
@@ -96,11 +104,16 @@ class FSDPStrategy:
             tactile=b.get("tactile"), next_tactile=b.get("next_tactile"), labels=b["labels"], actions=b["actions"],
             proprio=b["proprio"], gripper_xyz=b.get("gripper_xyz"), action_masks=b.get("action_masks"), output_hidden_states=True,
             repeated_diffusion_steps=self.repeated_diffusion_steps, use_diff=True)
-        loss_dict["total_loss"].backward()
-        sm.finish_backward()
-        self.clip_grad_norm()
-        sm.optimizer_step(self.current_lr(), weight_decay=self.weight_decay)
-        self.step += 1
+        (loss_dict["total_loss"] if acc == 1 else loss_dict["total_loss"] / acc).backward()
+        if last:
+            sm.finish_backward()
+            self.clip_grad_norm()
+            sm.optimizer_step(self.current_lr(), weight_decay=self.weight_decay)
+            self.step += 1
+            self._micro = 0
+        else:
+            sm.finish_micro_backward()
+            self._micro += 1
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
 
     # ------------------------------------------------------------------------------------------ checkpoints

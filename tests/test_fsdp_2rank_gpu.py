@@ -35,27 +35,41 @@ def _build(dev):
     return m
 
 
-def _run(rank, world, dev):
-    """Runs STEPS optimizer steps on this rank's slice of the global batch of 2; returns (losses, grad norms, weights)."""
+def _run(rank, world, dev, accumulate=False):
+    """Runs STEPS optimizer steps on this rank's slice of the global batch of 2; returns (losses, grad norms, weights).
+    accumulate=True: one process, per-device batch 1, the two samples as two micro-batches of one accumulation window."""
     from mla_amd.strategy import FSDPStrategy
     from oracle import recipe
     R = 2
     m = _build(dev)
-    strat = FSDPStrategy(m, 0, global_batch_size=2, per_device_batch_size=2 // world, learning_rate=1e-3, weight_decay=0.01,
+    split = world > 1 or accumulate
+    strat = FSDPStrategy(m, 0, global_batch_size=2, per_device_batch_size=1 if split else 2, learning_rate=1e-3, weight_decay=0.01,
                          max_grad_norm=1.0, lr_scheduler_type="constant", enable_gradient_checkpointing=False, repeated_diffusion_steps=R)
+    assert strat.grad_accumulation_steps == (2 if accumulate else 1)
     strat.run_setup(100)
     batch, draws = recipe.make_batch(B=2, R=R, ragged=False)
-    sel = slice(None) if world == 1 else slice(rank, rank + 1)
-    rows = torch.arange(2 * R) if world == 1 else torch.tensor([rank, rank + 2])       # tiled order: [s0, s1, s0, s1]
-    b = {k: (v[sel] if torch.is_tensor(v) else v) for k, v in batch.items() if k not in ("images", "point_cloud")}
-    b["images"] = {"front_image": batch["images"]["front_image"][sel]}
     orig = m.forward
-    m.forward = lambda **kw: orig(**kw, noise=draws["noise"][rows].to(dev), timestep=draws["timestep"][rows].to(dev))
+
+    def micro(part):
+        """part None: both samples; 0 / 1: that sample (and its rows of the tiled draws: order [s0, s1, s0, s1])."""
+        sel = slice(None) if part is None else slice(part, part + 1)
+        rows = torch.arange(2 * R) if part is None else torch.tensor([part, part + 2])
+        b = {k: (v[sel] if torch.is_tensor(v) else v) for k, v in batch.items() if k not in ("images", "point_cloud")}
+        b["images"] = {"front_image": batch["images"]["front_image"][sel]}
+        m.forward = lambda **kw: orig(**kw, noise=draws["noise"][rows].to(dev), timestep=draws["timestep"][rows].to(dev))
+        return strat.train_step(b)
     losses, norms = [], []
     for _ in range(STEPS):
-        out = strat.train_step(b)
-        losses.append(float(out["total_loss"]))
+        if accumulate:
+            first = micro(0)
+            assert strat.step == len(losses)                      # no optimizer step inside the window
+            out = micro(1)
+            losses.append(0.5 * (float(first["total_loss"]) + float(out["total_loss"])))
+        else:
+            out = micro(None if world == 1 else rank)
+            losses.append(float(out["total_loss"]))
         norms.append(float(strat.sharded._norm))
+    assert strat.step == STEPS
     full = strat.sharded.full_state_dict_fp32()
     keys = ("vlm.llm_backbone.llm.model.layers.3.mlp.down_proj.weight", "vlm.llm_backbone.llm.model.layers.0.self_attn.q_proj.weight",
             "vlm.projector_2d.mlp.2.weight", "vlm.final_layer.mlp.fc1.weight", "vlm.llm_backbone.llm.model.norm.weight",
@@ -106,4 +120,21 @@ def test_two_ranks_match_single_process(dev):
         du2, du1 = r0["weights"][k] - init[k], single["weights"][k] - init[k]
         cos = float((du2 * du1).sum() / (np.linalg.norm(du2) * np.linalg.norm(du1) + 1e-30))
         assert cos > 0.9, (k, cos)                 # AdamW's first steps are sign-like: bf16-level gradient noise flips tiny entries
+        assert abs(np.linalg.norm(du2) / np.linalg.norm(du1) - 1) < 0.1, k
+
+
+def test_gradient_accumulation_matches_one_big_batch(dev):
+    """grad_accumulation_steps = 2 (base_strategy_mla.py:100, :365-377): two micro-batches of one sample, loss / 2, one clip + AdamW
+    step per window == one step on both samples, up to bf16 rounding (same bounds as the data-parallel comparison above)."""
+    from oracle import recipe
+    single = _run(0, 1, dev)
+    acc = _run(0, 1, dev, accumulate=True)
+    for st in range(STEPS):
+        assert abs(acc["losses"][st] - single["losses"][st]) < 1e-2 * max(1.0, abs(single["losses"][st]))
+        assert abs(acc["norms"][st] - single["norms"][st]) < 5e-2 * single["norms"][st], (st, acc["norms"][st], single["norms"][st])
+    init = {k: recipe.det_weight(k, v.shape).numpy() for k, v in acc["weights"].items()}
+    for k in acc["weights"]:
+        du2, du1 = acc["weights"][k] - init[k], single["weights"][k] - init[k]
+        cos = float((du2 * du1).sum() / (np.linalg.norm(du2) * np.linalg.norm(du1) + 1e-30))
+        assert cos > 0.9, (k, cos)
         assert abs(np.linalg.norm(du2) / np.linalg.norm(du1) - 1) < 0.1, k
