@@ -120,7 +120,11 @@ class LLaMa2LLMBackbone(LLMBackbone):
 
     @property
     def prompt_builder_fn(self):
-        raise NotImplementedError("prompt construction belongs to the data pipeline (SURVEY 8f rank 4)")
+        """llama2.py:81-91: the pure builder for `llama2-*-pure` identifiers (the shipped `llama2-7b-pure`)."""
+        if self.identifier.startswith("llama2-") and self.identifier.endswith("-pure"):
+            from .data_utils import PurePromptBuilder
+            return PurePromptBuilder
+        raise ValueError(f"No PromptBuilder defined for LLM Backbone `{self.identifier}` (only the `-pure` Llama-2 builder is built)")
 
     def get_fsdp_wrapping_policy(self) -> Callable:
         cls = self.transformer_layer_cls

@@ -240,20 +240,27 @@ class MLA(nn.Module):
                             action_dim: int = 7, *, input_ids: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
                             camera_name: str = "rlbench_front", **kwargs) -> np.ndarray:
         """model_mla.py:592-775: 8-step DDIM (eta = 0) over the action chunk with the VLM as the epsilon model, then
-        un-normalisation. The model side and the image adapter are complete; prompt construction needs the Llama tokenizer (not in this image), so
+        un-normalisation.
         * ``image`` is a PIL image / uint8 HWC frame (pre-processed here like the reference does, :656-660) or an already
           pre-processed float tensor [3|4, 672, 672]; a ones mask channel is appended when missing;
-        * the prompt arrives tokenised as ``input_ids`` [1, L] (the reference builds it from ``instruction`` with the Llama
-          tokenizer and appends [29871, 32001, 32002, 29871], then drops the last three ids, :629-645, :711-713); pass the ids in
-          either form: if the last id is not 29871 the tail is appended here.
+        * the prompt is built from ``instruction`` with the backbone's prompt builder and tokenizer like the reference does
+          (:626-632; the Llama tokenizer files are not in this image, so a tokenizer has to be attached), or arrives tokenised as
+          ``input_ids`` [1, L]; [29871, 32001, 32002, 29871] is appended unless the last id already is 29871 and the last three ids
+          are dropped again (:640-645, :711-713).
         ``noise`` optionally fixes the initial sample (the reference draws it with torch.randn, :707). ``camera_name``: the shipped
         method does not forward it, so the reference's get_camera_params(None) raises (camera.py:54-56); it is an explicit
         argument here (the evaluation scripts use the RLBench front camera)."""
         self.vlm.eval()
         device = next(self.vlm.parameters()).device
         if input_ids is None:
-            raise NotImplementedError("prompt construction / tokenisation of `instruction` is a data adapter (SURVEY 8f rank 4): "
-                                      "pass input_ids")
+            # :626-632 -- prompt text from the backbone's builder, ids from the backbone's tokenizer (the Llama tokenizer files are not
+            # in this image: attach one as vlm.llm_backbone.tokenizer, or pass input_ids)
+            tokenizer = getattr(self.vlm.llm_backbone, "tokenizer", None)
+            if instruction is None or tokenizer is None or not callable(tokenizer):
+                raise ValueError("predict_action_diff needs `input_ids`, or `instruction` plus a callable vlm.llm_backbone.tokenizer")
+            builder = self.vlm.llm_backbone.prompt_builder_fn("openvla")
+            builder.add_turn(role="human", message=f"What action should the robot take to {instruction.lower()}?")
+            input_ids = tokenizer(builder.get_prompt(), truncation=True, return_tensors="pt").input_ids
         if cfg_scale > 1.0:
             raise NotImplementedError("classifier-free guidance: the reference calls self.vlm.forward_with_cfg (model_mla.py:718-729), which "
                                       "PrismaticVLM does not define -- cfg_scale > 1 raises there too; the shipped evaluation uses cfg_scale=0")

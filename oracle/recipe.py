@@ -3,6 +3,7 @@ and the tests (GPU box, no reference): everything is a function of the tensor's 
 image files have to be committed -- only the captured outputs are stored under tests/golden/."""
 import zlib
 
+import numpy as np
 import torch
 
 TINY_LLAMA = dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=9, num_attention_heads=2,
@@ -90,3 +91,57 @@ def make_batch(B: int = 2, L: int = 16, R: int = 2, ragged: bool = True, seed: i
         batch["next_images"] = torch.randn(B, 3, img, img, generator=_gen("next_images", seed))
         batch["next_point_cloud"] = lo + (hi - lo) * torch.rand(B, n_points, 3, generator=_gen("next_pc", seed))
     return batch, draws
+
+
+# ------------------------------------------------------------------------------------------------- data-side fixtures
+class ToyTokenizer:
+    """Stand-in for the Llama tokenizer (absent from the image) with the three calls the data transform makes: ``decode`` /
+    ``batch_decode`` print id i as "<i>", ``__call__`` maps "<i>" back to i, "</s>" to 2, any other character to 3 + ord % 200, and
+    prepends BOS (1) with add_special_tokens. One id per action token, like the real vocabulary tail."""
+    vocab_size, pad_token_id, padding_side = 1000, 999, "right"
+
+    def decode(self, ids):
+        return "".join(f"<{int(i)}>" for i in ids)
+
+    def batch_decode(self, rows):
+        return [self.decode(r) for r in rows]
+
+    def __call__(self, text, add_special_tokens=True):
+        import re
+        ids = [1] if add_special_tokens else []
+        for tok in re.findall(r"</s>|<\d+>|.", text, flags=re.S):
+            ids.append(2 if tok == "</s>" else int(tok[1:-1]) if (len(tok) > 2 and tok[1:-1].isdigit()) else 3 + ord(tok) % 200)
+        return type("Enc", (), {"input_ids": ids})()
+
+
+class ToyImageTransform:
+    """Deterministic stand-in for CLIPImageProcessor.preprocess (its arithmetic has its own fixture, tests/golden/preprocess.npz):
+    nearest-neighbour 224 -> 672 and /255, returned the way HF does ({"pixel_values": [tensor]})."""
+
+    def preprocess(self, img, return_tensors="pt"):
+        a = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float() / 255.0
+        return {"pixel_values": [a.repeat_interleave(3, 1).repeat_interleave(3, 2)]}
+
+
+def make_rlds_sample(window: int = 1, with_wrist: bool = False, with_tactile: bool = False, with_pc: bool = False, seed: int = 0):
+    """One sample in the layout RLDSBatchTransform reads (vla/datasets/datasets.py:39-110)."""
+    rng = np.random.default_rng(seed)
+    img = lambda: rng.integers(0, 256, (1, 224, 224, 3), dtype=np.uint8)  # noqa: E731
+    obs = {"image_primary": img(), "image_next_primary": img(), "proprio": rng.uniform(-1.2, 1.2, (window, 7)).astype(np.float32)}
+    if with_wrist:
+        obs["image_wrist_right"], obs["image_wrist_left"] = img(), img()
+    if with_tactile:
+        for k in ("tactile_right", "tactile_left", "next_tactile_right", "next_tactile_left"):
+            t = rng.integers(0, 400, (1, 6)).astype(np.float32)
+            t[0, rng.integers(0, 6)] = 65535
+            obs[k] = t
+        obs["gripper_xyz"] = rng.uniform(0, 1, (1, 3)).astype(np.float32)
+    if with_pc:
+        obs["point_cloud"] = rng.uniform(0, 1, (1, 64, 3)).astype(np.float32)
+        obs["next_point_cloud"] = rng.uniform(0, 1, (1, 64, 3)).astype(np.float32)
+    return {"dataset_name": b"rlbench", "action": rng.uniform(-1.3, 1.3, (window, 7)).astype(np.float32), "observation": obs,
+            "task": {"language_instruction": b"Close The Jar <image> now"}, "action_mask": np.ones((window, 7), dtype=bool)}
+
+
+RLDS_CASES = {"plain": dict(), "window3_wrist": dict(window=3, with_wrist=True), "tactile_pc": dict(with_tactile=True, with_pc=True),
+              "no_action_tok": dict(), "no_stop": dict(window=2)}

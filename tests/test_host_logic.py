@@ -297,3 +297,60 @@ def test_padded_collator_matches_reference_semantics():
                 assert all(torch.equal(v[kk], out[k][kk]) for kk in v), k
             else:
                 assert v == out[k], k
+
+
+def test_rlds_batch_transform_matches_reference_golden():
+    """Data-side transform: prompt text, action-token order, label masking, mask channel, tactile clean-up, against
+    vectors captured from the reference's own classes with the same toy tokenizer / image transform (oracle/capture_golden_transform.py)."""
+    from mla_amd.data_utils import ActionTokenizer, PurePromptBuilder, RLDSBatchTransform
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "transform.npz"), allow_pickle=True)
+    tok = recipe.ToyTokenizer()
+    for name, kw in recipe.RLDS_CASES.items():
+        at = None if name == "no_action_tok" else ActionTokenizer(tok)
+        tf = RLDSBatchTransform(at, tok, recipe.ToyImageTransform(), PurePromptBuilder, predict_stop_token=name != "no_stop",
+                                use_pointcloud=kw.get("with_pc", False), use_tactile=kw.get("with_tactile", False))
+        out = tf(recipe.make_rlds_sample(**kw))
+        seen = 0
+        for k, v in out.items():
+            if k == "images":
+                assert sorted(f"{name}::images.{c}" for c in v) == sorted(f for f in gold.files if f.startswith(f"{name}::images."))
+                for cam, t in v.items():
+                    assert t.shape == (4, 672, 672) and np.array_equal(t[:, ::37, ::41].numpy(), gold[f"{name}::images.{cam}"]), (name, cam)
+                    seen += 1
+            elif torch.is_tensor(v):
+                got = (v[:, ::37, ::41] if k == "next_images" else v).numpy()
+                ref = gold[f"{name}::{k}"]
+                assert got.dtype == ref.dtype and np.array_equal(got, ref), (name, k)
+                seen += 1
+            elif v is None:
+                assert str(gold[f"{name}::{k}"]) == "None", (name, k)
+                seen += 1
+        assert seen == sum(f.startswith(name + "::") for f in gold.files)
+        assert out["dataset_name"] == b"rlbench"
+    at = ActionTokenizer(tok)
+    a = np.linspace(-1.5, 1.5, 1001)
+    assert np.array_equal(at.token_ids(a), gold["at_ids"]) and at(a[::100]) == str(gold["at_str"])
+    assert np.array_equal(at.decode_token_ids_to_actions(np.arange(tok.vocab_size - 257, tok.vocab_size)), gold["at_decode"])
+    assert at.action_token_begin_idx == int(gold["at_begin"]) and at.vocab_size == 256
+    pb = PurePromptBuilder("openvla")
+    pb.add_turn("human", " <image> What now? ")
+    pb.add_turn("gpt", "")
+    assert pb.get_prompt() == str(gold["pb_prompt"]) and pb.get_potential_prompt("and then?") == str(gold["pb_potential"])
+    # the transform feeds the collator
+    from mla_amd.data_utils import PaddedCollatorForActionPrediction
+    tf = RLDSBatchTransform(ActionTokenizer(tok), tok, recipe.ToyImageTransform(), PurePromptBuilder, use_pointcloud=True, use_tactile=True)
+    items = [tf(recipe.make_rlds_sample(with_tactile=True, with_pc=True, seed=s)) for s in (0, 1)]
+    batch = PaddedCollatorForActionPrediction(64, tok.pad_token_id)(items)
+    assert batch["input_ids"].shape == batch["labels"].shape and batch["images"]["front_image"].shape == (2, 4, 672, 672)
+    assert batch["tactile"].shape == (2, 12) and batch["point_cloud"].shape == (2, 64, 3)
+
+
+def test_prompt_builder_selection():
+    from mla_amd.backbones import LLaMa2LLMBackbone
+    from mla_amd.data_utils import PurePromptBuilder
+    bb = LLaMa2LLMBackbone.__new__(LLaMa2LLMBackbone)
+    bb.identifier = "llama2-7b-pure"
+    assert bb.prompt_builder_fn is PurePromptBuilder
+    bb.identifier = "llama2-7b-chat"
+    with pytest.raises(ValueError):
+        bb.prompt_builder_fn

@@ -113,3 +113,29 @@ def test_predict_action_diff_from_uint8_frame(dev, model):
     pv = m.vlm.get_vision_tower_2d().image_processor.preprocess(frame)["pixel_values"][0]
     a2 = m.predict_action_diff(image=pv, pointcloud=pc[0], cur_robot_state=proprio[0, 0].numpy(), input_ids=ids, noise=noise)
     assert a1.shape == (4, 7) and np.allclose(a1, a2, rtol=1e-5, atol=1e-6)
+
+
+def test_predict_action_diff_from_instruction(dev, model):
+    """`instruction` path (model_mla.py:626-645): prompt from the backbone's builder, ids from the attached tokenizer, the
+    [29871, 32001, 32002, 29871] tail appended and its last three ids dropped == passing those ids directly."""
+    m, _ = model
+    ids, image, pc, proprio, noise, _ = infer_inputs()
+    seen = {}
+
+    class Tok:
+        def __call__(self, text, truncation=True, return_tensors="pt"):
+            seen["text"] = text
+            return type("Enc", (), {"input_ids": ids[:, :-1].clone()})()
+    bb = m.vlm.llm_backbone
+    old_tok, old_id = getattr(bb, "tokenizer", None), bb.identifier
+    bb.tokenizer, bb.identifier = Tok(), "llama2-7b-pure"
+    try:
+        a1 = m.predict_action_diff(image=image[0], pointcloud=pc[0], instruction="Close The JAR", cur_robot_state=proprio[0, 0].numpy(),
+                                   noise=noise)
+    finally:
+        bb.tokenizer, bb.identifier = old_tok, old_id
+    assert seen["text"] == "In: What action should the robot take to close the jar?\nOut:"
+    a2 = m.predict_action_diff(image=image[0], pointcloud=pc[0], cur_robot_state=proprio[0, 0].numpy(), input_ids=ids, noise=noise)
+    assert np.allclose(a1, a2, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        m.predict_action_diff(image=image[0], pointcloud=pc[0], cur_robot_state=proprio[0, 0].numpy(), noise=noise)
