@@ -98,8 +98,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int m0 = pid_m * 256, n0 = pid_n * 256;
 
   // ---- staging pointers: [slot][it]; each advances one K-tile per use
-  const size_t stepA = (dbg & 2) ? 64 : (AMODE == 0 ? 64 : (size_t)64 * p.lda);
-  const size_t stepB = (dbg & 2) ? 64 : (BMODE == 0 ? 64 : (size_t)64 * p.ldb);
+  // dbg & 64: every K-tile re-loads K-tile 0 (always an L2 hit, no fabric traffic); timing / power experiments only
+  const size_t stepA = (dbg & 64) ? 0 : (dbg & 2) ? 64 : (AMODE == 0 ? 64 : (size_t)64 * p.lda);
+  const size_t stepB = (dbg & 64) ? 0 : (dbg & 2) ? 64 : (BMODE == 0 ? 64 : (size_t)64 * p.ldb);
   const bf16_t* pA0[2]; const bf16_t* pA1[2]; const bf16_t* pB0[2]; const bf16_t* pB1[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   do {                                                                                            \
     const size_t back__ = (TCNT < nt) ? 0 : (size_t)TCNT * (STEP); /* dummy re-load of K-tile 0 past the end */ \
     char* dst__ = smem + (TCNT & 1) * BUF + (SLOTOFF) + wave * 2048;                              \
-    if (!NO_STAGE) {                                                                              \
+    if (!NO_STAGE || TCNT < 2) { /* ablation: the first two K-tiles are real, so LDS holds real operands */ \
       glds16(PTR[0] - back__, dst__);                                                             \
       glds16(PTR[1] - back__, dst__ + 1024);                                                      \
     }                                                                                             \
@@ -186,19 +187,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
-  if (NO_READ) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { fa[i][0] = fa[i][1] = bf16x8_t{}; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { fb0[i][0] = fb0[i][1] = fb1[i][0] = fb1[i][1] = bf16x8_t{}; }
-  }
+  bool rd_on = true;   // ablation NO_READ: fragments are read for the first two K-tiles only (registers keep real operands)
 
 #define READ_A(SLOTP)                                              \
-  if (!NO_READ) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) { \
+  if (rd_on) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) {    \
     fa[rb][0] = ldA(SLOTP, rb, 0); fa[rb][1] = ldA(SLOTP, rb, 1);  \
   }
 #define READ_B(DST, SLOTP)                                          \
-  if (!NO_READ) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {  \
+  if (rd_on) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {     \
     DST[cb][0] = ldB(SLOTP, cb, 0); DST[cb][1] = ldB(SLOTP, cb, 1); \
   }
 #define SEG_END()                                                  \
@@ -239,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   {                                                                  \
     const char* buf = smem + ((T_) & 1) * BUF;                       \
     const char* nbuf = smem + (((T_) + 1) & 1) * BUF;                \
+    if (NO_READ) rd_on = (T_) < 2;                                   \
     STAGE(pB1, tB1, stepB, SB1);                                     \
     READ_A(buf + SA0)                                                \
     SEG_END()                                                        \
@@ -333,6 +330,279 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef MMA
 }
 
+// ------------------------------------------------------------------------------------------------ persistent variant (NT)
+// One workgroup per CU walks a static list of work units (whole tiles, then at most a few split-K tail slices) with the K-tile
+// ring running CONTINUOUSLY across units: while the last K-tiles of unit u are multiplied, the staging cursors are already
+// loading the first K-tiles of unit u+1, so the pipeline fill of every tile but the first is hidden, and there is no workgroup
+// launch between tiles (measured on the non-persistent kernel: ~19 us per tile at K = 4096, 19 % of a 64-K-tile tile).
+// Staging uses buffer_load ... lds with the tensor as the buffer resource: per-lane offsets inside a tile are constants
+// (VGPRs), everything that changes from K-tile to K-tile and from unit to unit is a scalar offset (SGPRs); rows beyond M / N
+// are out of range of the resource and read as zero, so edge tiles need no clamping.
+// Unit order: XCD x (= blockIdx & 7, the hardware's round-robin) owns a contiguous range of tile ids, its W = gridDim / 8
+// workgroups take ids start + j + W * i, i.e. at any time the XCD works on W consecutive ids (a GROUP_M x W/GROUP_M block
+// of tiles sharing operand panels in its L2), exactly like the remapped non-persistent launch.
+struct Unit {
+  int m0, n0, kt0, nt;
+  float* part;
+};
+
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
+  const int GROUP_M = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int li = lane & 15, lg = lane >> 4;
+  const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
+  const int ntK = p.K / 64;
+
+  // ---- this workgroup's unit list
+  const int G = gridDim.x, W = G >> 3, b = blockIdx.x, x = b & 7, j = b >> 3;
+  const int F = p.sk_split > 1 ? p.sk_full : num_m * num_n;           // whole tiles
+  const int q8 = F >> 3, r8 = F & 7;
+  const int cnt_x = q8 + (x < r8 ? 1 : 0);
+  const int start_x = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+  const int nfull = j < cnt_x ? (cnt_x - j + W - 1) / W : 0;
+  const int tail_units = p.sk_split > 1 ? (num_m * num_n - p.sk_full) * p.sk_split : 0;
+  const int ntail = b < tail_units ? (tail_units - b + G - 1) / G : 0;
+  const int n_units = nfull + ntail;
+  if (n_units == 0) return;
+  auto get_unit = [&](int i) -> Unit {
+    Unit u;
+    int pid;
+    if (i < nfull) {
+      pid = start_x + j + W * i;
+      u.kt0 = 0; u.nt = ntK; u.part = nullptr;
+    } else {
+      const int t = b + (i - nfull) * G;
+      const int slice = t % p.sk_split;
+      pid = p.sk_full + t / p.sk_split;
+      u.kt0 = (int)((long long)slice * ntK / p.sk_split);
+      u.nt = (int)((long long)(slice + 1) * ntK / p.sk_split) - u.kt0;
+      u.part = p.sk_ws + (size_t)t * 65536;
+    }
+    const int in_group = GROUP_M * num_n;
+    const int first_m = (pid / in_group) * GROUP_M;
+    const int gsz = (num_m - first_m) < GROUP_M ? (num_m - first_m) : GROUP_M;
+    u.m0 = __builtin_amdgcn_readfirstlane((first_m + (pid % in_group) % gsz) * 256);
+    u.n0 = __builtin_amdgcn_readfirstlane(((pid % in_group) / gsz) * 256);
+    u.kt0 = __builtin_amdgcn_readfirstlane(u.kt0);
+    u.nt = __builtin_amdgcn_readfirstlane(u.nt);
+    return u;
+  };
+
+  // ---- staging: resources, per-lane offsets, per-slot scalar cursors
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((size_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(((size_t)(p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
+  int voA[2], voB[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = (wave * 2 + it) * 64 + lane;
+    const int rp = q >> 3, cp = q & 7;
+    const int c = cp ^ (rp & 7);
+    voA[it] = (rp * p.lda + c * 8) * 2;
+    voB[it] = (rp * p.ldb + c * 8) * 2;
+  }
+  const int rowA = p.lda * 2, rowB = p.ldb * 2;      // bytes per operand row
+  // slot X in {A0, B0, B1, A1}: so = scalar byte offset of the next K-tile to stage, left = K-tiles left in its unit, su = unit
+  // index, t = running K-tile count (LDS buffer parity)
+  int soA0, soB0, soB1, soA1, leftA0, leftB0, leftB1, leftA1, suA0 = 0, suB0 = 0, suB1 = 0, suA1 = 0, tA0 = 0, tB0 = 0, tB1 = 0, tA1 = 0;
+  Unit cu = get_unit(0);
+  soA0 = cu.m0 * rowA + cu.kt0 * 128;
+  soA1 = (cu.m0 + 128) * rowA + cu.kt0 * 128;
+  soB0 = cu.n0 * rowB + cu.kt0 * 128;
+  soB1 = (cu.n0 + 128) * rowB + cu.kt0 * 128;
+  leftA0 = leftB0 = leftB1 = leftA1 = cu.nt;
+
+#define PSTAGE(X, RS, VO, ROWB, ISA, HALF, SLOTOFF)                                                                        \
+  do {                                                                                                                     \
+    char* dst__ = smem + (t##X & 1) * BUF + (SLOTOFF) + wave * 2048;                                                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (MLA_LDS_AS void*)dst__, 16, VO[0], so##X, 0, 0);                         \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (MLA_LDS_AS void*)(dst__ + 1024), 16, VO[1], so##X, 0, 0);                \
+    so##X += 128; ++t##X;                                                                                                  \
+    if (--left##X == 0) {                                                                                                  \
+      if (++su##X < n_units) {                                                                                             \
+        const Unit nu__ = get_unit(su##X);                                                                                 \
+        so##X = ((ISA ? nu__.m0 : nu__.n0) + (HALF) * 128) * (ROWB) + nu__.kt0 * 128;                                      \
+        left##X = nu__.nt;                                                                                                 \
+      } else {                                                                                                             \
+        left##X = 0x7fffffff;   /* past the last unit: harmless loads (in range or zero-filled) into dead slots */         \
+      }                                                                                                                    \
+    }                                                                                                                      \
+  } while (0)
+#define ST_A0() PSTAGE(A0, rsA, voA, rowA, true, 0, SA0)
+#define ST_A1() PSTAGE(A1, rsA, voA, rowA, true, 1, SA1)
+#define ST_B0() PSTAGE(B0, rsB, voB, rowB, false, 0, SB0)
+#define ST_B1() PSTAGE(B1, rsB, voB, rowB, false, 1, SB1)
+
+  // ---- fragment read offsets (bytes inside a slot)
+  const int offA = (wr * 64 + li) * 128 + ((lg ^ (li & 7)) * 16);
+  const int offB = (wc * 32 + li) * 128 + ((lg ^ (li & 7)) * 16);
+  auto ldA = [&](const char* slot, int rb, int ks) -> bf16x8_t { return *(const bf16x8_t*)(slot + ((offA + rb * 2048) ^ (ks * 64))); };
+  auto ldB = [&](const char* slot, int cb, int ks) -> bf16x8_t { return *(const bf16x8_t*)(slot + ((offB + cb * 2048) ^ (ks * 64))); };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+
+#define PREAD_A(SLOTP)                                             \
+  _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) {               \
+    fa[rb][0] = ldA(SLOTP, rb, 0); fa[rb][1] = ldA(SLOTP, rb, 1);  \
+  }
+#define PREAD_B(DST, SLOTP)                                         \
+  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                \
+    DST[cb][0] = ldB(SLOTP, cb, 0); DST[cb][1] = ldB(SLOTP, cb, 1); \
+  }
+#define PSEG_END()                                   \
+  __builtin_amdgcn_sched_barrier(0);                 \
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   \
+  __builtin_amdgcn_s_barrier();                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0);
+#define PMMA(QI, QJ, FB)                                                                                         \
+  __builtin_amdgcn_s_setprio(1);                                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+  _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                               \
+  _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                               \
+    acc[QI * 4 + rb][QJ * 2 + cb] =                                                                              \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[cb][ks], fa[rb][ks], acc[QI * 4 + rb][QJ * 2 + cb], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                             \
+  asm volatile("" ::: "memory");                                                                                 \
+  __builtin_amdgcn_s_barrier();                                                                                  \
+  asm volatile("" ::: "memory");
+#define PTILE(X, Y, PAR)                                             \
+  {                                                                  \
+    const char* buf = smem + (PAR) * BUF;                            \
+    const char* nbuf = smem + (1 - (PAR)) * BUF;                     \
+    ST_B1();                                                         \
+    PREAD_A(buf + SA0)                                               \
+    PSEG_END()                                                       \
+    PMMA(0, 0, X)                                                    \
+    ST_A1();                                                         \
+    PREAD_B(Y, buf + SB1)                                            \
+    PSEG_END()                                                       \
+    PMMA(0, 1, Y)                                                    \
+    ST_A0();                                                         \
+    PREAD_A(buf + SA1)                                               \
+    PSEG_END()                                                       \
+    PMMA(1, 1, Y)                                                    \
+    ST_B0();                                                         \
+    PREAD_B(Y, nbuf + SB0)                                           \
+    PSEG_END()                                                       \
+    PMMA(1, 0, X)                                                    \
+  }
+
+  // epilogue of the current unit (same arithmetic and store pattern as gemm256_kernel), then clear the accumulators
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    const int m0 = cu.m0, n0 = cu.n0;
+    if (cu.part) {
+      float* part = cu.part;
+#pragma unroll
+      for (int ri = 0; ri < 8; ++ri) {
+        const int ml = (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const int nl = (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
+          *(f32x4_t*)(part + ml * 256 + nl) = acc[ri][ci];
+        }
+      }
+    } else {
+      const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0);
+#pragma unroll
+      for (int ri = 0; ri < 8; ++ri) {
+        const int m = m0 + (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const int n = n0 + (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
+          if (n >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[ri][ci][r] * p.alpha;
+          if (n + 3 < p.N && vec_ok) {
+            if (p.bias) {
+              const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
+              v[0] += bflo(bb[0]); v[1] += bfhi(bb[0]); v[2] += bflo(bb[1]); v[3] += bfhi(bb[1]);
+            }
+            if (p.R) {
+              const u32x2_t rr = *(const u32x2_t*)(p.R + (size_t)m * p.ldr + n);
+              v[0] += bflo(rr[0]); v[1] += bfhi(rr[0]); v[2] += bflo(rr[1]); v[3] += bfhi(rr[1]);
+            }
+            if (p.out_fp32) {
+              float* c = (float*)p.C + (size_t)m * p.ldc + n;
+              f32x4_t o = {v[0], v[1], v[2], v[3]};
+              if (p.accumulate) o += *(const f32x4_t*)c;
+              *(f32x4_t*)c = o;
+            } else {
+              u32x2_t o;
+              o[0] = pack2bf(v[0], v[1]);
+              o[1] = pack2bf(v[2], v[3]);
+              *(u32x2_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            }
+          } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) {
+              float xv = v[r];
+              if (p.bias) xv += bf2f(p.bias[n + r]);
+              if (p.R) xv += bf2f(p.R[(size_t)m * p.ldr + n + r]);
+              if (p.out_fp32) {
+                float* c = (float*)p.C + (size_t)m * p.ldc + n + r;
+                *c = p.accumulate ? (*c + xv) : xv;
+              } else {
+                ((bf16_t*)p.C)[(size_t)m * p.ldc + n + r] = f2bf(xv);
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- prologue: K-tiles 0 (all four slots) and 1 (SA0, SB0) of the first unit
+  ST_A0(); ST_B0(); ST_B1(); ST_A1(); ST_A0(); ST_B0();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  PREAD_B(fb0, smem + SB0)
+  if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger wave row 1 by one barrier
+
+  int ci_unit = 0, c_left = cu.nt;
+  for (;;) {
+    PTILE(fb0, fb1, 0)
+    if (--c_left == 0) {
+      epilogue();
+      if (++ci_unit == n_units) break;
+      cu = get_unit(ci_unit);
+      c_left = cu.nt;
+    }
+    PTILE(fb1, fb0, 1)
+    if (--c_left == 0) {
+      epilogue();
+      if (++ci_unit == n_units) break;
+      cu = get_unit(ci_unit);
+      c_left = cu.nt;
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // re-balance the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef PTILE
+#undef PMMA
+#undef PSEG_END
+#undef PREAD_A
+#undef PREAD_B
+#undef PSTAGE
+#undef ST_A0
+#undef ST_A1
+#undef ST_B0
+#undef ST_B1
+}
+
 // Fix-up of the split-K tail: one thread per 4 consecutive outputs of a tail tile; sums the sk_split fp32 partials (fixed order:
 // deterministic) and applies the same epilogue as the main kernel.
 __global__ __launch_bounds__(256) void gemm256_fixup_kernel(GemmArgs p) {
@@ -400,14 +670,22 @@ inline int choose_split(int tiles, int ncu, int nt, size_t ws_bytes, int* full_o
 }
 
 template <int AM, int BM_>
-int launch256(const GemmArgs& p, hipStream_t stream) {
+int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
     attr_set = true;
   }
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
-  if (p.sk_split > 1) {
+  if (AM == 0 && BM_ == 0 && persistent_grid > 0) {
+    static bool attr_p = false;
+    if (!attr_p) {
+      hipFuncSetAttribute((const void*)gemm256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+      attr_p = true;
+    }
+    hipLaunchKernelGGL(gemm256p_kernel, dim3(persistent_grid), dim3(512), 2 * BUF, stream, p);
+    if (p.sk_split > 1) hipLaunchKernelGGL(gemm256_fixup_kernel, dim3((num_m * num_n - p.sk_full) * 64), dim3(256), 0, stream, p);
+  } else if (p.sk_split > 1) {
     const int tail = num_m * num_n - p.sk_full;
     hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(p.sk_full + tail * p.sk_split), dim3(512), 2 * BUF, stream, p);
     hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
@@ -434,18 +712,26 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   GemmArgs p = *(const GemmArgs*)args;
   p.sk_split = 1;
   p.sk_full = 0;
+  static int ncu = 0, persist = -1;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (ncu <= 0) ncu = 256;
+    // opt-in (MLA_GEMM_PERSIST=1): bit-identical to the one-workgroup-per-tile launch and measured 0-3 % SLOWER on the twelve
+    // 7B shapes (DESIGN.md "GEMM: what bounds it"): the kernel is power-bound, hiding the per-tile pipeline fill buys nothing
+    const char* e = getenv("MLA_GEMM_PERSIST");
+    persist = (e && e[0] == '1') ? 1 : 0;
+  }
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   if (p.sk_ws && ws_bytes) {
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-      if (ncu <= 0) ncu = 256;
-    }
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     int full = 0;
     const int s = choose_split(tiles, ncu, p.K / 64, ws_bytes, &full);
     if (s > 1 && full % 8 == 0) { p.sk_split = s; p.sk_full = full; }
   }
-  return launch256<0, 0>(p, stream);
+  // persistent walk when there is more than one round of tiles and the operands fit 31-bit byte offsets (buffer addressing)
+  const size_t bytesA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bytesB = ((size_t)(p.N - 1) * p.ldb + p.K) * 2;
+  const int grid = ncu & ~7;
+  const bool use_p = (persist || (p.debug & 0x100)) && (p.debug & 0x80) == 0 && tiles > grid && bytesA < 0x7fffffffULL && bytesB < 0x7fffffffULL;
+  return launch256<0, 0>(p, stream, use_p ? grid : 0);
 }

@@ -337,3 +337,31 @@ def test_gemm256_splitk_tail(dev, M, N, K):
     hip.gemm(a, b, out=acc, accumulate=True)
     assert fro_rel(acc, (plain32 + 1.0).cpu()) < 1e-6
     assert torch.equal(hip.gemm(a, b), hip.gemm(a, b))          # deterministic
+
+
+@pytest.mark.parametrize("M,N,K", [(17536, 4096, 1024), (17536, 12288, 256), (2200, 7424, 2048), (4100, 33000, 128), (70000, 520, 64),
+                                   (8192, 8192, 512)])
+def test_gemm256_persistent_walk_is_bit_identical(dev, M, N, K):
+    """gemm256p_kernel (opt-in: one workgroup per CU walking a unit list, K-tile ring continuous across tiles, buffer-addressed staging
+    with zero-filled out-of-range rows; force_generic bit 0x1000) against the one-workgroup-per-tile kernel (bit 0x800): same per-tile
+    arithmetic in the same order, so every output form must match bit for bit -- whole tiles, split-K tail + fix-up, edge tiles,
+    strided operands."""
+    from mla_amd import hip
+    P, O = 0x1000, 0x800
+    a, b = bfr(M, K, seed=1).to(dev), bfr(N, K, seed=2).to(dev)
+    assert torch.equal(hip.gemm(a, b, force_generic=P), hip.gemm(a, b, force_generic=O))
+    assert torch.equal(hip.gemm(a, b, out_dtype=torch.float32, force_generic=P), hip.gemm(a, b, out_dtype=torch.float32, force_generic=O))
+    assert torch.equal(hip.gemm(a, b, force_generic=P | 3), hip.gemm(a, b, force_generic=O | 3))            # no split-K workspace
+    bias, res = bfr(N, seed=3).to(dev), bfr(M, N, seed=4).to(dev)
+    assert torch.equal(hip.gemm(a, b, bias=bias, residual=res, alpha=0.5, force_generic=P),
+                       hip.gemm(a, b, bias=bias, residual=res, alpha=0.5, force_generic=O))
+    acc1 = torch.ones((M, N), dtype=torch.float32, device=dev)
+    acc2 = torch.ones((M, N), dtype=torch.float32, device=dev)
+    hip.gemm(a, b, out=acc1, accumulate=True, force_generic=P)
+    hip.gemm(a, b, out=acc2, accumulate=True, force_generic=O)
+    assert torch.equal(acc1, acc2)
+    if K >= 256:      # operands that are column slices of wider matrices (lda, ldb > K)
+        av, bv = a[:, 64:64 + K // 2], b[:, K // 2:]
+        assert torch.equal(hip.gemm(av, bv, force_generic=P), hip.gemm(av, bv, force_generic=O))
+    ref = a[:512].float() @ b[:640].float().t()
+    assert fro_rel(hip.gemm(a, b, force_generic=P)[:512, :640], ref.cpu()) < 4e-3
