@@ -65,6 +65,17 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   return r;
 }
 
+// 8 bf16 <-> 8 floats (one 16-B access)
+__device__ __forceinline__ void unpack8(const u32x4_t& w, float* f) {
+  f[0] = bflo(w[0]); f[1] = bfhi(w[0]); f[2] = bflo(w[1]); f[3] = bfhi(w[1]);
+  f[4] = bflo(w[2]); f[5] = bfhi(w[2]); f[6] = bflo(w[3]); f[7] = bfhi(w[3]);
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  u32x4_t w;
+  w[0] = pack2bf(f[0], f[1]); w[1] = pack2bf(f[2], f[3]); w[2] = pack2bf(f[4], f[5]); w[3] = pack2bf(f[6], f[7]);
+  return w;
+}
+
 // async global -> LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const MLA_GLOBAL_AS void*)gsrc, (MLA_LDS_AS void*)lds_wave_base, 16, 0, 0);

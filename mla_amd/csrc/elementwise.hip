@@ -5,15 +5,6 @@
 
 namespace {
 
-__device__ __forceinline__ void unpack8(const u32x4_t& w, float* f) {
-  f[0] = bflo(w[0]); f[1] = bfhi(w[0]); f[2] = bflo(w[1]); f[3] = bfhi(w[1]);
-  f[4] = bflo(w[2]); f[5] = bfhi(w[2]); f[6] = bflo(w[3]); f[7] = bfhi(w[3]);
-}
-__device__ __forceinline__ u32x4_t pack8(const float* f) {
-  u32x4_t w;
-  w[0] = pack2bf(f[0], f[1]); w[1] = pack2bf(f[2], f[3]); w[2] = pack2bf(f[4], f[5]); w[3] = pack2bf(f[6], f[7]);
-  return w;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // RMSNorm  (reference: transformers/models/llama/modeling_llama.py:76-90; timm RmsNorm used by FinalLayer,

@@ -177,6 +177,59 @@ __global__ __launch_bounds__(256) void lga_prep_kernel(const float* __restrict__
   }
 }
 
+// Same result, 8 channels per lane: the sin and the cos half of a (coordinate, frequency) pair share one sincosf, the
+// 1 / alpha^(i/fd) table is computed once per block, features move as 16-B loads / stores. Needs fd = 2C/6 a multiple of 8.
+__global__ __launch_bounds__(256) void lga_prep_vec_kernel(const float* __restrict__ xyz, const bf16_t* __restrict__ feats,
+                                                           const long long* __restrict__ fps_idx, const int* __restrict__ knn,
+                                                           bf16_t* __restrict__ rows, float* __restrict__ lc_xyz, int N, int G,
+                                                           int K, int C, float alpha, float beta) {
+  __shared__ float rel[128][3];
+  __shared__ int nb[128];
+  __shared__ float mx[3];
+  __shared__ float de[256];
+  const int bg = blockIdx.x, b = bg / G, tid = threadIdx.x;
+  const int ci = (int)fps_idx[bg];
+  const float* pts = xyz + (size_t)b * N * 3;
+  const float cx = pts[ci * 3], cy = pts[ci * 3 + 1], cz = pts[ci * 3 + 2];
+  const int OD = 2 * C, fd = OD / 6;
+  if (tid < 3) lc_xyz[(size_t)bg * 3 + tid] = pts[ci * 3 + tid];
+  if (tid < fd) de[tid] = powf(alpha, (float)tid / (float)fd);
+  for (int kk = tid; kk < K; kk += 256) {
+    const int j = knn[(size_t)bg * K + kk];
+    nb[kk] = j;
+    rel[kk][0] = pts[j * 3] - cx;
+    rel[kk][1] = pts[j * 3 + 1] - cy;
+    rel[kk][2] = pts[j * 3 + 2] - cz;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float m = 0.f;
+    for (int kk = 0; kk < K; ++kk) m = fmaxf(m, fabsf(rel[kk][tid]));
+    mx[tid] = fmaxf(m, 1e-6f);
+  }
+  __syncthreads();
+  const bf16_t* fb = feats + (size_t)b * N * C;
+  const int nch = fd >> 3, per_k = 3 * nch;
+  for (int e = tid; e < K * per_k; e += 256) {
+    const int kk = e / per_k, q = e % per_k;
+    const int coord = q / nch, f0 = (q % nch) * 8;
+    const float base = beta * (rel[kk][coord] / mx[coord]);
+    const int ch_s = coord * 2 * fd + f0, ch_c = ch_s + fd;          // sin half, cos half
+    float fs[8], fc[8];
+    unpack8(*(const u32x4_t*)(ch_s < C ? fb + (size_t)nb[kk] * C + ch_s : fb + (size_t)ci * C + (ch_s - C)), fs);
+    unpack8(*(const u32x4_t*)(ch_c < C ? fb + (size_t)nb[kk] * C + ch_c : fb + (size_t)ci * C + (ch_c - C)), fc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float arg = base / de[f0 + j];
+      fs[j] += sinf(arg);
+      fc[j] += cosf(arg);
+    }
+    bf16_t* o = rows + ((size_t)bg * K + kk) * OD;
+    *(u32x4_t*)(o + ch_s) = pack8(fs);
+    *(u32x4_t*)(o + ch_c) = pack8(fc);
+  }
+}
+
 // backward of lga_prep w.r.t. the point features (coordinates carry no gradient: the positional embedding is a constant):
 //   dfeats[b][knn[b,g,k]][c] += drows[(b,g,k)][c]        dfeats[b][centre(b,g)][c] += sum_k drows[(b,g,k)][C + c]
 // fp32 atomics into a zero-initialised [B, N, C] buffer (a point is the neighbour of many groups)
@@ -234,6 +287,36 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const bf16_t* __r
   if (rl == 0 && ch < C) {
     partial[((size_t)blockIdx.y * 2) * C + ch] = s1[0][c] + s1[1][c] + s1[2][c] + s1[3][c];
     partial[((size_t)blockIdx.y * 2 + 1) * C + ch] = s2[0][c] + s2[1][c] + s2[2][c] + s2[3][c];
+  }
+}
+// same partials from 16-B loads: lane = (row lane rl, 8-channel chunk cg) with RL = 256 / (C/8) row lanes (blockDim = RL * C/8);
+// the RL per-lane sums of a column are combined in a fixed order (deterministic). Needs C % 8 == 0, C <= 2048, ld % 8 == 0.
+__global__ __launch_bounds__(256) void colstats_partial_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
+                                                                   long long rows, int C, int ld) {
+  extern __shared__ float sh[];                      // [2][RL][C]
+  const int C8 = C >> 3, RL = blockDim.x / C8;
+  const int cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
+  float a[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = q[j] = 0.f;
+  for (long long r = r0 + rl; r < r1; r += RL) {
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + r * ld + cg * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] += v[j]; q[j] += v[j] * v[j]; }
+  }
+  float* s1 = sh + (size_t)rl * C + cg * 8;
+  float* s2 = sh + (size_t)(RL + rl) * C + cg * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = a[j]; s2[j] = q[j]; }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+    float ta = 0.f, tq = 0.f;
+    for (int l = 0; l < RL; ++l) { ta += sh[(size_t)l * C + ch]; tq += sh[(size_t)(RL + l) * C + ch]; }
+    partial[((size_t)blockIdx.x * 2) * C + ch] = ta;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + ch] = tq;
   }
 }
 __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
@@ -332,8 +415,13 @@ extern "C" int mla_lga_prep(const float* xyz, const void* feats, const long long
                             float* lc_xyz, int B, int N, int G, int K, int C, float alpha, float beta, hipStream_t stream) {
   MLA_CHECK_ARG(xyz && feats && fps_idx && knn && rows && lc_xyz, "mla_lga_prep: null pointer");
   MLA_CHECK_ARG(K <= 128 && (2 * C) % 6 == 0, "mla_lga_prep: need K <= 128 and 2C divisible by 6");
-  hipLaunchKernelGGL(lga_prep_kernel, dim3(B * G), dim3(256), 0, stream, xyz, (const bf16_t*)feats, fps_idx, knn, (bf16_t*)rows,
-                     lc_xyz, N, G, K, C, alpha, beta);
+  const int fd = 2 * C / 6;
+  if (fd % 8 == 0 && fd <= 256 && C % 8 == 0 && (((uintptr_t)feats | (uintptr_t)rows) & 15) == 0)
+    hipLaunchKernelGGL(lga_prep_vec_kernel, dim3(B * G), dim3(256), 0, stream, xyz, (const bf16_t*)feats, fps_idx, knn, (bf16_t*)rows,
+                       lc_xyz, N, G, K, C, alpha, beta);
+  else
+    hipLaunchKernelGGL(lga_prep_kernel, dim3(B * G), dim3(256), 0, stream, xyz, (const bf16_t*)feats, fps_idx, knn, (bf16_t*)rows,
+                       lc_xyz, N, G, K, C, alpha, beta);
   MLA_LAUNCH_CHECK();
 }
 
@@ -344,7 +432,14 @@ extern "C" int mla_colstats_bf16(const void* x, float* mean, float* var, long lo
   MLA_CHECK_ARG(x && mean && var && workspace && rows > 0, "mla_colstats_bf16: bad args");
   const int P = mla_colstats_blocks(rows);
   MLA_CHECK_ARG(workspace_bytes >= (size_t)P * 2 * C * sizeof(float), "mla_colstats_bf16: workspace too small");
-  hipLaunchKernelGGL(colstats_partial_kernel, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const bf16_t*)x, workspace, rows, C, ld);
+  const int C8 = C / 8;
+  if (C % 8 == 0 && C8 <= 256 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
+    const int RL = 256 / C8;
+    hipLaunchKernelGGL(colstats_partial_vec_kernel, dim3(P), dim3(RL * C8), (size_t)2 * RL * C * sizeof(float), stream, (const bf16_t*)x,
+                       workspace, rows, C, ld);
+  } else {
+    hipLaunchKernelGGL(colstats_partial_kernel, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const bf16_t*)x, workspace, rows, C, ld);
+  }
   hipLaunchKernelGGL(colstats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, mean, var, P, C, rows);
   MLA_LAUNCH_CHECK();
 }
