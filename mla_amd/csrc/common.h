@@ -65,6 +65,16 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   return r;
 }
 
+// Work distribution of the streaming kernels: workgroup b owns the contiguous item range [b * chunk, (b + 1) * chunk) instead of
+// the usual grid-stride walk. With a grid-stride loop all CUs sweep one narrow window through every stream in lockstep and the
+// rate then depends on how the streams' physical addresses happen to relate (measured on AdamW's five streams: 4.5-4.6 TB/s vs
+// 5.7-6.2 TB/s on the same buffers, tools/exp_skew.py); contiguous chunks keep the active workgroups spread over all of memory.
+// Used by AdamW only: SwiGLU / RoPE (two or three bf16 streams with a row structure) measured 4-7 % SLOWER with it in the step.
+#define MLA_CHUNK_LOOP(IDX, TOTAL)                                                                            \
+  const long long chunk__ = ((((TOTAL) + gridDim.x - 1) / gridDim.x) + 255) & ~255LL;                         \
+  const long long lo__ = (long long)blockIdx.x * chunk__, hi__ = lo__ + chunk__ < (TOTAL) ? lo__ + chunk__ : (TOTAL); \
+  for (long long IDX = lo__ + threadIdx.x; IDX < hi__; IDX += 256)
+
 // 8 bf16 <-> 8 floats (one 16-B access)
 __device__ __forceinline__ void unpack8(const u32x4_t& w, float* f) {
   f[0] = bflo(w[0]); f[1] = bfhi(w[0]); f[2] = bflo(w[1]); f[3] = bfhi(w[1]);

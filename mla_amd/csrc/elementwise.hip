@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void adamw_vec4_kernel(f32x4_t* __restrict__ p
                                                          const float* __restrict__ grad_scale) {
   const float gs = grad_scale ? *grad_scale : 1.f;
   const float step = lr / bc1, isq = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+  MLA_CHUNK_LOOP(i, n4) {
     const f32x4_t g4 = __builtin_nontemporal_load(g + i);
     f32x4_t p4 = p[i], m4 = m[i], v4 = v[i];
 #pragma unroll
