@@ -76,6 +76,58 @@ __global__ __launch_bounds__(256) void tile_transpose_kernel(const bf16_t* __res
   }
 }
 
+// SwiGLU backward with both layouts in one pass (replaces swiglu_bwd + a 2-stream transpose of its 2I-wide output):
+//   dgu[t][i] = dact * up * silu'(gate), dgu[t][I + i] = dact * silu(gate)   (row-major, feeds the dgrad GEMM)
+//   dguT[i][t], dguT[I + i][t] = the same values, token-contiguous            (feeds the wgrad GEMM)
+// 64 x 64 tiles over [rows, I]; the row-major halves are stored straight from registers, the transposed ones through LDS.
+__global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const bf16_t* __restrict__ dact, const bf16_t* __restrict__ gu,
+                                                           bf16_t* __restrict__ dgu, bf16_t* __restrict__ dguT, long long R, int I,
+                                                           long long ldt) {
+  __shared__ unsigned short tg[64][66], tu[64][66];
+  const long long r0 = (long long)blockIdx.y * 64;
+  const int c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rr = (tid >> 3) + it * 32, cc = (tid & 7) * 8;
+    const long long r = r0 + rr;
+    const int c = c0 + cc;
+    if (r < R && c < I) {
+      const u32x4_t g = *(const u32x4_t*)(gu + r * 2 * I + c);
+      const u32x4_t u = *(const u32x4_t*)(gu + r * 2 * I + I + c);
+      const u32x4_t d = *(const u32x4_t*)(dact + r * I + c);
+      float gv[8], uv[8], dv[8], dg[8], du[8];
+      unpack8(g, gv); unpack8(u, uv); unpack8(d, dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sg = 1.f / (1.f + __expf(-gv[j]));
+        const float sl = gv[j] * sg;
+        dg[j] = dv[j] * uv[j] * (sg + sl * (1.f - sg));
+        du[j] = dv[j] * sl;
+      }
+      const u32x4_t pg = pack8(dg), pu = pack8(du);
+      *(u32x4_t*)(dgu + r * 2 * I + c) = pg;
+      *(u32x4_t*)(dgu + r * 2 * I + I + c) = pu;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tg[cc + 2 * j][rr] = (unsigned short)(pg[j] & 0xffffu); tg[cc + 2 * j + 1][rr] = (unsigned short)(pg[j] >> 16);
+        tu[cc + 2 * j][rr] = (unsigned short)(pu[j] & 0xffffu); tu[cc + 2 * j + 1][rr] = (unsigned short)(pu[j] >> 16);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int cc = (tid >> 3) + it * 32, rr = (tid & 7) * 8;
+    if (c0 + cc < I && r0 + rr < R) {
+      const uint32_t* pg = (const uint32_t*)&tg[cc][rr];
+      const uint32_t* pu = (const uint32_t*)&tu[cc][rr];
+      *(u32x4_t*)(dguT + (long long)(c0 + cc) * ldt + r0 + rr) = u32x4_t{pg[0], pg[1], pg[2], pg[3]};
+      *(u32x4_t*)(dguT + (long long)(I + c0 + cc) * ldt + r0 + rr) = u32x4_t{pu[0], pu[1], pu[2], pu[3]};
+    }
+  }
+}
+
 template <typename OP>
 int launch_tt(const void* src, void* dst, long long R, int C, long long ld, long long ldt, OP op, hipStream_t stream, const char* who) {
   if (!(src && dst && R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && ld % 8 == 0 && ldt % 8 == 0)) {
@@ -104,4 +156,20 @@ extern "C" int mla_rmsnorm_apply_t(const void* x, const void* w, const float* rs
 // dst[i][t] = silu(gu[t][i]) * gu[t][I + i]
 extern "C" int mla_swiglu_fwd_t(const void* gu, void* dst, long long rows, int I, long long ldt, hipStream_t stream) {
   return launch_tt(gu, dst, rows, I, 2LL * I, ldt, SwigluOp{I}, stream, "mla_swiglu_fwd_t");
+}
+
+// dgu = SwiGLU backward of dact (row-major [rows, 2I]) and dguT = its transpose [2I, ldt >= rows], in one pass
+extern "C" int mla_swiglu_bwd_t(const void* dact, const void* gu, void* dgu, void* dguT, long long rows, int I, long long ldt,
+                                hipStream_t stream) {
+  if (!(dact && gu && dgu && dguT && rows > 0 && I > 0 && rows % 8 == 0 && I % 8 == 0 && ldt % 8 == 0 && ldt >= rows)) {
+    mla_set_error("mla_swiglu_bwd_t: need rows, I, ldt multiples of 8 and ldt >= rows");
+    return -1;
+  }
+  if ((((uintptr_t)dact | (uintptr_t)gu | (uintptr_t)dgu | (uintptr_t)dguT) & 15) != 0) { mla_set_error("mla_swiglu_bwd_t: 16-B alignment"); return -1; }
+  dim3 grid((I + 63) / 64, (unsigned)((rows + 63) / 64));
+  hipLaunchKernelGGL(swiglu_bwd_t_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dact, (const bf16_t*)gu, (bf16_t*)dgu, (bf16_t*)dguT,
+                     rows, I, ldt);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mla_set_error("mla_swiglu_bwd_t: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
 }

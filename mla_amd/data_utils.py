@@ -12,6 +12,8 @@ from typing import Dict, Optional, Sequence
 import torch
 from torch.nn.utils.rnn import pad_sequence
 
+from .action_tokenizer import ActionTokenizer  # noqa: F401  (vla/action_tokenizer.py; the transform below calls it per action row)
+
 IGNORE_INDEX = -100
 
 
@@ -89,37 +91,6 @@ class PurePromptBuilder:
 
     def get_prompt(self) -> str:
         return self.prompt.removeprefix(self.bos).rstrip()
-
-
-class ActionTokenizer:
-    """vla/action_tokenizer.py:13-79: clip to [min, max], ``np.digitize`` against ``linspace(min, max, bins)`` (indices 1..bins),
-    token id = ``vocab_size - index`` (the least-used tail of a Llama vocabulary), decoded to a string by the base tokenizer; the
-    inverse maps ids back to bin centres with the last index folded onto the last interval."""
-
-    def __init__(self, tokenizer, bins: int = 256, min_action: int = -1, max_action: int = 1) -> None:
-        import numpy as np
-        self.tokenizer, self.n_bins, self.min_action, self.max_action = tokenizer, bins, min_action, max_action
-        self.bins = np.linspace(min_action, max_action, bins)
-        self.bin_centers = 0.5 * (self.bins[:-1] + self.bins[1:])
-        self.action_token_begin_idx = int(tokenizer.vocab_size - (bins + 1))
-
-    def token_ids(self, action):
-        import numpy as np
-        a = np.clip(action, a_min=float(self.min_action), a_max=float(self.max_action))
-        return self.tokenizer.vocab_size - np.digitize(a, self.bins)
-
-    def __call__(self, action):
-        ids = self.token_ids(action)
-        return self.tokenizer.decode(list(ids)) if ids.ndim == 1 else self.tokenizer.batch_decode(ids.tolist())
-
-    def decode_token_ids_to_actions(self, action_token_ids):
-        import numpy as np
-        idx = np.clip(self.tokenizer.vocab_size - action_token_ids - 1, a_min=0, a_max=self.bin_centers.shape[0] - 1)
-        return self.bin_centers[idx]
-
-    @property
-    def vocab_size(self) -> int:
-        return self.n_bins
 
 
 @dataclass

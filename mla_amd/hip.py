@@ -256,6 +256,15 @@ def swiglu_bwd(dact, gu2d, want_act=False):
     return dgu, act
 
 
+def swiglu_bwd_t(dact, gu2d):
+    """dgu [rows, 2I] and its transpose [2I, rows] from one pass over dact and gu."""
+    rows, two_i = gu2d.shape
+    dgu = torch.empty_like(gu2d)
+    dguT = torch.empty((two_i, rows), dtype=gu2d.dtype, device=gu2d.device)
+    call("mla_swiglu_bwd_t", _p(dact), _p(gu2d), _p(dgu), _p(dguT), rows, two_i // 2, rows)
+    return dgu, dguT
+
+
 def act_fwd(x, kind):
     y = torch.empty_like(x)
     call("mla_act_fwd", _p(x), _p(y), x.numel(), kind)
@@ -404,6 +413,7 @@ register_signatures({
     "mla_avgpool_tokens": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_local_attn": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "mla_local_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "mla_swiglu_bwd_t": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p],
     "mla_lga_prep_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mla_maxpool_k_bwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "mla_clip_preprocess": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,

@@ -512,14 +512,20 @@ class DecoderLayerFn(torch.autograd.Function):
             grads[8] = deliver_wgrad_nt((wd,), hip.transpose(d2), actT, need[8:9])[0]
             del actT
         act_ = None
-        dgu, _ = hip.swiglu_bwd(dact, gu)
+        want_w = need[6] or need[7]
+        fuse_t = want_w and dact.shape[0] % 8 == 0       # dgu and dgu^T from one pass (saves re-reading the 2I-wide gradient)
+        if fuse_t:
+            dgu, dguT = hip.swiglu_bwd_t(dact, gu)
+        else:
+            dgu, _ = hip.swiglu_bwd(dact, gu)
         del dact
         # ---- MLP: gate | up projection
         dxn2 = hip.gemm(dgu, wT((wg, wu)))                               # [T, H], K = 2I
-        if need[6] or need[7]:
+        if want_w:
             xn2T = hip.rmsnorm_apply_t(h1, ln2, rstd2) if xn2 is None else hip.transpose(xn2)
-            grads[6], grads[7] = deliver_wgrad_nt((wg, wu), hip.transpose(dgu), xn2T, need[6:8])
+            grads[6], grads[7] = deliver_wgrad_nt((wg, wu), dguT if fuse_t else hip.transpose(dgu), xn2T, need[6:8])
             del xn2T
+            dguT = None
         del dgu
         xn2 = None
         holder = {}

@@ -329,7 +329,7 @@ def test_rlds_batch_transform_matches_reference_golden():
         assert out["dataset_name"] == b"rlbench"
     at = ActionTokenizer(tok)
     a = np.linspace(-1.5, 1.5, 1001)
-    assert np.array_equal(at.token_ids(a), gold["at_ids"]) and at(a[::100]) == str(gold["at_str"])
+    assert np.array_equal(at.encode_ids(a), gold["at_ids"]) and at(a[::100]) == str(gold["at_str"])
     assert np.array_equal(at.decode_token_ids_to_actions(np.arange(tok.vocab_size - 257, tok.vocab_size)), gold["at_decode"])
     assert at.action_token_begin_idx == int(gold["at_begin"]) and at.vocab_size == 256
     pb = PurePromptBuilder("openvla")

@@ -151,6 +151,12 @@ def test_swiglu_and_acts(dev):
     dgu, act2 = hip.swiglu_bwd(d.to(dev), gu.to(dev), want_act=True)
     assert fro_rel(dgu[:, :I], g.grad) < 4e-3 and fro_rel(dgu[:, I:], u.grad) < 4e-3
     assert torch.equal(act2.cpu(), act.cpu())
+    # fused two-layout backward: bit-identical to swiglu_bwd and to its transpose (rows % 8 == 0, ragged tile edges)
+    for r2 in (40, 200):
+        gu2, d2 = bfr(r2, 2 * I, seed=3).to(dev), bfr(r2, I, seed=4).to(dev)
+        want, _ = hip.swiglu_bwd(d2, gu2)
+        got, gotT = hip.swiglu_bwd_t(d2, gu2)
+        assert torch.equal(got, want) and torch.equal(gotT, want.t().contiguous())
     x = bfr(1000, 7, seed=5, scale=2.0).contiguous()
     fns = {0: lambda t: F.gelu(t), 1: lambda t: F.gelu(t, approximate="tanh"), 2: F.relu, 3: F.silu}
     for kind, fn in fns.items():
