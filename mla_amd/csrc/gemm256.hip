@@ -9,10 +9,12 @@
 //   SA0/SA1 = the A rows every wave needs for its upper/lower 64 output rows, SB0/SB1 = the B rows for its left/right 32
 //   output columns.  Per K-tile each wave runs 4 phases = 4 quadrants of 16 MFMAs x 2 k-steps:
 //     ph1: read SA0,SB0 -> Q00   ph2: read SB1 -> Q01   ph3: read SA1 -> Q11   ph4: (no read) -> Q10
-//   Every phase also issues ONE half-tile of global_load_lds (2 x 16 B per lane) for a future K-tile, into a slot whose
-//   last reader finished >= 2 phases earlier:  ph1: SB1(t+1)  ph2: SA1(t+1)  ph3: SA0(t+2)  ph4: SB0(t+2).
-//   Loads are therefore 1-2 K-tiles ahead and are retired with a COUNTED s_waitcnt vmcnt(6) (3 half-tiles stay in
-//   flight across the barriers; never vmcnt(0) in the loop). The next tile's B0 fragments are prefetched in ph4, so the
+//   Every phase also issues ONE half-tile of global_load_lds (2 x 16 B per lane) for a future K-tile, into the slot whose
+//   last reader finished exactly 2 phases earlier (the earliest legal moment with the one-barrier stagger of the wave rows):
+//   ph1: SA1(t+1)  ph2: SB0(t+2)  ph3: SA0(t+2)  ph4: SB1(t+2).  Every half-tile is then issued 6 phases (1.5 K-tiles) before
+//   the phase that reads it, and the loop retires loads with a COUNTED s_waitcnt vmcnt(10): 5 half-tiles stay in flight across
+//   the barriers (never vmcnt(0) in the loop). [Until r1 the order was SB1(t+1) / SA1(t+1) / SA0(t+2) / SB0(t+2) with issue-to-read
+//   distances 5 / 5 / 6 / 4 phases and vmcnt(6): same LDS, 3 half-tiles in flight.] The next tile's B0 fragments are prefetched in ph4, so the
 //   per-phase ds_read counts are 8/4/8/4 (ablation: LDS reads + LDS-DMA writes cost ~35 % of the MFMA-only rate).
 // The two wave rows run staggered by one barrier (wave row 1 executes one extra s_barrier up front), so on every SIMD
 // one wave is in its ds_read/issue segment while its partner is in its MFMA segment; s_setprio(1) wraps the MFMAs.
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #define SEG_END()                                                  \
   __builtin_amdgcn_sched_barrier(0);                               \
   if (LGKM_BEFORE) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); \
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");           \
   if (!NO_BAR1) __builtin_amdgcn_s_barrier();                      \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
   __builtin_amdgcn_sched_barrier(0);
@@ -217,14 +219,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   if (!NO_BAR2) __builtin_amdgcn_s_barrier();                                                                    \
   asm volatile("" ::: "memory");
 
-  // ---- prologue: K-tiles 0 (all four slots) and 1 (SA0, SB0)
-  STAGE(pA0, tA0, stepA, SA0);
+  // ---- prologue: K-tiles 0 (all four slots) and 1 (SA0, SB0, SB1; SA1(1) is staged in phase 1 of tile 0)
+  // issue order = the loop's order (SB0, SA0, SB1, SA1 per K-tile): vmcnt is an in-order counter, the counted waits rely on it
   STAGE(pB0, tB0, stepB, SB0);
+  STAGE(pA0, tA0, stepA, SA0);
   STAGE(pB1, tB1, stepB, SB1);
   STAGE(pA1, tA1, stepA, SA1);
-  STAGE(pA0, tA0, stepA, SA0);
   STAGE(pB0, tB0, stepB, SB0);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // SA0(0), SB0(0) of this wave have landed
+  STAGE(pA0, tA0, stepA, SA0);
+  STAGE(pB1, tB1, stepB, SB1);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // SB0(0), SA0(0) of this wave have landed
   __builtin_amdgcn_s_barrier();
   READ_B(fb0, smem + SB0)                            // B0 fragments of K-tile 0 (later tiles prefetch theirs in phase 4)
   if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger wave row 1 by one barrier
@@ -236,19 +240,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const char* buf = smem + ((T_) & 1) * BUF;                       \
     const char* nbuf = smem + (((T_) + 1) & 1) * BUF;                \
     if (NO_READ) rd_on = (T_) < 2;                                   \
-    STAGE(pB1, tB1, stepB, SB1);                                     \
+    STAGE(pA1, tA1, stepA, SA1);   /* SA1(t+1) */                    \
     READ_A(buf + SA0)                                                \
     SEG_END()                                                        \
     MMA(0, 0, X)                                                     \
-    STAGE(pA1, tA1, stepA, SA1);                                     \
+    STAGE(pB0, tB0, stepB, SB0);   /* SB0(t+2) */                    \
     READ_B(Y, buf + SB1)                                             \
     SEG_END()                                                        \
     MMA(0, 1, Y)                                                     \
-    STAGE(pA0, tA0, stepA, SA0);                                     \
+    STAGE(pA0, tA0, stepA, SA0);   /* SA0(t+2) */                    \
     READ_A(buf + SA1)                                                \
     SEG_END()                                                        \
     MMA(1, 1, Y)                                                     \
-    STAGE(pB0, tB0, stepB, SB0);                                     \
+    STAGE(pB1, tB1, stepB, SB1);   /* SB1(t+2) */                    \
     READ_B(Y, nbuf + SB0)                                            \
     SEG_END()                                                        \
     MMA(1, 0, X)                                                     \
