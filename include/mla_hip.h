@@ -53,7 +53,8 @@ int mla_rmsnorm_bwd_blocks(int rows);
 /* dx = dres + d(rmsnorm)/dx ; dw (+)= sum_rows dy * x_hat ; workspace >= mla_rmsnorm_bwd_blocks(rows)*H floats */
 int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx, float* dw,
                     int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes, mla_stream_t stream);
-/* bias gradients: out[n] (+)= sum_r dy[r][n]; workspace >= mla_colsum_blocks(rows)*N floats */
+/* bias gradients of every nn.Linear with a bias on the path (autograd of util/nn_utils.py:21-34, models/diffusion/models.py:112-123):
+ * out[n] (+)= sum_r dy[r][n]; workspace >= mla_colsum_blocks(rows)*N floats */
 int mla_colsum_blocks(int rows);
 int mla_colsum_bf16(const void* dy, float* out, int accumulate, int rows, int N, int ld, float* workspace, size_t workspace_bytes,
                     mla_stream_t stream);
@@ -67,7 +68,9 @@ int mla_rope_inplace(void* buf, const float* cos_t, const float* sin_t, long lon
 /* ---- SwiGLU: LlamaMLP.forward modeling_llama.py:240; gu = [gate | up] per row */
 int mla_swiglu_fwd(const void* gu, void* act, long long rows, int I, mla_stream_t stream);
 int mla_swiglu_bwd(const void* dact, const void* gu, void* dgu, void* act_out, long long rows, int I, mla_stream_t stream);
-/* ---- activations: kind 0 GELU(erf), 1 GELU(tanh), 2 ReLU, 3 SiLU */
+/* ---- activations of the small heads: kind 0 GELU(erf) (MLPProjector util/nn_utils.py:21-34), 1 GELU(tanh) (timm Mlp in ActionEmbedder /
+ * FinalLayer, models/diffusion/models.py:112-123,173-189), 2 ReLU (contrastive heads models/mla/fuser/contrastive.py:173-183; Point-PN
+ * Point_PN.py:179,209,218), 3 SiLU (TimestepEmbedder models/diffusion/models.py:34-38) */
 int mla_act_fwd(const void* x, void* y, long long n, int kind, mla_stream_t stream);
 int mla_act_bwd(const void* dy, const void* x, void* dx, long long n, int kind, mla_stream_t stream);
 
