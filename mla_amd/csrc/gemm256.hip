@@ -339,9 +339,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 // ring running CONTINUOUSLY across units: while the last K-tiles of unit u are multiplied, the staging cursors are already
 // loading the first K-tiles of unit u+1, so the pipeline fill of every tile but the first is hidden, and there is no workgroup
 // launch between tiles (measured on the non-persistent kernel: ~19 us per tile at K = 4096, 19 % of a 64-K-tile tile).
-// Staging uses buffer_load ... lds with the tensor as the buffer resource: per-lane offsets inside a tile are constants
-// (VGPRs), everything that changes from K-tile to K-tile and from unit to unit is a scalar offset (SGPRs); rows beyond M / N
-// are out of range of the resource and read as zero, so edge tiles need no clamping.
+// Staging: global_load_lds with a uniform base + 32-bit lane offsets; what changes from K-tile to K-tile and from unit to unit is
+// the scalar base, the lane offsets are recomputed only at a unit switch (row clamp at the M / N edge).
 // Unit order: XCD x (= blockIdx & 7, the hardware's round-robin) owns a contiguous range of tile ids, its W = gridDim / 8
 // workgroups take ids start + j + W * i, i.e. at any time the XCD works on W consecutive ids (a GROUP_M x W/GROUP_M block
 // of tiles sharing operand panels in its L2), exactly like the remapped non-persistent launch.
@@ -395,49 +394,60 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
     return u;
   };
 
-  // ---- staging: resources, per-lane offsets, per-slot scalar cursors
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((size_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(((size_t)(p.N - 1) * p.ldb + p.K) * 2), 0x00020000);
-  int voA[2], voB[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int q = (wave * 2 + it) * 64 + lane;
-    const int rp = q >> 3, cp = q & 7;
-    const int c = cp ^ (rp & 7);
-    voA[it] = (rp * p.lda + c * 8) * 2;
-    voB[it] = (rp * p.ldb + c * 8) * 2;
-  }
+  // ---- staging: global_load_lds in its (uniform base + 32-bit lane offset) form. Per slot X in {A0, B0, B1, A1}: gb = uniform
+  // source address of the next K-tile of that half-tile, vo[2] = this lane's byte offsets inside the half-tile (rows clamped to the
+  // last valid one at the M / N edge), left = K-tiles left in the slot's current unit, su = its unit index, t = running K-tile
+  // count (LDS buffer parity). [The first version staged through buffer_load ... lds with SGPR offsets: that form costs the issuing
+  // wave 100-230 cycles per load (tools/micro/dma_asm.hip) and made the K-tile slope 4-5 % worse than the one-tile kernel's.]
   const int rowA = p.lda * 2, rowB = p.ldb * 2;      // bytes per operand row
-  // slot X in {A0, B0, B1, A1}: so = scalar byte offset of the next K-tile to stage, left = K-tiles left in its unit, su = unit
-  // index, t = running K-tile count (LDS buffer parity)
-  int soA0, soB0, soB1, soA1, leftA0, leftB0, leftB1, leftA1, suA0 = 0, suB0 = 0, suB1 = 0, suA1 = 0, tA0 = 0, tB0 = 0, tB1 = 0, tA1 = 0;
+  const char* gbA0; const char* gbA1; const char* gbB0; const char* gbB1;
+  unsigned voA0[2], voA1[2], voB0[2], voB1[2];
+  int stA0 = 128, stA1 = 128, stB0 = 128, stB1 = 128;   // K-tile byte step; 0 once a slot has run past its last unit
+  int leftA0, leftB0, leftB1, leftA1, suA0 = 0, suB0 = 0, suB1 = 0, suA1 = 0, tA0 = 0, tB0 = 0, tB1 = 0, tA1 = 0;
+  // points slot state at unit u: half-tile rows [hb, hb + 128) of the operand, K-tile u.kt0
+#define PSLOT_SET(X, U, ISA, HALF)                                                                                  \
+  do {                                                                                                              \
+    const int lim_rows__ = (ISA) ? p.M : p.N;                                                                       \
+    int hb__ = ((ISA) ? (U).m0 : (U).n0) + (HALF) * 128;                                                            \
+    int lim__ = lim_rows__ - 1 - hb__;                                                                              \
+    if (lim__ < 0) { hb__ = lim_rows__ - 128; lim__ = 127; }      /* half-tile entirely past the edge: any valid rows */ \
+    lim__ = lim__ < 127 ? lim__ : 127;                                                                              \
+    gb##X = (const char*)((ISA) ? p.A : p.B) + (size_t)hb__ * ((ISA) ? rowA : rowB) + (size_t)(U).kt0 * 128;        \
+    _Pragma("unroll") for (int it__ = 0; it__ < 2; ++it__) {                                                        \
+      const int q__ = (wave * 2 + it__) * 64 + lane;                                                                \
+      const int rp__ = q__ >> 3, cp__ = q__ & 7;                                                                    \
+      const int c__ = cp__ ^ (rp__ & 7);                                                                            \
+      const int re__ = rp__ < lim__ ? rp__ : lim__;                                                                 \
+      vo##X[it__] = (unsigned)((re__ * ((ISA) ? p.lda : p.ldb) + c__ * 8) * 2);                                     \
+    }                                                                                                               \
+    left##X = (U).nt;                                                                                               \
+  } while (0)
   Unit cu = get_unit(0);
-  soA0 = cu.m0 * rowA + cu.kt0 * 128;
-  soA1 = (cu.m0 + 128) * rowA + cu.kt0 * 128;
-  soB0 = cu.n0 * rowB + cu.kt0 * 128;
-  soB1 = (cu.n0 + 128) * rowB + cu.kt0 * 128;
-  leftA0 = leftB0 = leftB1 = leftA1 = cu.nt;
+  PSLOT_SET(A0, cu, true, 0);
+  PSLOT_SET(A1, cu, true, 1);
+  PSLOT_SET(B0, cu, false, 0);
+  PSLOT_SET(B1, cu, false, 1);
 
-#define PSTAGE(X, RS, VO, ROWB, ISA, HALF, SLOTOFF)                                                                        \
+#define PSTAGE(X, ISA, HALF, SLOTOFF)                                                                                      \
   do {                                                                                                                     \
     char* dst__ = smem + (t##X & 1) * BUF + (SLOTOFF) + wave * 2048;                                                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (MLA_LDS_AS void*)dst__, 16, VO[0], so##X, 0, 0);                         \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (MLA_LDS_AS void*)(dst__ + 1024), 16, VO[1], so##X, 0, 0);                \
-    so##X += 128; ++t##X;                                                                                                  \
+    glds16(gb##X + vo##X[0], dst__);                                                                                       \
+    glds16(gb##X + vo##X[1], dst__ + 1024);                                                                                \
+    gb##X += st##X; ++t##X;                                                                                                \
     if (--left##X == 0) {                                                                                                  \
       if (++su##X < n_units) {                                                                                             \
         const Unit nu__ = get_unit(su##X);                                                                                 \
-        so##X = ((ISA ? nu__.m0 : nu__.n0) + (HALF) * 128) * (ROWB) + nu__.kt0 * 128;                                      \
-        left##X = nu__.nt;                                                                                                 \
+        PSLOT_SET(X, nu__, ISA, HALF);                                                                                     \
       } else {                                                                                                             \
-        left##X = 0x7fffffff;   /* past the last unit: harmless loads (in range or zero-filled) into dead slots */         \
+        /* past the last unit: keep re-loading the last K-tile of the last unit into dead slots */                        \
+        gb##X -= 128; st##X = 0; left##X = 0x7fffffff;                                                                     \
       }                                                                                                                    \
     }                                                                                                                      \
   } while (0)
-#define ST_A0() PSTAGE(A0, rsA, voA, rowA, true, 0, SA0)
-#define ST_A1() PSTAGE(A1, rsA, voA, rowA, true, 1, SA1)
-#define ST_B0() PSTAGE(B0, rsB, voB, rowB, false, 0, SB0)
-#define ST_B1() PSTAGE(B1, rsB, voB, rowB, false, 1, SB1)
+#define ST_A0() PSTAGE(A0, true, 0, SA0)
+#define ST_A1() PSTAGE(A1, true, 1, SA1)
+#define ST_B0() PSTAGE(B0, false, 0, SB0)
+#define ST_B1() PSTAGE(B1, false, 1, SB1)
 
   // ---- fragment read offsets (bytes inside a slot)
   const int offA = (wr * 64 + li) * 128 + ((lg ^ (li & 7)) * 16);
@@ -601,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
 #undef PREAD_A
 #undef PREAD_B
 #undef PSTAGE
+#undef PSLOT_SET
 #undef ST_A0
 #undef ST_A1
 #undef ST_B0
@@ -722,8 +733,8 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (ncu <= 0) ncu = 256;
-    // opt-in (MLA_GEMM_PERSIST=1): bit-identical to the one-workgroup-per-tile launch and measured 0-3 % SLOWER on the twelve
-    // 7B shapes (DESIGN.md "GEMM: what bounds it"): the kernel is power-bound, hiding the per-tile pipeline fill buys nothing
+    // opt-in (MLA_GEMM_PERSIST=1): bit-identical to the one-workgroup-per-tile launch and measured -1.5 ... +0.3 % against it on the
+    // twelve 7B shapes: hiding the per-tile pipeline fill is paid back by the unit bookkeeping in the hot loop
     const char* e = getenv("MLA_GEMM_PERSIST");
     persist = (e && e[0] == '1') ? 1 : 0;
   }

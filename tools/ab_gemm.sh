@@ -1,5 +1,5 @@
-# A/B of two builds of the library in one box (power/clock differences between boxes exceed the effects measured)
+# A/B of the GEMM dispatch in one box (power/clock differences between boxes exceed the effects measured)
 for rep in 1 2; do
-echo "== new"; python tools/bench_gemm.py 2>&1 | grep -v "qkv fwd  \|TN" | cut -c1-75
-echo "== old"; MLA_HIP_LIB=$PWD/build_old/libmla_hip.so python tools/bench_gemm.py 2>&1 | grep -v "qkv fwd  \|TN" | cut -c1-75
+echo "== persistent"; MLA_GEMM_PERSIST=1 python tools/bench_gemm.py 2>&1 | grep -v "qkv fwd  \|TN" | cut -c1-75
+echo "== one workgroup per tile"; python tools/bench_gemm.py 2>&1 | grep -v "qkv fwd  \|TN" | cut -c1-75
 done

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ src, float* __
   asm volatile(
       "s_mov_b32 s20, %[lds]\n s_mov_b32 s21, 0\n s_mov_b32 s22, %[iters]\n s_mov_b32 m0, s20\n"
       "v_mov_b32 v0, 0\n v_mov_b32 v1, 0\n v_mov_b32 v2, 0\n v_mov_b32 v3, 0\n v_mov_b32 v4, 0\n v_mov_b32 v5, 0\n v_mov_b32 v6, 0\n v_mov_b32 v7, 0\n"
-      "v_mov_b32 v8, %[voff]\n v_mov_b32 v9, %[rd]\n"
+      "v_mov_b32 v8, %[voff]\n v_mov_b32 v9, %[rd]\n v_mov_b32 v10, %[plo]\n v_mov_b32 v11, %[phi]\n"
       "s_nop 4\n"
       "1:\n"
       ".set i, 0\n"
@@ -28,15 +28,15 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ src, float* __
       "  v_mfma_f32_16x16x32_bf16 a[i*4:i*4+3], v[0:3], v[4:7], a[i*4:i*4+3]\n"
       "  .if (%c[nl] >= 1) && (i == 3)\n"
       "    .if %c[m0up]\n s_add_u32 m0, s20, 1024\n s_nop 0\n .endif\n"
-      "    .if %c[form] == 0\n global_load_lds_dwordx4 v8, %[gbase] offset:0\n .else\n buffer_load_dwordx4 v8, %[rsrc], s21 offen lds\n .endif\n"
+      "    .if %c[form] == 0\n global_load_lds_dwordx4 v8, %[gbase] offset:0\n .elseif %c[form] == 2\n global_load_lds_dwordx4 v[10:11], off offset:0\n .else\n buffer_load_dwordx4 v8, %[rsrc], s21 offen lds\n .endif\n"
       "  .endif\n"
       "  .if (%c[nl] >= 2) && (i == 11)\n"
       "    .if %c[m0up]\n s_add_u32 m0, s20, 2048\n s_nop 0\n .endif\n"
-      "    .if %c[form] == 0\n global_load_lds_dwordx4 v8, %[gbase] offset:128\n .else\n buffer_load_dwordx4 v8, %[rsrc], s21 offen offset:128 lds\n .endif\n"
+      "    .if %c[form] == 0\n global_load_lds_dwordx4 v8, %[gbase] offset:128\n .elseif %c[form] == 2\n global_load_lds_dwordx4 v[10:11], off offset:128\n .else\n buffer_load_dwordx4 v8, %[rsrc], s21 offen offset:128 lds\n .endif\n"
       "  .endif\n"
       "  .if (%c[nl] >= 4) && ((i == 7) || (i == 15))\n"
       "    .if %c[m0up]\n s_add_u32 m0, s20, 3072\n s_nop 0\n .endif\n"
-      "    .if %c[form] == 0\n global_load_lds_dwordx4 v8, %[gbase] offset:256\n .else\n buffer_load_dwordx4 v8, %[rsrc], s21 offen offset:256 lds\n .endif\n"
+      "    .if %c[form] == 0\n global_load_lds_dwordx4 v8, %[gbase] offset:256\n .elseif %c[form] == 2\n global_load_lds_dwordx4 v[10:11], off offset:256\n .else\n buffer_load_dwordx4 v8, %[rsrc], s21 offen offset:256 lds\n .endif\n"
       "  .endif\n"
       "  .if (%c[nread] >= 1) && ((i %% %c[rdiv]) == 1)\n"
       "    ds_read_b128 v[12:15], v9 offset:(i*512)\n"
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ src, float* __
       "v_accvgpr_read_b32 %[r], a0\n"
       : [r] "=v"(r)
       : [lds] "s"(lds_base), [iters] "s"(iters), [voff] "v"(voff), [rd] "v"(rd_addr), [gbase] "s"(src), [rsrc] "s"(rs), [nl] "n"(NL), [form] "n"(FORM),
-        [m0up] "n"(M0UP), [nread] "n"(NREAD), [rdiv] "n"(NREAD > 0 ? 16 / NREAD : 99)
-      : "memory", "s20", "s21", "s22", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v12", "v13", "v14", "v15", "a0", "a1", "a2",
+        [plo] "v"((unsigned)((size_t)(src + voff))), [phi] "v"((unsigned)(((size_t)(src + voff)) >> 32)), [m0up] "n"(M0UP), [nread] "n"(NREAD), [rdiv] "n"(NREAD > 0 ? 16 / NREAD : 99)
+      : "memory", "s20", "s21", "s22", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "a0", "a1", "a2",
         "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23",
         "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43",
         "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63",
@@ -92,6 +92,10 @@ int main(int argc, char** argv) {
   run<2, 1, 1, 0>(src, out, iters, row_bytes, "16 MFMA + 2 buffer_load lds,  m0 rewritten");
   run<2, 1, 1, 4>(src, out, iters, row_bytes, "16 MFMA + 2 buffer_load lds + 4 ds_read_b128  (= 128x128 wave tile mix)");
   run<2, 0, 1, 4>(src, out, iters, row_bytes, "16 MFMA + 2 global_load_lds + 4 ds_read_b128");
+  run<1, 2, 1, 0>(src, out, iters, row_bytes, "16 MFMA + 1 global_load_lds (64-bit VGPR address), m0 rewritten");
+  run<2, 2, 1, 0>(src, out, iters, row_bytes, "16 MFMA + 2 global_load_lds (64-bit VGPR address), m0 rewritten");
+  run<4, 2, 1, 4>(src, out, iters, row_bytes, "16 MFMA + 4 global_load_lds (64-bit VGPR address) + 4 ds_read_b128");
+  run<4, 0, 1, 4>(src, out, iters, row_bytes, "16 MFMA + 4 global_load_lds (SGPR base) + 4 ds_read_b128");
   run<4, 1, 1, 4>(src, out, iters, row_bytes, "16 MFMA + 4 buffer_load lds + 4 ds_read_b128");
   return 0;
 }
