@@ -9,7 +9,7 @@ mkdir -p "$HERE/build"
 pids=()
 for f in api gemm gemm256 gemm_asm transpose elementwise attention loss pointcloud vision gen; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$HERE/build/$f.o" ] || { [ "$f" = gemm_asm ] && [ "$HERE/gemm_asm_8w_loop.inc" -nt "$HERE/build/$f.o" ]; }; then
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$HERE/build/$f.o" ] || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$HERE/build/$f.o" ]; }; }; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
     pids+=($!)
   fi

@@ -20,7 +20,8 @@
 #include "gemm_args.h"
 
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream);  // gemm256.hip
-int mla_gemm_asm_dispatch(const void* args, hipStream_t stream);                           // gemm_asm.hip
+int mla_gemm_asm_dispatch(const void* args, hipStream_t stream);
+int mla_gemm_asm4_dispatch(const void* args, hipStream_t stream);                           // gemm_asm.hip
 
 namespace {
 
@@ -305,6 +306,9 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const void* R, 
   // force_generic == 4: the assembly-scheduled 256x256x32 kernel (gemm_asm.hip); K % 128 == 0, N % 4 == 0
   if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 4)
     return mla_gemm_asm_dispatch(&p, stream);
+  // force_generic == 5: the 4-wave (128 x 128 per wave) assembly kernel, same eligibility
+  if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 5)
+    return mla_gemm_asm4_dispatch(&p, stream);
   if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 &&
       a_mode == 0 && b_mode == 0 && (force_generic == 0 || force_generic == 3))
     return mla_gemm256_dispatch(&p, a_mode, b_mode, force_generic == 0 ? workspace_bytes : 0, stream);

@@ -306,23 +306,25 @@ def test_tile_transposes(dev):
     assert torch.equal(hip.swiglu_fwd_t(gu).cpu(), hip.swiglu_fwd(gu).t().contiguous().cpu())
 
 
+@pytest.mark.parametrize("fg", [4, 5])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 256), (1000, 520, 1024), (264, 4096, 384), (2200, 1032, 4096)])
-def test_gemm_asm_kernel(dev, M, N, K):
-    """The assembly-scheduled 256x256x64 kernel (opt-in, force_generic=4): edge tiles in M and N, bias / residual / alpha,
-    fp32 accumulate-into-C epilogue; compared with fp32 matmul and bit-compared with gemm256 (same MFMA order per output)."""
+def test_gemm_asm_kernel(dev, M, N, K, fg):
+    """The assembly-scheduled 256x256x64 kernels (opt-in; force_generic=4: 8 waves x 128x64, 5: 4 waves x 128x128): edge tiles in M and
+    N, bias / residual / alpha, fp32 accumulate-into-C epilogue; compared with fp32 matmul and bit-compared with gemm256 (same MFMA
+    order per output)."""
     from mla_amd import hip
     a, b = bfr(M, K, seed=1).to(dev), bfr(N, K, seed=2).to(dev)
     ref = a.float().cpu() @ b.float().cpu().t()
-    out32 = hip.gemm(a, b, out_dtype=torch.float32, force_generic=4)
+    out32 = hip.gemm(a, b, out_dtype=torch.float32, force_generic=fg)
     assert fro_rel(out32, ref) < 2e-4 and max_rel(out32, ref) < 1e-3
     bias, res = bfr(N, seed=3).to(dev), bfr(M, N, seed=4).to(dev)
-    got = hip.gemm(a, b, bias=bias, residual=res, alpha=0.5, force_generic=4)
+    got = hip.gemm(a, b, bias=bias, residual=res, alpha=0.5, force_generic=fg)
     want = 0.5 * ref + bias.float().cpu() + res.float().cpu()
     assert fro_rel(got, want) < 4e-3
     acc = torch.ones((M, N), dtype=torch.float32, device=dev)
-    hip.gemm(a, b, out=acc, accumulate=True, force_generic=4)
+    hip.gemm(a, b, out=acc, accumulate=True, force_generic=fg)
     assert fro_rel(acc, ref + 1.0) < 2e-4
-    assert torch.equal(hip.gemm(a, b, force_generic=4), hip.gemm(a, b, force_generic=3))
+    assert torch.equal(hip.gemm(a, b, force_generic=fg), hip.gemm(a, b, force_generic=3))
 
 
 @pytest.mark.parametrize("M,N,K", [(17536, 4096, 1024), (2200, 7424, 2048), (4096, 2048, 4096), (17536, 11008, 512)])

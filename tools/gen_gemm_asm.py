@@ -266,8 +266,9 @@ class CfgK64(Cfg):
         # ---- ks0
         lines = [f"; ---- tile set {tset}, k-step 0: MFMA buf0, read ks1 -> buf1", "s_waitcnt lgkmcnt(0)"]
         aux = {}
-        for n, r in enumerate(self.reads_for(tset, 1, 1)):
-            aux.setdefault(n, []).append(r)
+        rd0 = self.reads_for(tset, 1, 1)
+        for n, r in enumerate(rd0):
+            aux.setdefault((n * (nm - 2)) // len(rd0) if "spread" in self.flags else n, []).append(r)
         lines += self.mfmas(0, aux)
         # ---- ks1
         lines += [f"; ---- tile set {tset}, k-step 1: MFMA buf1, load tile t+2 -> set {tset}, read next tile ks0 -> buf0",
@@ -289,6 +290,20 @@ class CfgK64(Cfg):
             aux.setdefault(mid, []).extend([f"s_waitcnt vmcnt({nload})"] + ([] if "nobarrier" in self.flags else ["s_barrier"]))
             for n, r in enumerate(reads):
                 aux.setdefault(mid + 1 + n, []).append(r)
+        elif "spread" in self.flags:
+            # one-wave-per-SIMD kernels: an LDS-DMA load costs its issuer 3-4 cycles when it sits BETWEEN MFMAs and stalls the only
+            # MFMA issuer when loads come in clusters (tools/micro/dma_asm.hip) -> loads and reads alternate, evenly spaced
+            aux.setdefault(0, []).extend(loads[0])
+            items = []
+            ld, rd = list(loads[1:]), list(reads)
+            while ld or rd:
+                if rd:
+                    items.append([rd.pop(0)])
+                if ld:
+                    items.append(ld.pop(0))
+            span = nm - 3
+            for k, it in enumerate(items):
+                aux.setdefault(1 + (k * span) // len(items), []).extend(it)
         elif "loadsfirst" in self.flags:
             aux.setdefault(0, []).extend(loads[0])
             for q in range(len(loads) - 1):
@@ -348,6 +363,12 @@ def main():
     n = c.emit("gemm_asm_8w_loop.inc")
     c.emit_clobbers("gemm_asm_8w_clobbers.inc", "G8W_CLOBBERS")
     print(f"8w/k64: {n} lines, {c.nvgpr} VGPRs + {c.nacc} AGPRs")
+    # 4 waves = 2 x 2, 128 x 128 per wave (8 x 8 fragments in a[0:255], two 64-VGPR fragment buffers), one wave per SIMD: -25 % LDS
+    # traffic per K-tile; every wave stages 64 rows of A and of B (8 + 8 loads per tile)
+    c4 = CfgK64("4w", 8, 8, 8, set(os.environ.get("GEN4W_FLAGS", "spread").split(",")))      # GEN4W_FLAGS: timing experiments
+    n4 = c4.emit("gemm_asm_4w_loop.inc")
+    c4.emit_clobbers("gemm_asm_4w_clobbers.inc", "G4W_CLOBBERS")
+    print(f"4w/k64: {n4} lines, {c4.nvgpr} VGPRs + {c4.nacc} AGPRs")
     for v, fl in VARIANTS.items():
         CfgK64("8w", 8, 4, 4, fl | {"loadsfirst"}).emit(f"gemm_asm_8w_loop_v{v}.inc")
     CfgK64("8w", 8, 4, 4).emit("gemm_asm_8w_loop_v7.inc")                                     # reads before loads in k-step 1
