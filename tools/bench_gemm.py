@@ -35,9 +35,10 @@ for name, M, N, K, am, bm in (shapes if __name__ == "__main__" else []):
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     ms = timeit(lambda: hip.gemm(a, b, out=out, a_mode=am, b_mode=bm))
     ms128 = timeit(lambda: hip.gemm(a, b, out=out, a_mode=am, b_mode=bm, force_generic=2))
+    ms8w = timeit(lambda: hip.gemm(a, b, out=out, a_mode=am, b_mode=bm, force_generic=4)) if (am == 0 and bm == 0 and K % 128 == 0) else float("nan")
     ms4w = timeit(lambda: hip.gemm(a, b, out=out, a_mode=am, b_mode=bm, force_generic=5)) if (am == 0 and bm == 0 and K % 128 == 0) else float("nan")
     A = a if am == 0 else a.t()
     Bt = b.t() if bm == 0 else b
     ms_ref = timeit(lambda: torch.matmul(A, Bt))
     fl = 2.0 * M * N * K
-    print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d}  k256 {ms:7.3f} ms {fl/ms/1e9:7.1f} TF/s | asm4w {fl/ms4w/1e9:7.1f} | k128 {ms128:7.3f} ms {fl/ms128/1e9:7.1f} TF/s | hipBLASLt {ms_ref:8.3f} ms {fl/ms_ref/1e9:8.1f} TF/s", flush=True)
+    print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d}  k256 {ms:7.3f} ms {fl/ms/1e9:7.1f} TF/s | asm8w {fl/ms8w/1e9:7.1f} | asm4w {fl/ms4w/1e9:7.1f} | k128 {ms128:7.3f} ms {fl/ms128/1e9:7.1f} TF/s | hipBLASLt {ms_ref:8.3f} ms {fl/ms_ref/1e9:8.1f} TF/s", flush=True)

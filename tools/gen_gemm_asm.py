@@ -359,7 +359,7 @@ VARIANTS = {1: {"noglds"}, 2: {"noreads"}, 3: {"noglds", "noreads"}, 4: {"nobarr
 
 
 def main():
-    c = CfgK64("8w", 8, 4, 4, {"loadsfirst"})
+    c = CfgK64("8w", 8, 4, 4, set(os.environ.get("GEN8W_FLAGS", "loadsfirst").split(",")))    # GEN8W_FLAGS: schedule experiments
     n = c.emit("gemm_asm_8w_loop.inc")
     c.emit_clobbers("gemm_asm_8w_clobbers.inc", "G8W_CLOBBERS")
     print(f"8w/k64: {n} lines, {c.nvgpr} VGPRs + {c.nacc} AGPRs")
