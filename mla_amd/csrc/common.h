@@ -87,8 +87,12 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 }
 
 // async global -> LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16.
+#ifndef MLA_GLDS_AUX
+#define MLA_GLDS_AUX 0   // cache-policy bits of the LDS-DMA loads. Measured on gemm256 (4 shapes, A/B in one box): 1 (sc0) +-0.5 %,
+                         // 2 (nt) and 3 (sc0 + nt) -5 ... -25 % -- the operand panels are re-read by 4-8 CUs through the XCD's L2
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const MLA_GLOBAL_AS void*)gsrc, (MLA_LDS_AS void*)lds_wave_base, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const MLA_GLOBAL_AS void*)gsrc, (MLA_LDS_AS void*)lds_wave_base, 16, 0, MLA_GLDS_AUX);
 }
 
 // LDS transpose read: 4 x b16 per lane (see DESIGN.md "tr16 semantics", verified by mla_selftest_tr16)
