@@ -323,6 +323,53 @@ class CfgK64(Cfg):
         lines += self.mfmas(1, aux)
         return lines
 
+    def tile_pgr2(self, tset):
+        """One K-tile of the 4-wave loop with loads 1.5 tiles ahead (flag "pgr2"). The LDS set is handed back operand by operand:
+             k-step 0 (MFMA buf0):  read A(t,ks1) -> buf1 | lgkmcnt(0) BARRIER 1: A region of this set is free | load A(t+2) | read
+                                    B(t,ks1) -> buf1 | lgkmcnt(0) BARRIER 2: B region free | load B(t+2)
+             k-step 1 (MFMA buf1):  vmcnt(24) BARRIER 3: A(t+1) landed | read A(t+1,ks0) -> buf0 | vmcnt(16) BARRIER 4: B(t+1) landed |
+                                    read B(t+1,ks0) -> buf0
+           vmcnt is in-order: behind A(t+1) sit B(t+1), A(t+2), B(t+2) = 24 loads; behind B(t+1) 16. Every load is issued >= 1.3 tiles
+           before the barrier that waits for it (the one-barrier schedule: <= 1 tile)."""
+        nm = self.FI * self.FJ
+        NL = self.NLOAD
+        loads = self.load_group(tset)                       # [pointer bundle, A x NL, B x NL]
+        ptr, la, lb = loads[0], loads[1:1 + NL], loads[1 + NL:1 + 2 * NL]
+        ra1 = [self.ds_read(self.afrag(1, x), False, tset, 1, x) for x in range(self.FI)]
+        rb1 = [self.ds_read(self.bfrag(1, x), True, tset, 1, x) for x in range(self.FJ)]
+        ra0 = [self.ds_read(self.afrag(0, x), False, tset ^ 1, 0, x) for x in range(self.FI)]
+        rb0 = [self.ds_read(self.bfrag(0, x), True, tset ^ 1, 0, x) for x in range(self.FJ)]
+        bar = [] if "nobarrier" in self.flags else ["s_barrier"]
+        # ---- k-step 0
+        aux = {}
+        for k, r in enumerate(ra1):
+            aux.setdefault(2 * k, []).append(r)
+        n = 2 * len(ra1) + 2
+        aux.setdefault(n, []).extend(["s_waitcnt lgkmcnt(0)"] + bar)
+        aux.setdefault(n + 1, []).extend(ptr)
+        for k in range(NL):                                 # A loads and B(ks1) reads alternate, one instruction per MFMA
+            aux.setdefault(n + 2 + 2 * k, []).extend(la[k])
+            aux.setdefault(n + 3 + 2 * k, []).append(rb1[k] if k < len(rb1) else "s_nop 0")
+        n2 = n + 2 + 2 * NL + 2
+        aux.setdefault(n2, []).extend(["s_waitcnt lgkmcnt(0)"] + bar)
+        gap = max(1, (nm - n2 - 2) // NL)
+        for k in range(NL):
+            aux.setdefault(n2 + 1 + k * gap, []).extend(lb[k])
+        assert max(aux) < nm, (max(aux), nm)
+        lines = [f"; ---- tile set {tset}, k-step 0 (pgr2)", "s_waitcnt lgkmcnt(0)"] + self.mfmas(0, aux)
+        # ---- k-step 1
+        aux = {}
+        aux.setdefault(1, []).extend([f"s_waitcnt vmcnt({3 * NL})"] + bar)
+        for k, r in enumerate(ra0):
+            aux.setdefault(3 + 2 * k, []).append(r)
+        n3 = 3 + 2 * len(ra0) + 4
+        aux.setdefault(n3, []).extend([f"s_waitcnt vmcnt({2 * NL})"] + bar)
+        for k, r in enumerate(rb0):
+            aux.setdefault(n3 + 2 + 2 * k, []).append(r)
+        assert max(aux) < nm, (max(aux), nm)
+        lines += [f"; ---- tile set {tset}, k-step 1 (pgr2)"] + self.mfmas(1, aux)
+        return lines
+
     def prologue(self):
         vb = self.vbase
         lines = ["; ---- prologue", "s_mov_b64 s[40:41], %[pA]", "s_mov_b64 s[42:43], %[pB]", "s_mov_b32 s44, 0", "s_mov_b32 s45, %[kmax]",
@@ -350,7 +397,8 @@ class CfgK64(Cfg):
         return lines
 
     def body(self, two_schedules=False):
-        out = self.prologue() + ["1:"] + self.tile(0) + self.tile(1)
+        tile = self.tile_pgr2 if "pgr2" in self.flags else self.tile
+        out = self.prologue() + ["1:"] + tile(0) + tile(1)
         out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 1b"]
         return out + ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7", "s_nop 7"]
 
