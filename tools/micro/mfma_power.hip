@@ -113,6 +113,45 @@ __global__ __launch_bounds__(512) void mfma_order_loop(const bf16x8* __restrict_
   out[blockIdx.x * 512 + lane] = s;
 }
 
+// the same 128 x 64 wave tile with v_mfma_f32_32x32x16_bf16: 4 x 2 blocks of 32 x 32 (16 accumulator registers each), 4 k-steps of 16 per
+// 64-k tile = 32 MFMAs of 32768 flops per iteration (the same flops as the 64 MFMAs of the 16x16x32 loops)
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+__global__ __launch_bounds__(512) void mfma32_loop(const bf16x8* __restrict__ src, float* __restrict__ out, int iters) {
+  const int lane = threadIdx.x;
+  bf16x8 a[4][4], b[4][2];
+  const bf16x8* p = src + (size_t)(blockIdx.x * 512 + lane) * 24;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[s][i] = p[s * 6 + i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[s][j] = p[s * 6 + 4 + j];
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+  out[blockIdx.x * 512 + lane] = sum;
+}
+
 __global__ __launch_bounds__(512) void mfma_loop(const bf16x8* __restrict__ src, float* __restrict__ out, int iters) {
   const int lane = threadIdx.x;
   bf16x8 a[2][8], b[2][4];
@@ -193,6 +232,9 @@ int main(int argc, char** argv) {
         hipEventElapsedTime(&t, e0, e1);
         printf("    gemm256-shaped MFMA stream, %s: %.1f TFLOP/s\n", name, flops / t / 1e9);
       };
+      run(mfma32_loop, "32x32x16 MFMA, 4x2 blocks");
+      run(mfma_order_loop<4, 2, 0>, "order 4x2 k-outer    ");
+      run(mfma32_loop, "32x32x16 MFMA (again)   ");
       run(mfma_order_loop<8, 4, 0>, "order 8x4 k-outer    ");
       run(mfma_order_loop<4, 4, 0>, "order 4x4 k-outer    ");
       run(mfma_order_loop<4, 2, 0>, "order 4x2 k-outer    ");
