@@ -130,6 +130,39 @@ def test_decoder_layer_fwd_bwd(dev, save_level, lens):
         assert fro_rel(w.grad, pr[n].grad) < 2e-2, n
 
 
+def test_decoder_layer_at_7b_dimensions(dev):
+    """One LlamaDecoderLayer at the benchmark's true dimensions (H 4096, I 11008, 32 heads x 128, S = 548; 2 sequences keep the fp32
+    oracle at a few seconds of CPU time): the 256x256 GEMM with its split-K tail, the all-NT backward with its transposes, the
+    head-dim-128 attention at the benchmark's sequence length -- output, input gradient and every weight gradient against the oracle."""
+    from mla_amd import ops
+    H, I, nh, B, S = 4096, 11008, 32, 2, 548
+    names = ["input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+             "self_attn.o_proj.weight", "post_attention_layernorm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+             "mlp.down_proj.weight"]
+    shapes = [(H,), (H, H), (H, H), (H, H), (H, H), (H,), (I, H), (I, H), (H, I)]
+    g = torch.Generator().manual_seed(7)
+    p32 = {n: ((torch.ones(s) + 0.1 * torch.randn(s, generator=g)) if len(s) == 1 else 0.02 * torch.randn(s, generator=g)).to(BF).float()
+           for n, s in zip(names, shapes)}
+    x = torch.randn(B, S, H, generator=g).to(BF)
+    dy = torch.randn(B, S, H, generator=g).to(BF)
+    seqlens = torch.tensor([S, 500])
+    cos, sin = O.rope_tables(S, H // nh)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    xr = x.float().requires_grad_(True)
+    pr = {n: v.clone().requires_grad_(True) for n, v in p32.items()}
+    ref = O.decoder_layer(xr, pr, cos, sin, nh, 1e-5, seqlens)
+    ref.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    wd = [p32[n].to(BF).to(dev).requires_grad_(True) for n in names]
+    out = ops.decoder_layer(xd, seqlens.to(dev).int(), cos.to(dev), sin.to(dev), nh, 1e-5, 1, wd)
+    out.backward(dy.to(dev))
+    valid = torch.arange(S)[None] < seqlens[:, None]
+    assert fro_rel(out[valid.to(dev)], ref[valid]) < 1e-2
+    assert fro_rel(xd.grad[valid.to(dev)], xr.grad[valid]) < 2e-2
+    for n, w in zip(names, wd):
+        assert fro_rel(w.grad, pr[n].grad) < 2e-2, n
+
+
 def _run_hip_e2e(dev, save_level=2):
     m = build_tiny_mla(dev, save_level)
     batch, draws = recipe.make_batch(R=2)
