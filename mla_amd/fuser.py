@@ -121,7 +121,9 @@ class CoordinateAwareContrastiveLoss(nn.Module):
         D = img_proj.shape[-1]
         # row gathers / compaction are index plumbing (torch); all arithmetic below runs in the HIP kernels
         base = (torch.arange(B, device=linear.device) * n_patches)[:, None]
-        vidx = torch.nonzero(valid_mask.reshape(-1), as_tuple=False).squeeze(-1)   # host sync, like the reference's mask index
+        vidx = getattr(valid_mask, "_mla_valid_index", None)      # taken early by PrismaticVLM.forward (no sync behind the decoder)
+        if vidx is None:
+            vidx = torch.nonzero(valid_mask.reshape(-1), as_tuple=False).squeeze(-1)   # host sync, like the reference's mask index
         M = int(vidx.numel())
         if M == 0:
             return torch.tensor(0.0, device=image_features.device, requires_grad=True)

@@ -324,6 +324,11 @@ class PrismaticVLM(nn.Module):
 
         parts, patch_indices, valid_mask, pos_pc_tac, lin_img_tac, _ = self.get_fused_tokens(images, point_cloud, tactile, gripper_xyz,
                                                                                         camera_name)
+        if self.training and self.use_contrastive and valid_mask is not None:
+            # the contrastive loss compacts the valid correspondences (a host-synchronising index, like the reference's mask index,
+            # contrastive.py:196-203). The mask only depends on the point centres, so the index is taken HERE, while the GPU has
+            # barely started the step, instead of after the decoder forward where the same sync drains a full launch queue
+            valid_mask._mla_valid_index = torch.nonzero(valid_mask.reshape(-1), as_tuple=False).squeeze(-1)
         n_fused = sum(p.shape[1] for p in parts)
         N_pc = N_img = 256
         pc_idx = (1, 1 + N_pc)
