@@ -329,6 +329,7 @@ class PrismaticVLM(nn.Module):
             # contrastive.py:196-203). The mask only depends on the point centres, so the index is taken HERE, while the GPU has
             # barely started the step, instead of after the decoder forward where the same sync drains a full launch queue
             valid_mask._mla_valid_index = torch.nonzero(valid_mask.reshape(-1), as_tuple=False).squeeze(-1)
+        self.vision_tower_2d.assert_masks_ok()      # pixel-mask verdict of the vision tokenizer (free behind the sync above)
         n_fused = sum(p.shape[1] for p in parts)
         N_pc = N_img = 256
         pc_idx = (1, 1 + N_pc)

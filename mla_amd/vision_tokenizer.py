@@ -156,10 +156,10 @@ class VisionTokenizer(nn.Module):
         B, CT, Hi, Wi = pixel_values.shape
         P, cs, C = self.patch_stride, self.conv_stride, self.hidden_size
         gh, gw = Hi // P, Wi // P
-        masks = pixel_values[:, -1]
-        if not bool((masks == 1).all()):
-            raise NotImplementedError("cropped pixel masks: only the all-ones mask yields the 256 tokens the reference's "
-                                      "N_img = 256 layout needs (models/vlm/prismatic.py:932-933)")
+        # only the all-ones pixel mask is supported; the verdict is read back by assert_masks_ok() -- called by the owner at its next
+        # host synchronisation point (PrismaticVLM.forward, right after the contrastive index) so that the check does not stall an
+        # empty launch queue at the very start of the step
+        self._mask_ok = (pixel_values[:, -1] == 1).all()
         kreal = 3 * P * P
         kpad = ((kreal + 31) // 32) * 32
         la = self.local_attention
@@ -187,6 +187,14 @@ class VisionTokenizer(nn.Module):
             agg = hip.local_attn(qv, kv, B, gh, gw, cs, la.num_heads, la.scale)
             tok = hip.gemm(agg, la.proj.weight, bias=la.proj.bias, residual=red)
         return tok.view(B, (gh // cs) * (gw // cs), C)
+
+    def assert_masks_ok(self) -> None:
+        ok = getattr(self, "_mask_ok", None)
+        if ok is not None:
+            self._mask_ok = None
+            if not bool(ok):
+                raise NotImplementedError("cropped pixel masks: only the all-ones mask yields the 256 tokens the reference's "
+                                          "N_img = 256 layout needs (models/vlm/prismatic.py:932-933)")
 
     def forward(self, pixel_values, modules, repeat: int = 1):
         """Reference signature (pixel_values, projector) -> (list of [256, token_size] tokens, list of [h, w]).

@@ -264,3 +264,19 @@ def test_full_size_step_is_deterministic_and_consistent(dev):
     assert abs(coef - min(1.0, 1.0 / (norm + 1e-6))) < 1e-5
     del strat, mla
     torch.cuda.empty_cache()
+
+
+def test_cropped_pixel_mask_is_rejected(dev):
+    """The vision tokenizer only supports the all-ones pixel mask (N_img = 256 layout); the check is deferred to the owner's next
+    synchronisation point and must still fire."""
+    from mla_amd.vision_tokenizer import MLP_GELU, VisionTokenizer
+    vt, proj = VisionTokenizer(1024), MLP_GELU(1024, recipe.TOKEN_SIZE, 2)
+    vt.requires_grad_(False).to(dev).to(BF); proj.to(dev).to(BF)
+    img = torch.randn(1, 4, 672, 672)
+    img[:, 3] = 1.0
+    vt(img.to(dev), proj)
+    vt.assert_masks_ok()
+    img[0, 3, :14] = 0.0
+    vt(img.to(dev), proj)
+    with pytest.raises(NotImplementedError):
+        vt.assert_masks_ok()
