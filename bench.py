@@ -113,8 +113,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs through torch.distributed.run (one process per GPU)")
+        if "RANK" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: re-launch ourselves as N ranks (one process per GPU) under torch.distributed.run --
+            # exactly the command the driver uses; rank 0 of the children prints the JSON line
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                      "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:       # launched through torch.distributed.run (also with --gpus 1)
@@ -186,7 +195,7 @@ def main():
                     "algorithmic_bytes_per_launch_2B_outputs": round(abytes), "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
                     "gemm_ms_per_step": round(tsum / args.steps * 1e3, 1)}
         out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+               "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": ("BASELINE.json configs[1]: MLA-Llama2-7B SFT, use_pointcloud+use_contrastive, 672x672(+mask) image + "
                                        "1024 points + 32 text tokens, per-GPU batch 8 x 4 diffusion repeats = 32 x 548 tokens" if args.config == 1 else

@@ -53,6 +53,14 @@ int mla_rmsnorm_bwd_blocks(int rows);
 /* dx = dres + d(rmsnorm)/dx ; dw (+)= sum_rows dy * x_hat ; workspace >= mla_rmsnorm_bwd_blocks(rows)*H floats */
 int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx, float* dw,
                     int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes, mla_stream_t stream);
+/* ---- timm==0.9.10 RmsNorm (FinalLayer.norm_final, models/diffusion/models.py:18,177; pin pyproject.toml:44): timm v0.9.10
+ * timm/layers/fast_norm.py::rms_norm computes v = torch.var(x, dim=-1, keepdim=True) (unbiased, mean-subtracted) and returns
+ * x * rsqrt(v + eps) * weight -- not the mean-of-squares norm above. mean/rstd [rows] fp32 are saved for the backward. */
+int mla_timm_rmsnorm_fwd(const void* x, const void* w, void* y, float* mean, float* rstd, int rows, int H, float eps,
+                         mla_stream_t stream);
+/* dx = d(timm rms_norm)/dx ; dw (+)= sum_rows dy * x * rstd ; workspace >= mla_rmsnorm_bwd_blocks(rows)*H floats */
+int mla_timm_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx, float* dw,
+                         int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes, mla_stream_t stream);
 /* bias gradients of every nn.Linear with a bias on the path (autograd of util/nn_utils.py:21-34, models/diffusion/models.py:112-123):
  * out[n] (+)= sum_r dy[r][n]; workspace >= mla_colsum_blocks(rows)*N floats */
 int mla_colsum_blocks(int rows);

@@ -48,6 +48,120 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// timm==0.9.10 RmsNorm, the norm_final of the diffusion FinalLayer (models/diffusion/models.py:18,177; pin pyproject.toml:44).
+// timm tag v0.9.10, timm/layers/norm.py::RmsNorm.forward -> timm/layers/fast_norm.py::fast_rms_norm -> (no apex) rms_norm:
+//     v = torch.var(x, dim=-1, keepdim=True)      # UNBIASED and mean-subtracted: sum((x - mean)^2) / (H - 1)
+//     x = x * torch.rsqrt(v + eps);  x = x * weight
+// i.e. NOT the mean-of-squares RMS norm of LlamaRMSNorm (timm >= 1.0.13 fixed this and kept the 0.9 behaviour as "SimpleNorm").
+// x itself is not centred. Rounding points follow the reference's bf16 autocast run: var and var + eps are bf16 tensors,
+// torch.rsqrt is on autocast's fp32 list, so x * rsqrt(.) * weight is an fp32 product, cast to bf16 by fc1 (autocast Linear).
+// One 256-thread block per row.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void timm_rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                               bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                               float* __restrict__ rstd_out, int rows, int H, float eps) {
+  __shared__ float scratch[16];
+  const int row = blockIdx.x;
+  const int nchunk = H >> 3;
+  const bf16_t* xr = x + (size_t)row * H;
+  float xv[NORM_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      unpack8(*(const u32x4_t*)(xr + ch * 8), xv[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xv[c][j];
+    }
+  }
+  const float mean = block_sum(s, scratch) / (float)H;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xv[c][j] - mean; ss += d * d; }
+    }
+  }
+  const float var = bf2f(f2bf(block_sum(ss, scratch) / (float)(H - 1)));
+  const float rstd = 1.0f / sqrtf(bf2f(f2bf(var + eps)));
+  if (threadIdx.x == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      float wv[8], o[8];
+      unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = xv[c][j] * rstd * wv[j];
+      *(u32x4_t*)(y + (size_t)row * H + ch * 8) = pack8(o);
+    }
+  }
+}
+
+// y_j = x_j r w_j, r = (var + eps)^-1/2, var = sum_i (x_i - mean)^2 / (H - 1):
+// dx_i = dy_i w_i r - r^3 (x_i - mean) / (H - 1) * sum_j dy_j w_j x_j ;  dw partial[blockIdx][j] = sum_rows dy_j x_j r
+__global__ __launch_bounds__(256) void timm_rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                               const bf16_t* __restrict__ w, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                               float* __restrict__ dw_partial, int rows, int H) {
+  __shared__ float scratch[16];
+  const int nchunk = H >> 3;
+  float wv[NORM_MAXC][8], dwacc[NORM_MAXC][8];
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwacc[c][j] = 0.f;
+    if (ch < nchunk) unpack8(*(const u32x4_t*)(w + ch * 8), wv[c]);
+  }
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float rs = rstd[row], mu = mean[row];
+    float xv[NORM_MAXC][8], dn[NORM_MAXC][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NORM_MAXC; ++c) {
+      const int ch = threadIdx.x + c * 256;
+      if (ch < nchunk) {
+        float dyv[8];
+        unpack8(*(const u32x4_t*)(x + (size_t)row * H + ch * 8), xv[c]);
+        unpack8(*(const u32x4_t*)(dy + (size_t)row * H + ch * 8), dyv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          dn[c][j] = dyv[j] * wv[c][j];
+          dot += dn[c][j] * xv[c][j];
+          dwacc[c][j] += dyv[j] * xv[c][j] * rs;
+        }
+      }
+    }
+    dot = block_sum(dot, scratch) * rs * rs * rs / (float)(H - 1);
+#pragma unroll
+    for (int c = 0; c < NORM_MAXC; ++c) {
+      const int ch = threadIdx.x + c * 256;
+      if (ch < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * dn[c][j] - (xv[c][j] - mu) * dot;
+        *(u32x4_t*)(dx + (size_t)row * H + ch * 8) = pack8(o);
+      }
+    }
+  }
+  if (dw_partial) {
+#pragma unroll
+    for (int c = 0; c < NORM_MAXC; ++c) {
+      const int ch = threadIdx.x + c * 256;
+      if (ch < nchunk) {
+        float* o = dw_partial + (size_t)blockIdx.x * H + ch * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = dwacc[c][j];
+      }
+    }
+  }
+}
+
 // dx = dres + rstd * (dy*w - n * mean(dy*w*n)),  n = x*rstd ;  dw partial[blockIdx][h] = sum_rows dy*n
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
@@ -541,6 +655,30 @@ extern "C" int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   MLA_CHECK_ARG(!dw || (workspace && workspace_bytes >= (size_t)nb * H * sizeof(float)), "mla_rmsnorm_bwd: workspace too small");
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
                      (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
+  if (dw)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_timm_rmsnorm_fwd(const void* x, const void* w, void* y, float* mean, float* rstd, int rows, int H, float eps,
+                                    hipStream_t stream) {
+  MLA_CHECK_ARG(x && w && y && mean && rstd, "mla_timm_rmsnorm_fwd: null pointer");
+  MLA_CHECK_ARG(rows > 0 && H > 8 && H % 8 == 0 && H <= 8192, "mla_timm_rmsnorm_fwd: need H%%8==0, 8<H<=8192 (H=%d)", H);
+  MLA_CHECK_ARG(AL16(x) && AL16(w) && AL16(y), "mla_timm_rmsnorm_fwd: pointers must be 16-B aligned");
+  hipLaunchKernelGGL(timm_rmsnorm_fwd_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
+                     mean, rstd, rows, H, eps);
+  MLA_LAUNCH_CHECK();
+}
+
+extern "C" int mla_timm_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx,
+                                    float* dw, int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes,
+                                    hipStream_t stream) {
+  MLA_CHECK_ARG(dy && x && w && mean && rstd && dx, "mla_timm_rmsnorm_bwd: null pointer");
+  MLA_CHECK_ARG(rows > 0 && H > 8 && H % 8 == 0 && H <= 8192, "mla_timm_rmsnorm_bwd: need H%%8==0, 8<H<=8192 (H=%d)", H);
+  const int nb = mla_rmsnorm_bwd_blocks(rows);
+  MLA_CHECK_ARG(!dw || (workspace && workspace_bytes >= (size_t)nb * H * sizeof(float)), "mla_timm_rmsnorm_bwd: workspace too small");
+  hipLaunchKernelGGL(timm_rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
   if (dw)
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
   MLA_LAUNCH_CHECK();

@@ -189,7 +189,15 @@ class Mlp(nn.Module):
 
 
 class RmsNorm(nn.Module):
-    """timm.layers.RmsNorm(C, eps): x * rsqrt(mean(x^2) + eps) * weight."""
+    """timm==0.9.10 `RmsNorm(channels, eps)` (pin: pyproject.toml:44; imported at models/diffusion/models.py:18).
+
+    timm tag v0.9.10: `timm/layers/norm.py::RmsNorm.forward` calls `fast_rms_norm(x, normalized_shape, weight, eps)`
+    (`timm/layers/fast_norm.py`), which without apex falls through to `rms_norm`:
+        v = torch.var(x, dim=dims, keepdim=True);  x = x * torch.rsqrt(v + eps);  x = x * weight
+    `torch.var` is the UNBIASED, mean-subtracted variance -- this is not the mean-of-squares RMS norm (timm 1.0.13 fixed
+    `RmsNorm` and kept this arithmetic under the name `SimpleNorm`). With apex installed timm 0.9.10 would dispatch to
+    `fused_rms_norm_affine` (true RMS); the reference's environment (pyproject.toml) does not install apex, so the
+    torch.var form is the one matched here."""
 
     def __init__(self, channels, eps=1e-6):
         super().__init__()
@@ -197,7 +205,7 @@ class RmsNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(channels))
 
     def forward(self, x):
-        return ops.rmsnorm(x, self.weight, self.eps)
+        return ops.timm_rmsnorm(x, self.weight, self.eps)
 
 
 class ActionEmbedder(nn.Module):  # models.py:112-123

@@ -35,6 +35,9 @@ _SIGNATURES = {
                          c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p],
     "mla_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "mla_rmsnorm_bwd_blocks": [c_int],
+    "mla_timm_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "mla_timm_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                             c_size_t, c_void_p],
     "mla_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                         c_size_t, c_void_p],
     "mla_colsum_blocks": [c_int],
@@ -217,6 +220,27 @@ def rmsnorm_bwd(dy, x2d, w, rstd, dres=None, dw_out=None, dw_accumulate=False):
     nb = lib().mla_rmsnorm_bwd_blocks(rows)
     ws = workspace(nb * H * 4, x2d.device) if dw_out is not None else None
     call("mla_rmsnorm_bwd", _p(dy), _p(x2d), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw_out), 1 if dw_accumulate else 0, rows, H,
+         _p(ws), ws.numel() if ws is not None else 0)
+    return dx
+
+
+def timm_rmsnorm_fwd(x2d, w, eps):
+    """timm==0.9.10 RmsNorm (torch.var based, see include/mla_hip.h). Returns (y, mean, rstd)."""
+    _req(x2d, torch.bfloat16, "timm_rmsnorm x")
+    _req(w, torch.bfloat16, "timm_rmsnorm w")
+    rows, H = x2d.shape
+    y = torch.empty_like(x2d)
+    stats = torch.empty(2, rows, dtype=torch.float32, device=x2d.device)
+    call("mla_timm_rmsnorm_fwd", _p(x2d), _p(w), _p(y), _p(stats[0]), _p(stats[1]), rows, H, float(eps))
+    return y, stats[0], stats[1]
+
+
+def timm_rmsnorm_bwd(dy, x2d, w, mean, rstd, dw_out=None, dw_accumulate=False):
+    rows, H = x2d.shape
+    dx = torch.empty_like(x2d)
+    nb = lib().mla_rmsnorm_bwd_blocks(rows)
+    ws = workspace(nb * H * 4, x2d.device) if dw_out is not None else None
+    call("mla_timm_rmsnorm_bwd", _p(dy), _p(x2d), _p(w), _p(mean), _p(rstd), _p(dx), _p(dw_out), 1 if dw_accumulate else 0, rows, H,
          _p(ws), ws.numel() if ws is not None else 0)
     return dx
 

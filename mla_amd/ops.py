@@ -251,6 +251,40 @@ def rmsnorm(x, weight, eps):
     return RMSNormFn.apply(x, weight, eps)
 
 
+class TimmRmsNormFn(torch.autograd.Function):
+    """timm==0.9.10 RmsNorm: x * rsqrt(torch.var(x, -1) + eps) * weight (hip.timm_rmsnorm_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        _check_bf16_cuda(x, weight)
+        x2 = _as2d(x)
+        y, mean, rstd = hip.timm_rmsnorm_fwd(x2, weight, eps)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.weight = weight
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        w = ctx.weight
+        dy2 = _as2d(dy)
+        out = {}
+
+        def run(dw_out, acc):
+            out["dx"] = hip.timm_rmsnorm_bwd(dy2, x2, w, mean, rstd, dw_out=dw_out, dw_accumulate=acc)
+
+        if ctx.needs_input_grad[1]:
+            dw = deliver_vec_grad(w, run)
+        else:
+            run(None, False)
+            dw = None
+        return out["dx"].view(dy.shape), dw, None
+
+
+def timm_rmsnorm(x, weight, eps):
+    return TimmRmsNormFn.apply(x, weight, eps)
+
+
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kind):

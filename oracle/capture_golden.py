@@ -165,6 +165,24 @@ def capture_components():
     with torch.no_grad():
         toks, hw = vt(batch["images"]["front_image"], proj)
     res["vt_tokens_slice"] = torch.stack(toks)[:, :, :64].numpy()
+    # --- FinalLayer (models/diffusion/models.py:173-189) on NON-zero-mean rows with outlier channels: the input on which timm
+    # 0.9.10's torch.var-based RmsNorm and a mean-of-squares RMS norm visibly differ (Llama hidden states look like this)
+    from models.diffusion.models import FinalLayer
+    fl = FinalLayer(256, 7)
+    fl.load_state_dict({k: recipe.det_weight("vlm.final_layer." + k, v.shape) for k, v in fl.state_dict().items()})
+    with torch.no_grad():
+        fl.norm_final.weight.copy_(1.0 + 0.25 * torch.randn(256, generator=g))
+    xf = torch.randn(12, 256, generator=g) * torch.linspace(0.5, 2.0, 12)[:, None] + torch.linspace(-3.0, 3.0, 12)[:, None]
+    xf[:, 7] += 20.0
+    xf[:, 100] -= 12.0
+    xf.requires_grad_(True)
+    nf = fl.norm_final(xf)
+    yf = fl.mlp(nf)
+    gy = torch.randn(yf.shape, generator=g)
+    gx, gnw, gfc1 = torch.autograd.grad(yf, [xf, fl.norm_final.weight, fl.mlp.fc1.weight], gy)
+    res["fl_x"], res["fl_norm_w"], res["fl_normed"], res["fl_y"], res["fl_gy"] = (xf.detach().numpy(), fl.norm_final.weight.detach().numpy(),
+                                                                                   nf.detach().numpy(), yf.detach().numpy(), gy.numpy())
+    res["fl_gx"], res["fl_g_norm_w"], res["fl_g_fc1_w"] = gx.numpy(), gnw.numpy(), gfc1.numpy()
     np.savez_compressed(os.path.join(OUT, "components.npz"), **res)
     print("components.npz keys:", len(res))
 

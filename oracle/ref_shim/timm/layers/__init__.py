@@ -1,3 +1,5 @@
+"""Stand-in for the pieces of timm==0.9.10 (pyproject.toml:44) that models/diffusion/models.py:18 imports. timm cannot be
+installed in the build image, so each class restates the published v0.9.10 source it names. TEST INFRASTRUCTURE ONLY."""
 import torch
 import torch.nn as nn
 
@@ -21,18 +23,39 @@ class Mlp(nn.Module):
         return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
 
 
+def rms_norm(x, normalized_shape, weight=None, eps=1e-5):
+    """Restatement of timm tag v0.9.10 `timm/layers/fast_norm.py::rms_norm` (the non-scripting branch; timm is not installable in
+    the build image, the reference pins timm==0.9.10 at pyproject.toml:44):
+
+        dims = tuple(range(-1, -norm_ndim - 1, -1));  v = torch.var(x, dim=dims, keepdim=True)
+        x = x * torch.rsqrt(v + eps);  if weight is not None: x = x * weight
+
+    `torch.var` defaults to the unbiased (N - 1), MEAN-SUBTRACTED variance, so 0.9.10's "RmsNorm" is not a mean-of-squares
+    RMS norm. timm 1.0.13 ("Fix existing RmsNorm layer & fn to match standard formulation ... move old impl to SimpleNorm")
+    changed it; the 0.9.10 arithmetic survives there as `simple_norm`. `fast_rms_norm` only takes another route under
+    torch.jit scripting (same formula) or with apex installed (`fused_rms_norm_affine`, true RMS) -- the reference does not
+    depend on apex (pyproject.toml), so this fallback is what `FinalLayer.norm_final` runs."""
+    dims = tuple(range(-1, -len(normalized_shape) - 1, -1))
+    v = torch.var(x, dim=dims, keepdim=True)
+    x = x * torch.rsqrt(v + eps)
+    if weight is not None:
+        x = x * weight
+    return x
+
+
 class RmsNorm(nn.Module):
-    """timm.layers.RmsNorm: x * rsqrt(mean(x^2, -1) + eps) * weight (fast_rms_norm fallback path, computed in x's dtype)."""
+    """timm v0.9.10 `timm/layers/norm.py::RmsNorm(channels, eps=1e-6, affine=True)`: weight initialised to ones;
+    forward = fast_rms_norm(x, self.normalized_shape, self.weight, self.eps) -> rms_norm above."""
 
     def __init__(self, channels, eps=1e-6, affine=True, device=None, dtype=None):
         super().__init__()
         self.normalized_shape = (channels,)
         self.eps = eps
-        self.weight = nn.Parameter(torch.ones(channels))
+        self.elementwise_affine = affine
+        self.weight = nn.Parameter(torch.ones(channels)) if affine else None
 
     def forward(self, x):
-        v = torch.var(x, dim=-1, keepdim=True, unbiased=False) + x.mean(-1, keepdim=True) ** 2 if False else torch.mean(x * x, dim=-1, keepdim=True)
-        return x * torch.rsqrt(v + self.eps) * self.weight
+        return rms_norm(x, self.normalized_shape, self.weight, self.eps)
 
 
 class DropPath(nn.Module):

@@ -120,10 +120,19 @@ def timestep_embedder(t, w0, b0, w2, b2):
     return F.linear(F.silu(F.linear(timestep_embedding(t).to(w0.dtype), w0, b0)), w2, b2)
 
 
+def timm_rms_norm(x, weight, eps: float = 1e-6):
+    """timm==0.9.10 RmsNorm.forward (timm v0.9.10 timm/layers/fast_norm.py::rms_norm, reached from
+    models/diffusion/models.py:177,187): v = torch.var(x, dim=-1, keepdim=True) -- unbiased and mean-subtracted --
+    then x * rsqrt(v + eps) * weight. Rounding points as in the reference's bf16-autocast run: var and var + eps stay in
+    x's dtype, torch.rsqrt is on autocast's fp32 list, so the two products are fp32 (identity for fp32 inputs)."""
+    v = torch.var(x, dim=-1, keepdim=True)
+    r = torch.rsqrt((v + eps).float())
+    return x.float() * r * weight.float()
+
+
 def final_layer(x, norm_w, fc1_w, fc1_b, fc2_w, fc2_b, eps: float = 1e-6):
-    """FinalLayer.forward models/diffusion/models.py:186-189; timm RmsNorm = x*rsqrt(mean(x^2)+eps)*w."""
-    x32 = x.float()
-    n = (x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype) * norm_w
+    """FinalLayer.forward models/diffusion/models.py:186-189: timm 0.9.10 RmsNorm (torch.var based) -> Mlp."""
+    n = timm_rms_norm(x, norm_w, eps).to(x.dtype)
     return mlp_gelu_tanh(n, fc1_w, fc1_b, fc2_w, fc2_b)
 
 

@@ -120,6 +120,58 @@ def test_rmsnorm(dev, rows, H):
     assert fro_rel(dw, wf.grad) < 1e-3
 
 
+@pytest.mark.parametrize("rows,H", [(32, 4096), (12, 256), (700, 1024)])
+def test_timm_rmsnorm_var_based(dev, rows, H):
+    """timm==0.9.10 RmsNorm of FinalLayer.norm_final (torch.var based, models/diffusion/models.py:177): kernel vs the oracle on
+    NON-zero-mean rows with outlier channels; the mean-of-squares kernel must be visibly different on the same input."""
+    from mla_amd import hip
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, H, generator=g) * torch.linspace(0.5, 2.0, rows)[:, None] + torch.linspace(-3.0, 3.0, rows)[:, None]
+    x[:, 7] += 20.0
+    x[:, H // 2] -= 12.0
+    x = x.to(BF)
+    w = (1 + 0.25 * torch.randn(H, generator=g)).to(BF)
+    y, mean, rstd = hip.timm_rmsnorm_fwd(x.to(dev), w.to(dev), 1e-6)
+    ref = O.timm_rms_norm(x, w, 1e-6)                                   # bf16 rounding points of the autocast reference
+    ref32 = O.timm_rms_norm(x.float(), w.float(), 1e-6)
+    e_bf, e_32 = fro_rel(y, ref), fro_rel(y, ref32)
+    print(f"timm_rmsnorm fwd rows={rows} H={H}: fro vs bf16-order oracle {e_bf:.2e}, vs fp32 oracle {e_32:.2e}")
+    assert e_bf < 3e-3 and e_32 < 6e-3
+    y_ms, _ = hip.rmsnorm_fwd(x.to(dev), w.to(dev), 1e-6)
+    assert fro_rel(y_ms, ref32) > 1e-2, "input does not separate torch.var from mean-of-squares"
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    dy = bfr(rows, H, seed=3)
+    O.timm_rms_norm(xf, wf, 1e-6).backward(dy.float())
+    dw = torch.zeros(H, dtype=torch.float32, device=dev)
+    dx = hip.timm_rmsnorm_bwd(dy.to(dev), x.to(dev), w.to(dev), mean, rstd, dw_out=dw)
+    e_dx, e_dw = fro_rel(dx, xf.grad), fro_rel(dw, wf.grad)
+    print(f"timm_rmsnorm bwd: dx {e_dx:.2e} dw {e_dw:.2e}")
+    assert e_dx < 6e-3 and e_dw < 4e-3
+
+
+def test_final_layer_vs_reference_golden(dev):
+    """FinalLayer module (timm 0.9.10 RmsNorm + Mlp) forward/backward vs vectors captured from the reference's class."""
+    import os
+    import numpy as np
+    from mla_amd.diffusion import FinalLayer
+    from oracle import recipe
+    c = np.load(os.path.join(os.path.dirname(__file__), "golden", "components.npz"))
+    fl = FinalLayer(256, 7)
+    fl.load_state_dict({k: recipe.det_weight("vlm.final_layer." + k, v.shape) for k, v in fl.state_dict().items()})
+    with torch.no_grad():
+        fl.norm_final.weight.copy_(torch.from_numpy(c["fl_norm_w"]))
+    fl = fl.to(dev).to(BF)
+    x = torch.from_numpy(c["fl_x"]).to(dev).to(BF).requires_grad_(True)
+    y = fl(x)
+    y.backward(torch.from_numpy(c["fl_gy"]).to(dev).to(BF))
+    e_y, e_gx = fro_rel(y, torch.from_numpy(c["fl_y"])), fro_rel(x.grad, torch.from_numpy(c["fl_gx"]))
+    gnw = getattr(fl.norm_final.weight, "main_grad", None)
+    gnw = gnw if gnw is not None else fl.norm_final.weight.grad
+    e_gw = fro_rel(gnw, torch.from_numpy(c["fl_g_norm_w"]))
+    print(f"FinalLayer vs reference golden: y {e_y:.2e} dx {e_gx:.2e} dnorm_w {e_gw:.2e}")
+    assert e_y < 1.5e-2 and e_gx < 2e-2 and e_gw < 2e-2
+
+
 def test_rope_roundtrip_and_oracle(dev):
     from mla_amd import hip
     B, S, H, D = 2, 37, 4, 128

@@ -49,6 +49,29 @@ def test_projection_exact(comp, cam):
     assert np.array_equal(valid.numpy(), comp[f"proj_valid_{cam}"])
 
 
+def test_final_layer_timm_0_9_10_rmsnorm_matches_reference(comp):
+    """FinalLayer (models/diffusion/models.py:173-189) through the reference's own class with the timm==0.9.10 RmsNorm restated
+    from timm's v0.9.10 source (torch.var based): oracle forward + autograd vs the captured vectors, on non-zero-mean rows where a
+    mean-of-squares norm would be off by tens of percent."""
+    x = torch.from_numpy(comp["fl_x"]).requires_grad_(True)
+    nw = torch.from_numpy(comp["fl_norm_w"]).requires_grad_(True)
+    P = "vlm.final_layer.mlp."
+    fc1w = recipe.det_weight(P + "fc1.weight", (256, 256)).requires_grad_(True)
+    fc1b, fc2w, fc2b = recipe.det_weight(P + "fc1.bias", (256,)), recipe.det_weight(P + "fc2.weight", (7, 256)), recipe.det_weight(P + "fc2.bias", (7,))
+    n = O.timm_rms_norm(x, nw, 1e-6)
+    assert np.allclose(n.detach().numpy(), comp["fl_normed"], rtol=1e-5, atol=1e-5)
+    y = O.final_layer(x, nw, fc1w, fc1b, fc2w, fc2b)
+    assert np.allclose(y.detach().numpy(), comp["fl_y"], rtol=1e-5, atol=1e-5)
+    gx, gnw, gfc1 = torch.autograd.grad(y, [x, nw, fc1w], torch.from_numpy(comp["fl_gy"]))
+    assert np.allclose(gx.numpy(), comp["fl_gx"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(gnw.numpy(), comp["fl_g_norm_w"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(gfc1.numpy(), comp["fl_g_fc1_w"], rtol=1e-4, atol=1e-5)
+    # the choice is visible: the mean-of-squares formula (LlamaRMSNorm, timm >= 1.0.13) is far from what 0.9.10 computes here
+    xs = comp["fl_x"]
+    meansq = xs / np.sqrt((xs * xs).mean(-1, keepdims=True) + 1e-6) * comp["fl_norm_w"]
+    assert np.abs(meansq - comp["fl_normed"]).max() / np.abs(comp["fl_normed"]).max() > 1e-2
+
+
 def _sd(prefix, shapes):
     return {k: recipe.det_weight(prefix + k, s) for k, s in shapes.items()}
 
