@@ -158,11 +158,13 @@ def main():
     for _ in range(args.warmup):
         losses = strat.train_step(batch)
     prof = None if args.no_gemm_profile else []
+    strat.synchronize()                        # flush the warm-up's deferred optimizer updates: the timed region owns exactly K of them
     sync()
     hip.GEMM_PROFILE = prof
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = strat.train_step(batch)
+    strat.synchronize()                        # the last step's AdamW (normally overlapped with the next forward) completes inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     hip.GEMM_PROFILE = None

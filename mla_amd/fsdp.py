@@ -168,9 +168,9 @@ class ShardedModel:
                  process_group=None, no_decay: Optional[Callable[[str, nn.Parameter], bool]] = None):
         self.model, self.device = model, device
         self.pg = process_group
+        import os
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
-        import os
         # MLA_FORCE_COLLECTIVES=1 runs the sharded code path (separate shards, RCCL calls, side stream) even with one rank:
         # used to validate the collective plumbing on a single-GPU box
         self.coll = self.world > 1 or (os.environ.get("MLA_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
@@ -213,15 +213,31 @@ class ShardedModel:
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
         self._coef = torch.ones(1, dtype=torch.float32, device=device)
         self._norm = torch.zeros(1, dtype=torch.float32, device=device)
+        self.on_gpu = self.device.type == "cuda"
+        if self.on_gpu:
+            # every launch of libmla_hip.so goes to the CURRENT device's current stream (hip._stream): the owner of this object
+            # must have made `device` current (FSDPStrategy.__init__ does), otherwise kernels would run on another device's stream
+            assert torch.cuda.current_device() == (self.device.index or 0), \
+                f"torch.cuda.set_device({self.device}) must be called before sharding a model onto it"
+        # side stream for the collectives (reduce-scatter launched per unit from the backward, all-gather behind the optimizer).
+        # NB (measured, round 2): running AdamW itself on a side stream underneath the next forward -- whole, per layer gated on the
+        # forward reaching the layer in front, low stream priority, grid capped to 128..1024 workgroups -- never changed the step
+        # time: the GEMMs slow down by exactly the AdamW time hidden (the chip is power-bound either way), so it stays inline.
         self.comm_stream = self.ops.stream(device) if self.coll else None
-        # all-gather consumption: a unit's forward waits for ITS gather only (issued right after that unit's optimizer update on
-        # the side stream), so the gathers of later layers keep streaming in behind the forward pass instead of being waited
-        # for up front; units without a module (root) are waited for in begin_step
-        if self.coll and self.device.type == "cuda":
+        # consumption: a unit's forward waits for ITS all-gather only, so later layers keep streaming in behind the forward pass
+        # instead of being waited for up front. Units without a module (root: embeddings, heads, embedders) are waited for in
+        # begin_step AND by a pre-hook on every module that directly owns one of their parameters, so an eval forward /
+        # predict_action_diff right after optimizer_step never reads half-gathered weights.
+        if self.on_gpu and self.comm_stream is not None:
             for u in self.units:
                 mod = getattr(u, "module", None)
                 if mod is not None:
                     mod.register_forward_pre_hook(lambda m, inp, uu=u: self.wait_unit(uu))
+                else:
+                    owned = {id(p) for _, p, _ in u.params}
+                    for m in model.modules():
+                        if any(id(p) in owned for p in m.parameters(recurse=False)):
+                            m.register_forward_pre_hook(lambda mm, inp, uu=u: self.wait_unit(uu))
         # reduce-scatter launch hooks on the decoder layers (fires when the layer's backward has been enqueued)
         for u in self.units:
             mod = getattr(u, "module", None)
@@ -276,6 +292,11 @@ class ShardedModel:
             torch.cuda.current_stream(self.device).wait_event(u.gather_event)
         u.gather_event = None
 
+    def wait_all(self):
+        """Main stream waits for every outstanding optimizer update / all-gather (checkpointing, evaluation, state access)."""
+        for u in self.units:
+            self.wait_unit(u)
+
     # ------------------------------------------------------------------------------------------ step API
     def begin_step(self):
         for u in self.units:
@@ -294,6 +315,8 @@ class ShardedModel:
                 u.collect_autograd_grads()
 
     def finish_backward(self):
+        if self.on_gpu:
+            self.wait_all()   # normally long satisfied (every used unit waited in its forward)
         for u in self.units:
             if u.trainable:
                 u.finish_backward()
@@ -321,6 +344,7 @@ class ShardedModel:
 
     def optimizer_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
         self.step_count += 1
+
         for u in self.units:
             if not u.trainable:
                 continue
@@ -329,7 +353,7 @@ class ShardedModel:
                                u.flat16[g0:g0 + (le - ls)], lr, betas, eps, weight_decay if decayed else 0.0, self.step_count,
                                self._coef)
             if self.coll:
-                if self.device.type == "cuda":
+                if self.on_gpu:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(self.device))
                     with torch.cuda.stream(self.comm_stream):
@@ -341,14 +365,28 @@ class ShardedModel:
                     self._all_gather(u)
 
     # ------------------------------------------------------------------------------------------ checkpoint helpers
-    def full_state_dict_fp32(self) -> Dict[str, torch.Tensor]:
-        """Gathers fp32 master weights of every parameter (rank-0-style full state dict, fsdp.py:100-141)."""
-        out = {}
+    def iter_full_state_fp32(self, to_cpu_on_rank0: bool = False):
+        """Yields ``(name, fp32 tensor)`` for every parameter, ONE UNIT AT A TIME: each unit's master shards are gathered (all ranks
+        take part in the collectives), handed out, and freed before the next unit is touched, so the peak extra device memory is
+        one unit (<= 0.8 GB for a 7B decoder layer), not the +27 GB of a whole fp32 model. With ``to_cpu_on_rank0`` only rank 0
+        receives tensors (already copied to host memory); the other ranks get ``(name, None)`` -- the reference's
+        FullStateDictConfig(offload_to_cpu=True, rank0_only=True), training/strategies/fsdp.py:107-110."""
+        if self.on_gpu:
+            self.wait_all()
         for u in self.units:
             full = self._gather_master(u)
+            keep = (not to_cpu_on_rank0) or self.rank == 0
             for n, p, o in u.params:
-                out[n] = full[o:o + p.numel()].view(p.shape).clone()
-        return out
+                if not keep:
+                    yield n, None
+                    continue
+                t = full[o:o + p.numel()].view(p.shape)
+                yield n, (t.cpu() if to_cpu_on_rank0 else t.clone())
+            del full
+
+    def full_state_dict_fp32(self) -> Dict[str, torch.Tensor]:
+        """Full fp32 state dict on the device of every rank (tests / small models; checkpoints use iter_full_state_fp32)."""
+        return dict(self.iter_full_state_fp32())
 
     def _gather_master(self, u: FlatUnit):
         if not self.coll:

@@ -34,6 +34,10 @@ class FSDPStrategy:
                  repeated_diffusion_steps: int = 4, cast_forward_inputs: bool = True, local_ops=None, **_):
         self.vlm, self.stage = vlm, stage
         self.device = torch.device("cuda", device_id) if isinstance(device_id, int) else torch.device(device_id)
+        if self.device.type == "cuda":
+            # the reference does this in scripts/train.py:80 (torch.cuda.set_device(device_id)); libmla_hip.so launches go to the
+            # current device's current stream, so the strategy pins it rather than trusting the caller
+            torch.cuda.set_device(self.device)
         self.epochs, self.max_steps = epochs, max_steps
         self.global_batch_size, self.per_device_batch_size = global_batch_size, per_device_batch_size
         self.learning_rate, self.weight_decay, self.max_grad_norm = learning_rate, weight_decay, max_grad_norm
@@ -116,6 +120,12 @@ class FSDPStrategy:
             self._micro += 1
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in loss_dict.items()}
 
+    def synchronize(self) -> None:
+        """Main stream waits for every outstanding side-stream all-gather (module forwards do this per unit on their own). Call it
+        before reading parameter storage directly on the main stream; ``save_checkpoint`` / ``full_state_dict_fp32`` do."""
+        if self.sharded is not None and self.sharded.on_gpu:
+            self.sharded.wait_all()
+
     # ------------------------------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, run_dir, global_step: int, epoch: int, train_loss: Optional[float] = None, only_trainable: bool = True):
         """training/strategies/fsdp.py:100-141: gather the full fp32 state dict (every rank takes part in the gathers), split it
@@ -125,15 +135,17 @@ class FSDPStrategy:
         from collections import OrderedDict
         from pathlib import Path
         assert self.sharded is not None, "save_checkpoint needs run_setup() first"
-        full = {k: v.cpu() for k, v in self.sharded.full_state_dict_fp32().items()}
+        # one unit at a time; only rank 0 keeps (host) copies -- FullStateDictConfig(offload_to_cpu=True, rank0_only=True)
+        full = {k: v for k, v in self.sharded.iter_full_state_fp32(to_cpu_on_rank0=True) if v is not None}
         mkeys = list(self.vlm.trainable_module_keys if only_trainable else self.vlm.all_module_keys)
         model_state_dicts = {mkey: OrderedDict() for mkey in mkeys}
-        for key, val in self.vlm.state_dict().items():          # module order; buffers (BatchNorm statistics) come from here
-            for mkey in mkeys:
-                if key.startswith(mkey + "."):
-                    model_state_dicts[mkey][key[len(mkey) + 1:]] = full[key] if key in full else val.detach().cpu().clone()
-        path = None
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if rank == 0:
+            for key, val in self.vlm.state_dict().items():      # module order; buffers (BatchNorm statistics) come from here
+                for mkey in mkeys:
+                    if key.startswith(mkey + "."):
+                        model_state_dicts[mkey][key[len(mkey) + 1:]] = full[key] if key in full else val.detach().cpu().clone()
+        path = None
         if rank == 0:
             ckpt_dir = Path(run_dir) / "checkpoints"
             ckpt_dir.mkdir(parents=True, exist_ok=True)

@@ -374,6 +374,7 @@ def test_post_training_step_through_fsdp(dev):
     assert float(mg[:E].abs().max()) > 0 and float(mg[E:].abs().max()) > 0        # both views of the packed weight delivered
     assert float(gm.image_gen_queries.main_grad.abs().max()) > 0                     # autograd-delivered small parameter
     assert float(gm.mae_alpha_head.weight.main_grad.abs().max()) == 0               # dead branch with the all-true ROI
+    strat.synchronize()                      # deferred AdamW: direct parameter reads wait for it explicitly
     assert not torch.equal(gm.intent_decoder.layers[0].multihead_attn.in_proj_weight.detach().float(), w0)
     assert not torch.equal(gm.image_gen_queries.detach().float(), q0)
     l2 = strat.train_step(b)

@@ -248,6 +248,7 @@ def test_pretrain_step_with_point_tower_through_fsdp(dev):
     l1 = strat.train_step(b)
     assert float(conv.weight.main_grad.abs().max()) > 0 and float(bn.weight.main_grad.abs().max()) > 0
     assert float(enc.raw_point_embed.net[0].weight.main_grad.abs().max()) > 0
+    strat.synchronize()                      # the AdamW update runs on the side stream; direct parameter reads wait for it
     assert not torch.equal(conv.weight.detach().float(), w0) and not torch.equal(bn.weight.detach().float(), g0)
     assert int(bn.num_batches_tracked) == 1
     l2 = strat.train_step(b)
