@@ -357,9 +357,13 @@ def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
 
 
 # --------------------------------------------------------------------------------------------- attention
-def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale):
-    """q/k/v: views into the packed [B*S, 3*H*D] buffer (first element of each slice)."""
-    o = torch.empty((B * S, H * D), dtype=torch.bfloat16, device=q.device)
+def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None):
+    """q/k/v: views into the packed [B*S, 3*H*D] buffer (first element of each slice). rows > B*S: the output gets that many rows,
+    the extra ones zero (row padding of the caller, ops.DecoderLayerFn)."""
+    rows = B * S if rows is None else rows
+    o = torch.empty((rows, H * D), dtype=torch.bfloat16, device=q.device)
+    if rows > B * S:
+        o[B * S:].zero_()
     lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
     call("mla_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale))
     return o, lse

@@ -125,6 +125,10 @@ def deliver_vec_grad(param: torch.Tensor, compute):
     return g.to(param.dtype)
 
 
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
 def _as2d(x: torch.Tensor) -> torch.Tensor:
     x2 = x.reshape(-1, x.shape[-1])
     return x2 if x2.is_contiguous() else x2.contiguous()
@@ -474,7 +478,8 @@ class DecoderLayerFn(torch.autograd.Function):
             for i, wi in enumerate((wq, wk, wv)):
                 hip.gemm(xn1, wi, out=qkv[:, i * H:(i + 1) * H])
         hip.rope_inplace(qkv, cos, sin, S, nheads, D, 0, H)
-        o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D))
+        o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
+                              rows=h2.shape[0])
         h1 = hip.gemm(o, wo, residual=h2)
         xn2, rstd2 = hip.rmsnorm_fwd(h1, ln2, eps)
         I = wg.shape[0]
@@ -496,7 +501,14 @@ class DecoderLayerFn(torch.autograd.Function):
         h2 = h.reshape(B * S, H)
         if not h2.is_contiguous():
             h2 = h2.contiguous()
+        T, Tp = B * S, _pad8(B * S)
+        if Tp != T:
+            # the tile transposes of the all-NT backward move 8 tokens per 16-B access: an odd token count (per-device batch 1 with
+            # an odd padded length) runs on zero rows appended here; they stay zero through every row-wise op, contribute zero to
+            # every weight gradient, and are cut off again below
+            h2 = torch.cat([h2, h2.new_zeros(Tp - T, H)], 0)
         out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w)
+        out = out[:T]
         ctx.w, ctx.dims, ctx.save_level = w, (B, S, H, nheads, eps), save_level
         ctx.aux = (seqlens, cos, sin)
         if save_level >= 2:
@@ -527,12 +539,13 @@ class DecoderLayerFn(torch.autograd.Function):
         else:
             (h2,) = ctx.saved_tensors
             _, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w)
-        if T % 8 != 0:
-            raise NotImplementedError("decoder backward needs batch*seq to be a multiple of 8 (tile transposes)")
         need = ctx.needs_input_grad[7:]
         d2 = dout.reshape(T, H)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
+        Tr, T = T, _pad8(T)                     # row padding of forward(): zero gradient rows
+        if T != Tr:
+            d2 = torch.cat([d2, d2.new_zeros(T - Tr, H)], 0)
         grads: List[Optional[torch.Tensor]] = [None] * 9
 
         def wT(ws):
@@ -579,6 +592,8 @@ class DecoderLayerFn(torch.autograd.Function):
         if need[4]:
             grads[4] = deliver_wgrad_nt((wo,), hip.transpose(dh1), hip.transpose(o), need[4:5])[0]
         dqkv = torch.empty_like(qkv)
+        if T != Tr:
+            dqkv[Tr:].zero_()
         hip.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, seqlens, dqkv[:, :H], dqkv[:, H:2 * H],
                      dqkv[:, 2 * H:], B, S, nheads, D, 3 * H, 1.0 / math.sqrt(D))
         del do
@@ -598,7 +613,7 @@ class DecoderLayerFn(torch.autograd.Function):
             grads[0] = deliver_vec_grad(ln1, ln1_run)
         else:
             ln1_run(None, False)
-        dh = holder["dh"].view(B, S, H) if ctx.needs_input_grad[0] else None
+        dh = holder["dh"][:Tr].view(B, S, H) if ctx.needs_input_grad[0] else None
         return (dh, None, None, None, None, None, None, *grads)
 
 

@@ -222,7 +222,9 @@ def test_swiglu_and_acts(dev):
 
 
 @pytest.mark.parametrize("B,S,H,lens", [(2, 64, 2, None), (2, 100, 2, None), (2, 100, 3, [70, 100]), (1, 548, 2, None),
-                                         (3, 200, 1, [1, 129, 64])])
+                                         (3, 200, 1, [1, 129, 64]),
+                                         # BASELINE configs[4] sequence length (32 K/V tiles, XCD decode with 16+ row blocks)
+                                         (1, 2048, 2, None), (2, 2048, 3, [2048, 1531])])
 def test_attention_fwd_bwd(dev, B, S, H, lens):
     from mla_amd import hip
     D = 128
@@ -238,7 +240,8 @@ def test_attention_fwd_bwd(dev, B, S, H, lens):
     vf = qkv[:, 2 * H * D:].float().view(B, S, H, D).transpose(1, 2).requires_grad_(True)
     ref = O.causal_attention(qf, kf, vf, seqlens.long() if seqlens is not None else None)
     ref2d = ref.transpose(1, 2).reshape(B * S, H * D)
-    assert fro_rel(o, ref2d) < 5e-3 and max_rel(o, ref2d) < 3e-2
+    e_o = fro_rel(o, ref2d)
+    assert e_o < 5e-3 and max_rel(o, ref2d) < 3e-2
     ref2d.backward(do.float())
     dqkv = torch.full_like(dq, float("nan"))
     hip.attn_bwd(q, k, v, o, do.to(dev), lse, sl_dev, dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:], B, S, H, D,
@@ -247,9 +250,9 @@ def test_attention_fwd_bwd(dev, B, S, H, lens):
     gk = kf.grad.transpose(1, 2).reshape(B * S, H * D)
     gv = vf.grad.transpose(1, 2).reshape(B * S, H * D)
     assert torch.isfinite(dqkv.float()).all()
-    assert fro_rel(dqkv[:, :H * D], gq) < 1e-2
-    assert fro_rel(dqkv[:, H * D:2 * H * D], gk) < 1e-2
-    assert fro_rel(dqkv[:, 2 * H * D:], gv) < 1e-2
+    e_q, e_k, e_v = fro_rel(dqkv[:, :H * D], gq), fro_rel(dqkv[:, H * D:2 * H * D], gk), fro_rel(dqkv[:, 2 * H * D:], gv)
+    print(f"attention B={B} S={S} H={H} lens={lens}: o {e_o:.2e} dq {e_q:.2e} dk {e_k:.2e} dv {e_v:.2e}")
+    assert e_q < 1e-2 and e_k < 1e-2 and e_v < 1e-2
     if seqlens is not None:  # pad rows: zero output and zero dq (flash/varlen semantics)
         for b_ in range(B):
             rows = slice(b_ * S + int(seqlens[b_]), (b_ + 1) * S)

@@ -101,10 +101,12 @@ def test_vision_tokenizer_tokens(dev, comp):
 
 
 @pytest.mark.parametrize("save_level", [2, 1, 0])
-@pytest.mark.parametrize("lens", [None, [100, 37]])
+@pytest.mark.parametrize("lens", [None, [100, 37], "odd"])
 def test_decoder_layer_fwd_bwd(dev, save_level, lens):
     from mla_amd import ops
     H, I, nh, B, S = 256, 512, 2, 2, 100
+    if lens == "odd":            # batch*seq NOT a multiple of 8 (per-device batch 1, odd padded length): zero-row padding path
+        B, S, lens = 1, 61, [57]
     names = ["input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
              "self_attn.o_proj.weight", "post_attention_layernorm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
              "mlp.down_proj.weight"]
@@ -124,10 +126,20 @@ def test_decoder_layer_fwd_bwd(dev, save_level, lens):
     out = ops.decoder_layer(xd, sl, cos.to(dev), sin.to(dev), nh, 1e-5, save_level, wd)
     out.backward(dy.to(dev))
     valid = torch.ones(B, S, dtype=torch.bool) if seqlens is None else torch.arange(S)[None] < seqlens[:, None]
+    assert out.shape == (B, S, H) and xd.grad.shape == (B, S, H)
     assert fro_rel(out[valid.to(dev)], ref[valid]) < 1e-2
     assert fro_rel(xd.grad[valid.to(dev)], xr.grad[valid]) < 2e-2
     for n, w in zip(names, wd):
         assert fro_rel(w.grad, pr[n].grad) < 2e-2, n
+
+
+# 1.5 x the values measured on MI355X in round 2 (printed by the test on every run): out 6.3e-3, dx 8.2e-3, ln1 1.04e-2,
+# q/k 1.10e-2, v 9.8e-3, o 9.7e-3, ln2 6.6e-3, gate 7.1e-3, up/down 6.7e-3 (weight gradients here are ROUNDED TO bf16 on delivery
+# because the test installs no fp32 main_grad; the training path writes them in fp32)
+DECODER_7B_BOUNDS = {"out": 9.4e-3, "dx": 1.23e-2, "input_layernorm.weight": 1.56e-2, "self_attn.q_proj.weight": 1.65e-2,
+                     "self_attn.k_proj.weight": 1.65e-2, "self_attn.v_proj.weight": 1.47e-2, "self_attn.o_proj.weight": 1.46e-2,
+                     "post_attention_layernorm.weight": 1.0e-2, "mlp.gate_proj.weight": 1.07e-2, "mlp.up_proj.weight": 1.0e-2,
+                     "mlp.down_proj.weight": 1.0e-2, "default": 1.65e-2}
 
 
 def test_decoder_layer_at_7b_dimensions(dev):
@@ -157,10 +169,17 @@ def test_decoder_layer_at_7b_dimensions(dev):
     out = ops.decoder_layer(xd, seqlens.to(dev).int(), cos.to(dev), sin.to(dev), nh, 1e-5, 1, wd)
     out.backward(dy.to(dev))
     valid = torch.arange(S)[None] < seqlens[:, None]
-    assert fro_rel(out[valid.to(dev)], ref[valid]) < 1e-2
-    assert fro_rel(xd.grad[valid.to(dev)], xr.grad[valid]) < 2e-2
+    # Measured on MI355X (round 2, printed below on every run): bf16 storage of every intermediate puts the end-to-end layer at
+    # 3-6e-3 Frobenius-relative against the fp32 oracle (one bf16 rounding = 2^-9 = 2e-3 per stored tensor, ~6 stored tensors on the
+    # longest path); north_star's 1e-3 is met per KERNEL on fp32-accumulate outputs (tests/test_kernels_gpu.py: GEMM fp32-out
+    # 2e-4). Bounds = 1.5 x the measured values.
+    errs = {"out": fro_rel(out[valid.to(dev)], ref[valid]), "dx": fro_rel(xd.grad[valid.to(dev)], xr.grad[valid])}
     for n, w in zip(names, wd):
-        assert fro_rel(w.grad, pr[n].grad) < 2e-2, n
+        errs[n] = fro_rel(w.grad, pr[n].grad)
+    print("decoder layer @7B dims, Frobenius-relative error vs fp32 oracle: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    bounds = DECODER_7B_BOUNDS
+    for k, v in errs.items():
+        assert v < bounds.get(k, bounds["default"]), (k, v)
 
 
 def _run_hip_e2e(dev, save_level=2):
@@ -227,7 +246,6 @@ def test_mla_e2e_against_oracle_flash_semantics(dev):
     pad = ~ref["mask"]
     assert fro_rel(last[~pad], ref["hidden_states"][-1][~pad]) < 3e-2
     assert float(out.hidden_states[5].float().cpu()[pad].abs().max()) < 1e3  # pad rows stay finite
-    assert torch.equal(ref["patch_indices"], torch.zeros(0) if False else ref["patch_indices"])
 
 
 def test_full_size_step_is_deterministic_and_consistent(dev):
@@ -264,6 +282,36 @@ def test_full_size_step_is_deterministic_and_consistent(dev):
     assert abs(coef - min(1.0, 1.0 / (norm + 1e-6))) < 1e-5
     del strat, mla
     torch.cuda.empty_cache()
+
+
+def test_contrastive_loss_no_valid_correspondence_branch(dev):
+    """models/mla/fuser/contrastive.py:206-207: when no point projects into the image (M = 0) the loss is the constant 0.0 with
+    requires_grad=True and NO gradient reaches the projection heads or the tapped hidden states; with >= 1 valid pair the same module
+    gives a positive loss and gradients. (The reference's train loop reaches this branch whenever valid_mask is all False, e.g. a
+    sample whose point cloud lies outside the camera frustum.)"""
+    from mla_amd.fuser import CoordinateAwareContrastiveLoss
+    torch.manual_seed(3)
+    mod = CoordinateAwareContrastiveLoss(feature_dim=128, projection_dim=64).to(dev).to(BF)
+    img = torch.randn(2, 16, 128, device=dev).to(BF).requires_grad_(True)
+    pc = torch.randn(2, 16, 128, device=dev).to(BF).requires_grad_(True)
+    idx = torch.randint(0, 4, (2, 16, 2), device=dev)
+    loss0 = mod(img, pc, idx, torch.zeros(2, 16, dtype=torch.bool, device=dev))
+    assert float(loss0) == 0.0 and loss0.requires_grad and loss0.grad_fn is None
+    loss0.backward()                                              # legal, and touches nothing
+    assert img.grad is None and pc.grad is None and all(p.grad is None for p in mod.parameters())
+    valid = torch.zeros(2, 16, dtype=torch.bool, device=dev)
+    valid[0, 3] = valid[1, 5] = valid[1, 9] = True
+    loss = mod(img, pc, idx, valid)
+    loss.backward()
+    assert float(loss) > 0 and img.grad is not None and float(img.grad.float().abs().max()) > 0
+    # oracle on the same weights / inputs (fp32)
+    sd = {k: v.detach().float().cpu() for k, v in mod.state_dict().items()}
+    heads = {f"{a}_{n}_{wb[0]}": sd[f"{m}_projection_head.{n}.{wb}"] for a, m in (("img", "image"), ("pc", "pointcloud"))
+             for n in (0, 2) for wb in ("weight", "bias")}
+    ref = O.coordinate_contrastive_loss(img.detach().float().cpu(), pc.detach().float().cpu(), idx.cpu(), valid.cpu(), heads, 0.07)
+    assert abs(float(loss) - float(ref)) < 3e-2 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    assert float(O.coordinate_contrastive_loss(img.detach().float().cpu(), pc.detach().float().cpu(), idx.cpu(),
+                                               torch.zeros(2, 16, dtype=torch.bool), heads, 0.07)) == 0.0
 
 
 def test_cropped_pixel_mask_is_rejected(dev):
