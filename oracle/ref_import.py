@@ -54,14 +54,11 @@ def setup():
     _done = True
 
 
-def build_reference_mla(cfg_kwargs: dict, token_size: int, use_pointcloud=True, use_contrastive=True, future_action_window_size=0,
-                        generation=None, use_tactile=False):
-    """Tiny reference MLA: real PrismaticVLM/MLA/LlamaForCausalLM classes, eager attention, fake tokenizer."""
+def build_reference_backbone(cfg_kwargs: dict):
+    """The reference's LLMBackbone interface around a tiny real LlamaForCausalLM (eager attention, fake tokenizer)."""
     setup()
     import torch
     from models.backbones.llm.base_llm import LLMBackbone
-    from models.mla import MLA
-    from models.vlm.prismatic import PrismaticVLM
     from transformers import LlamaConfig, LlamaForCausalLM
     from transformers.models.llama.modeling_llama import LlamaDecoderLayer
 
@@ -92,7 +89,16 @@ def build_reference_mla(cfg_kwargs: dict, token_size: int, use_pointcloud=True, 
         def forward(self, **kw):
             return self.llm(**kw)
 
-    bb = _Backbone()
+    return _Backbone()
+
+
+def build_reference_mla(cfg_kwargs: dict, token_size: int, use_pointcloud=True, use_contrastive=True, future_action_window_size=0,
+                        generation=None, use_tactile=False):
+    """Tiny reference MLA: real PrismaticVLM/MLA/LlamaForCausalLM classes, eager attention, fake tokenizer."""
+    setup()
+    from models.mla import MLA
+    from models.vlm.prismatic import PrismaticVLM
+    bb = build_reference_backbone(cfg_kwargs)
     gen = generation or dict(use_generation=False)
     if gen.get("use_generation"):
         # the shipped constructor reads self.tactile_dim (prismatic.py:267) which only exists when use_tactile=True (:234-236), so
