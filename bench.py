@@ -57,9 +57,18 @@ def build(device, save_level, tiny=False, use_pointcloud=True, generation=False,
     return mla
 
 
-def cpu_baseline(seconds_budget=24.0):
-    """Oracle decoder layer (fp32, true 7B dims) fwd+bwd on the host cores (bounded sample), extrapolated to samples/s.
-    Thread counts {64, all cores} are tried (oversubscribing a many-core host slows torch's CPU GEMMs down); the best is reported."""
+def cpu_baseline(seconds_budget=28.0):
+    """BASELINE.md section 3, timed on the GPU box's host cores in the same run as the GPU numbers, on a bounded sample:
+      (i)   one Llama-2-7B decoder layer fwd+bwd (fp32 oracle, true dims, 2 x 548 tokens), median of the iterations after the warm-up
+            one, for each thread count of the sweep {64, all cores} (oversubscribing a many-core host slows torch's CPU GEMMs down);
+      (ii)  encoders / heads forward at true dims on 2 samples: vision tokenizer 672^2 -> 4096-d tokens, point tokenizer 1024 points,
+            3-D projector, contrastive head on 256+256 tapped tokens, embedders + FinalLayer (timm 0.9.10 RmsNorm), lm_head + shifted CE;
+      (iii) the tiny end-to-end step of configs[0] (oracle mla_forward + backward) measured directly.
+    value = 8 samples / (17 536 tokens x 32 layers at (i)'s rate + 32 tiled encoder passes and the heads at (ii)'s rate): the 7B CPU
+    step is EXTRAPOLATED from per-layer timing (a real fp32 7B step needs ~110 GB and tens of minutes)."""
+    import statistics
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import mla_oracle, recipe
     from oracle import torch_oracle as O
     H, I, nh, S, Bs = 4096, 11008, 32, L_TEXT + S_FUSED + 3, 2
     g = torch.Generator().manual_seed(0)
@@ -71,8 +80,8 @@ def cpu_baseline(seconds_budget=24.0):
     x = torch.randn(Bs, S, H, generator=g).requires_grad_(True)
     cos, sin = O.rope_tables(S, H // nh)
     ncpu = os.cpu_count() or 1
-    best = None
-    t_end = time.time() + seconds_budget
+    t_start = time.time()
+    sweep = {}
     for nthreads in sorted({min(64, ncpu), ncpu}):
         torch.set_num_threads(nthreads)
         times = []
@@ -80,18 +89,68 @@ def cpu_baseline(seconds_budget=24.0):
             t0 = time.time()
             O.decoder_layer(x, p, cos, sin, nh, 1e-5).sum().backward()
             times.append(time.time() - t0)
-            if time.time() > t_end:
+            if time.time() - t_start > 0.55 * seconds_budget and len(times) >= 2:
                 break
-        t = min(times[1:]) if len(times) > 1 else times[0]
-        if best is None or t < best[0]:
-            best = (t, nthreads, len(times))
-        if time.time() > t_end:
-            break
-    t, nthreads, n = best
-    samples_per_s = (Bs * S / t) / 32 / (S * R_DIFF)
-    return {"value": samples_per_s, "unit": "samples/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle LlamaDecoderLayer fwd+bwd fp32 at 7B dims, {Bs}x{S} tokens, best of {n} runs ({t:.2f} s/iter on "
-                      f"{nthreads} threads of {ncpu} host CPUs), extrapolated x32 layers (encoders / heads / optimizer excluded)"}
+        sweep[nthreads] = (statistics.median(times[1:]) if len(times) > 1 else times[0], len(times))
+    nthreads = min(sweep, key=lambda k: sweep[k][0])
+    t_layer, n_it = sweep[nthreads]
+    torch.set_num_threads(nthreads)
+    del p, x
+
+    # (ii) encoders / heads at true dims (forward; the towers are frozen in SFT, the trainable heads are < 0.3 % of the step)
+    from tests_shapes import MLA_TINY_SHAPES
+    tower = {k: v for k, v in MLA_TINY_SHAPES.items() if k.startswith(("vlm.vision_tower_2d.", "vlm.vision_tower_3d."))}
+    sd = recipe.make_state_dict(tower)
+    rnd = lambda *sh: torch.randn(*sh, generator=g) * 0.02   # noqa: E731
+    proj2d = dict(w0=rnd(H, 1024), b0=rnd(H), w2=rnd(H, H), b2=rnd(H))
+    proj3d = dict(w0=rnd(H, 768), b0=rnd(H), w2=rnd(H, H), b2=rnd(H))
+    img = torch.randn(Bs, 4, 672, 672, generator=g)
+    img[:, 3] = 1.0
+    pc = torch.rand(Bs, 1024, 3, generator=g)
+    heads = {f"{a}_{n}_{w}": (rnd(H, H) if (n == 0 and w == "w") else rnd(256, H) if w == "w" else rnd(H if n == 0 else 256))
+             for a in ("img", "pc") for n in (0, 2) for w in ("w", "b")}
+    lm_w, hid = rnd(32064, H), torch.randn(Bs, S, H, generator=g)
+    labels = torch.randint(0, 32000, (Bs, S), generator=g)
+    parts = {}
+    with torch.no_grad():
+        def timed(name, fn):
+            t0 = time.time()
+            out = fn()
+            parts[name] = time.time() - t0
+            return out
+        vt = timed("vision_tokenizer", lambda: O.vision_tokenizer(img, mla_oracle.vision_weights(sd), proj2d))
+        ptok = timed("point_tokenizer", lambda: O.point_tokenizer(pc, mla_oracle.point_weights(sd), [torch.zeros(Bs, dtype=torch.long)] * 2))
+        timed("projector_3d", lambda: O.mlp_projector(ptok[0], proj3d["w0"], proj3d["b0"], proj3d["w2"], proj3d["b2"]))
+        timed("contrastive_head", lambda: O.coordinate_contrastive_loss(hid[:, 257:513], hid[:, 1:257], torch.zeros(Bs, 256, 2, dtype=torch.long),
+                                                                        torch.ones(Bs, 256, dtype=torch.bool), heads))
+        ew = [rnd(H, 7), rnd(H), rnd(H, H), rnd(H), rnd(H, 256), rnd(H), rnd(H, H), rnd(H), rnd(H, H), rnd(H), rnd(7, H), rnd(7)]
+        timed("embedders_final_layer", lambda: (O.mlp_gelu_tanh(torch.randn(Bs * R_DIFF, 7), *ew[0:4]),
+                                                O.timestep_embedder(torch.arange(Bs * R_DIFF), *ew[4:8]),
+                                                O.final_layer(hid[:, -1], torch.ones(H), *ew[8:12])))
+        timed("lm_head_ce", lambda: O.shifted_cross_entropy(torch.nn.functional.linear(hid, lm_w), labels))
+    del lm_w, hid, heads, proj2d, proj3d
+    # (iii) configs[0]: the tiny end-to-end step, forward + backward through the whole oracle
+    tiny_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in recipe.make_state_dict(MLA_TINY_SHAPES).items()}
+    batch, draws = recipe.make_batch(R=2)
+    t0 = time.time()
+    out = mla_oracle.mla_forward(tiny_sd, batch, draws, 9, 2, 1e-5, 2)
+    out["total_loss"].backward()
+    t_tiny = time.time() - t0
+
+    tok_step = B_PER_GPU * R_DIFF * S
+    per_seq = {"vision_tokenizer": parts["vision_tokenizer"] / Bs, "point_tokenizer": (parts["point_tokenizer"] + parts["projector_3d"]) / Bs,
+               "heads": (parts["contrastive_head"] + parts["embedders_final_layer"] + parts["lm_head_ce"]) / Bs}
+    t_enc = B_PER_GPU * R_DIFF * sum(per_seq.values())                      # the reference runs every encoder on the R-tiled batch
+    t_step = 32 * t_layer * tok_step / (Bs * S) + t_enc
+    return {"value": B_PER_GPU / t_step, "unit": "samples/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle (fp32 CPU restatement of the reference step) on {ncpu} host CPUs: LlamaDecoderLayer fwd+bwd at 7B dims on "
+                      f"{Bs}x{S} tokens = {t_layer:.2f} s (median of {max(n_it - 1, 1)} after warm-up, {nthreads} threads) x 32 layers x "
+                      f"{tok_step // (Bs * S)} token blocks + encoders/heads forward at true dims on {Bs} samples x {B_PER_GPU * R_DIFF // Bs} "
+                      f"({t_enc:.1f} s per step); 7B step EXTRAPOLATED to {t_step:.0f} s",
+            "threads_sweep_s_per_layer_iter": {str(k): round(v[0], 3) for k, v in sweep.items()},
+            "components_s_on_2_samples": {k: round(v, 3) for k, v in parts.items()},
+            "tiny_e2e_step_s": round(t_tiny, 3),
+            "tiny_e2e_note": "BASELINE.json configs[0] (9-layer 256-d Llama, 4 sequences): oracle forward + backward, measured directly"}
 
 
 def main():
