@@ -249,6 +249,15 @@ def main():
             if os.path.exists(tpath) and args.config == 1 and not args.tiny:
                 with open(tpath) as fh:
                     traffic = round(json.load(fh)["hbm_bytes_per_launch"])
+            if os.environ.get("MLA_BENCH_GEMM_SHAPES"):
+                by = {}
+                for t, fl, key in big:
+                    e = by.setdefault(key, [0, 0.0, fl])
+                    e[0] += 1
+                    e[1] += t
+                for key, (n, t, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                    print(f"# gemm (a_mode, b_mode, M, N, K)={key}: {n // args.steps}/step, {t / n:.4f} ms avg, {fl * n / t / 1e9:.0f} TFLOP/s, "
+                          f"{t / args.steps:.1f} ms/step", file=sys.stderr)
             abytes = sum(2.0 * (k[2] * k[4] + k[3] * k[4]) + 2.0 * k[2] * k[3] for _, _, k in big) / len(big)
             roof = {"bound": "mfma", "kernel": "gemm256_kernel<0,0> (+ gemm128_kernel for small shapes): bf16 MFMA GEMM launches >= 0.1 TFLOP",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),

@@ -19,9 +19,6 @@ namespace {
 
 constexpr int D = 128;
 constexpr int TROWS = 64;
-#ifndef MLA_ATTN_ABL
-#define MLA_ATTN_ABL 0      // timing experiments only: 1 = no V^T fragment reads, 2 = no softmax arithmetic, 3 = no K fragment reads
-#endif
 #ifndef MLA_ATTN_RB
 #define MLA_ATTN_RB 2
 #endif
@@ -35,12 +32,12 @@ constexpr float LN2 = 0.6931471805599453f;
 template <int SW>
 __device__ __forceinline__ int swz(int row, int c) { return SW == 0 ? (c ^ (row & 15)) : (c ^ ((row & 7) << 1)); }
 
-template <int SW>
+template <int SW, int NW = 4>
 __device__ __forceinline__ void stage_rows64(const bf16_t* __restrict__ base, long long ld, int row0, int row_lim,
                                              char* tile, int wave, int lane) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int instr = wave * 4 + it;
+  for (int it = 0; it < 16 / NW; ++it) {
+    const int instr = wave * (16 / NW) + it;
     const int p = instr * 64 + lane;
     const int row = p >> 4, cp = p & 15;
     const int c = swz<SW>(row, cp);
@@ -137,12 +134,98 @@ struct AttnArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-// RB = 16-row query blocks per wave (block = 4 waves x RB x 16 query rows). RB = 2 reads every K / V^T fragment once for two
+// RB = 16-row query groups per wave (block = 4 waves x RB x 16 query rows). RB = 2 reads every K / V^T fragment once for two
 // MFMAs: LDS fragment reads per MFMA drop from 1.5 to 0.75 (the 64-row version is LDS-read bound at ~0.23 PFLOP/s).
+//
+// Causal / padding work skipping (round 2): a 128-row block against 64-key tiles used to compute every (wave, tile) pair up to the
+// block's LAST row -- at S = 548 only 55 % of the issued MFMA work was on or below the diagonal and inside the sequence. Now
+//   * the 8 row groups of a block are dealt to the waves in PAIRS (wave w owns groups w and 7 - w), so the four waves of a block
+//     have the same amount of causal work, and
+//   * every (wave, group, key tile) is tested wave-uniformly: a group whose rows all lie above the tile (fully masked), or at /
+//     beyond min(S, seqlen) (padding), issues no MFMA, no softmax and no fragment reads for that tile (MASK template below).
+// Granularity of the remaining waste: 16 rows x 64 keys on the diagonal.
 template <int RB>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+__device__ __forceinline__ int row_group(int wave, int rb) { return RB == 2 ? (rb == 0 ? wave : 7 - wave) : wave; }
+#ifndef MLA_ATTN_FWD_NW
+#define MLA_ATTN_FWD_NW 4
+#endif
+constexpr int FWD_NW = MLA_ATTN_FWD_NW;          // waves per forward block: 4 (x RB = 2 row groups) or 8 (x RB = 1)
+constexpr int FWD_RB = FWD_NW == 8 ? 1 : MLA_ATTN_RB;
+
+template <int RB, int MASK>
+__device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], f32x4_t (&ot)[RB][8],
+                                         float (&m)[RB], float (&l)[RB], const int (&myq)[RB], const int (&grow0)[RB], int kt,
+                                         int lane, float sc2) {
+  const int g = lane >> 4;
+  f32x4_t st[RB][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) st[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t kf = frag_rows<0>(kt_, f, ks, lane);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        if ((MASK >> rb) & 1) st[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][f], 0, 0, 0);
+    }
+  }
+  bf16x8_t pf[RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    if (!((MASK >> rb) & 1)) continue;
+    float mx = -INFINITY;
+    if (kt * 64 + 63 > grow0[rb]) {   // wave-uniform: only tiles that touch the diagonal need the causal mask
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[rb][f][r]);      // max of the RAW scores: the scale is positive
+    mx = group_max(mx) * sc2;
+    const float mnew = fmaxf(m[rb], mx);
+    const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+    const float alpha = __builtin_amdgcn_exp2f(m[rb] - msafe);
+    float rs = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(st[rb][f][r], sc2, -msafe));   // scale folded into the exponent's fma
+        st[rb][f][r] = e;
+        rs += e;
+      }
+    rs = group_sum(rs);
+    l[rb] = l[rb] * alpha + rs;
+    m[rb] = mnew;
+    // lazy rescale: once the running maximum has settled (most tiles of a causal row block) alpha == 1 in every lane of the
+    // wave and the 64 output accumulators need no multiply -- wave-uniform test, skips 32 packed multiplies per row block
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ot[rb][i] *= alpha;
+    }
+    pf[rb][0] = pack_frag(st[rb][0], st[rb][1]);
+    pf[rb][1] = pack_frag(st[rb][2], st[rb][3]);
+  }
+#pragma unroll
+  for (int fd = 0; fd < 8; ++fd)
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const bf16x8_t vf = frag_tr<1>(vt_, fd, ks2, lane);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        if ((MASK >> rb) & 1) ot[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[rb][ks2], ot[rb][fd], 0, 0, 0);
+    }
+}
+
+template <int RB, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BQ = 64 * RB;
+  constexpr int BQ = 16 * NW * RB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nqb = (p.S + BQ - 1) / BQ;
@@ -150,11 +233,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   if (!decode_block(nqb, p.H, p.B, qb, h, b)) return;
   qb = nqb - 1 - qb;                               // heaviest (most key tiles) first
   const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
+  const int row_lim = seqlen < p.S ? seqlen : p.S;  // rows at / beyond it are padding: zero output, no work
   const int q0 = qb * BQ;
   const int g = lane >> 4;
-  int myq[RB];
+  int myq[RB], grow0[RB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) myq[rb] = q0 + (wave * RB + rb) * 16 + (lane & 15);
+  for (int rb = 0; rb < RB; ++rb) {
+    grow0[rb] = q0 + row_group<RB>(wave, rb) * 16;       // wave-uniform first row of the group
+    myq[rb] = grow0[rb] + (lane & 15);
+  }
   const bf16_t* qb_ = p.q + (long long)b * p.S * p.ld + h * D;
   const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
   const bf16_t* vb_ = p.v + (long long)b * p.S * p.ld + h * D;
@@ -163,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   int nkt = (q0 + BQ + 63) / 64;          // key tiles up to the last query row of the block (causal)
   const int kt_lim = (seqlen + 63) / 64;
   if (nkt > kt_lim) nkt = kt_lim;
-  if (nkt <= 0) {  // whole block is padding
+  if (nkt <= 0 || q0 >= row_lim) {  // whole block is padding
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
       if (myq[rb] < p.S) {
@@ -191,8 +278,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   unsigned koff[4], voff[4];
   stage_offs<0>(p.ld, wave, lane, koff);
   stage_offs<1>(p.ld, wave, lane, voff);
-  stage_rows64<0>(kb_, p.ld, 0, p.S, smem, wave, lane);
-  stage_rows64<1>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
+  stage_rows64<0, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
+  stage_rows64<1, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -204,83 +291,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         stage_fast(kb_ + (long long)(kt + 1) * 64 * p.ld, koff, nx, wave);
         stage_fast(vb_ + (long long)(kt + 1) * 64 * p.ld, voff, nx + TILE_BYTES, wave);
       } else {
-        stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
-        stage_rows64<1>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+        stage_rows64<0, NW>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
+        stage_rows64<1, NW>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
       }
     }
-    f32x4_t st[RB][4];
+    // which of this wave's row groups have any unmasked, non-padding (row, key) pair in this key tile (wave-uniform)
+    int mask = 0;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) st[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-#if MLA_ATTN_ABL == 3
-        const bf16x8_t kf = qf[0][ks];
-#else
-        const bf16x8_t kf = frag_rows<0>(kt_, f, ks, lane);
-#endif
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) st[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][f], 0, 0, 0);
-      }
+    for (int rb = 0; rb < RB; ++rb)
+      if (grow0[rb] < row_lim && kt * 64 <= grow0[rb] + 15) mask |= 1 << rb;
+    if (RB == 2) {
+      if (mask == 3) fwd_tile<RB, 3>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
+      else if (mask == 2) fwd_tile<RB, 2>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
+      else if (mask == 1) fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
+    } else if (mask) {
+      fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
     }
-    bf16x8_t pf[RB][2];
-#if MLA_ATTN_ABL == 2
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) { pf[rb][0] = pack_frag(st[rb][0], st[rb][1]); pf[rb][1] = pack_frag(st[rb][2], st[rb][3]); }
-#else
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      float mx = -INFINITY;
-      if (kt * 64 + 63 > q0 + (wave * RB + rb) * 16) {   // wave-uniform: only tiles that touch the diagonal need the causal mask
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[rb][f][r]);      // max of the RAW scores: the scale is positive
-      mx = group_max(mx) * sc2;
-      const float mnew = fmaxf(m[rb], mx);
-      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = __builtin_amdgcn_exp2f(m[rb] - msafe);
-      float rs = 0.f;
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(st[rb][f][r], sc2, -msafe));   // scale folded into the exponent's fma
-          st[rb][f][r] = e;
-          rs += e;
-        }
-      rs = group_sum(rs);
-      l[rb] = l[rb] * alpha + rs;
-      m[rb] = mnew;
-      // lazy rescale: once the running maximum has settled (most tiles of a causal row block) alpha == 1 in every lane of the
-      // wave and the 64 output accumulators need no multiply -- wave-uniform test, skips 32 packed multiplies per row block
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ot[rb][i] *= alpha;
-      }
-      pf[rb][0] = pack_frag(st[rb][0], st[rb][1]);
-      pf[rb][1] = pack_frag(st[rb][2], st[rb][3]);
-    }
-#endif
-#pragma unroll
-    for (int fd = 0; fd < 8; ++fd)
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-#if MLA_ATTN_ABL == 1
-        const bf16x8_t vf = qf[0][ks2];
-#else
-        const bf16x8_t vf = frag_tr<1>(vt_, fd, ks2, lane);
-#endif
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) ot[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[rb][ks2], ot[rb][fd], 0, 0, 0);
-      }
   }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -324,6 +350,65 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+// Same row-group pairing and per-(wave, group, tile) skipping as the forward kernel.
+template <int RB, int MASK>
+__device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], const bf16x8_t (&dof)[RB][4],
+                                        f32x4_t (&dqt)[RB][8], const float (&lse2)[RB], const float (&dlt)[RB],
+                                        const int (&myq)[RB], const int (&grow0)[RB], int kt, int lane, float sc2) {
+  const int g = lane >> 4;
+  bf16x8_t ds[RB][2];
+  {
+    f32x4_t st[RB][4], dp[RB][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        st[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t kf = frag_rows<0>(kt_, f, ks, lane), vf = frag_rows<0>(vt_, f, ks, lane);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          if ((MASK >> rb) & 1) {
+            st[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][f], 0, 0, 0);
+            dp[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[rb][ks], dp[rb][f], 0, 0, 0);
+          }
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      if (!((MASK >> rb) & 1)) continue;
+      if (kt * 64 + 63 > grow0[rb]) {   // diagonal tile: causal mask (exp2(-inf) = 0)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(st[rb][f][r] * sc2 - lse2[rb]);
+          st[rb][f][r] = pr * (dp[rb][f][r] - dlt[rb]);
+        }
+      ds[rb][0] = pack_frag(st[rb][0], st[rb][1]);
+      ds[rb][1] = pack_frag(st[rb][2], st[rb][3]);
+    }
+  }
+#pragma unroll
+  for (int fd = 0; fd < 8; ++fd)
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const bf16x8_t ktf = frag_tr<0>(kt_, fd, ks2, lane);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        if ((MASK >> rb) & 1) dqt[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, ds[rb][ks2], dqt[rb][fd], 0, 0, 0);
+    }
+}
+
 template <int RB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -335,11 +420,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   if (!decode_block(nqb, p.H, p.B, qb, h, b)) return;
   qb = nqb - 1 - qb;                               // heaviest (most key tiles) first
   const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
+  const int row_lim = seqlen < p.S ? seqlen : p.S;
   const int q0 = qb * BQ;
   const int g = lane >> 4;
-  int myq[RB];
+  int myq[RB], grow0[RB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) myq[rb] = q0 + (wave * RB + rb) * 16 + (lane & 15);
+  for (int rb = 0; rb < RB; ++rb) {
+    grow0[rb] = q0 + row_group<RB>(wave, rb) * 16;
+    myq[rb] = grow0[rb] + (lane & 15);
+  }
   const bf16_t* qb_ = p.q + (long long)b * p.S * p.ld + h * D;
   const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
   const bf16_t* vb_ = p.v + (long long)b * p.S * p.ld + h * D;
@@ -347,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   int nkt = (q0 + BQ + 63) / 64;
   const int kt_lim = (seqlen + 63) / 64;
   if (nkt > kt_lim) nkt = kt_lim;
-  if (nkt <= 0) {
+  if (nkt <= 0 || q0 >= row_lim) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
       if (myq[rb] < p.S) {
@@ -386,54 +475,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
       stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);       // (register budget: no precomputed offsets here)
       stage_rows64<0>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
     }
-    bf16x8_t ds[RB][2];
-    {
-      f32x4_t st[RB][4], dp[RB][4];
+    int mask = 0;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-          st[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          dp[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8_t kf = frag_rows<0>(kt_, f, ks, lane), vf = frag_rows<0>(vt_, f, ks, lane);
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) {
-            st[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][f], 0, 0, 0);
-            dp[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[rb][ks], dp[rb][f], 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        if (kt * 64 + 63 > q0 + (wave * RB + rb) * 16) {   // diagonal tile: causal mask (exp2(-inf) = 0)
-#pragma unroll
-          for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
-        }
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(st[rb][f][r] * sc2 - lse2[rb]);
-            st[rb][f][r] = pr * (dp[rb][f][r] - dlt[rb]);
-          }
-        ds[rb][0] = pack_frag(st[rb][0], st[rb][1]);
-        ds[rb][1] = pack_frag(st[rb][2], st[rb][3]);
-      }
+    for (int rb = 0; rb < RB; ++rb)
+      if (grow0[rb] < row_lim && kt * 64 <= grow0[rb] + 15) mask |= 1 << rb;
+    if (RB == 2) {
+      if (mask == 3) dq_tile<RB, 3>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
+      else if (mask == 2) dq_tile<RB, 2>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
+      else if (mask == 1) dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
+    } else if (mask) {
+      dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
     }
-#pragma unroll
-    for (int fd = 0; fd < 8; ++fd)
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        const bf16x8_t ktf = frag_tr<0>(kt_, fd, ks2, lane);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) dqt[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, ds[rb][ks2], dqt[rb][fd], 0, 0, 0);
-      }
   }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -583,8 +635,9 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
   p.seqlens = seqlens; p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
   if (check_common(p, "mla_attn_fwd")) return -1;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<ATTN_RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); attr = true; }
-  hipLaunchKernelGGL(attn_fwd_kernel<ATTN_RB>, dim3(grid_blocks((S + 64 * ATTN_RB - 1) / (64 * ATTN_RB), H, B)), dim3(256), 4 * TILE_BYTES, stream, p);
+  constexpr int BQ = 16 * FWD_NW * FWD_RB;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_RB, FWD_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); attr = true; }
+  hipLaunchKernelGGL((attn_fwd_kernel<FWD_RB, FWD_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * FWD_NW), 4 * TILE_BYTES, stream, p);
   MLA_LAUNCH_CHECK();
 }
 

@@ -281,10 +281,116 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     return;
   }
   const bool vec_ok = ((p.ldc & 3) == 0) && (p.R == nullptr || (p.ldr & 3) == 0);
+  // ---- fast epilogue: the tile goes through LDS (free now) and leaves as WHOLE ROWS -- 16 B per lane, 512 B / 1 KiB contiguous
+  // per half-wave / wave. The direct path below stores 8 B (bf16) per lane to 16 different rows per instruction (32-B pieces of 16
+  // cache lines): measured 8-13 us per tile round, i.e. 10-20 % of a K = 4096 launch (tools/exp_epilogue.py).
+  //   bf16 output without bias / residual: one pass, bf16 image [256][256] (row pitch 512 B, 16-B chunks XOR-swizzled by row & 31)
+  //   fp32 output, or bias / residual (added in fp32 before the single rounding): two passes of 128 rows, fp32 image
+  //   [128][256] (row pitch 1 KiB, chunks swizzled by row & 63)
+  const bool fast = (p.N & 7) == 0 && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
+                    (p.R == nullptr || ((p.ldr & 7) == 0 && (((uintptr_t)p.R) & 15) == 0)) &&
+                    (p.bias == nullptr || (((uintptr_t)p.bias) & 15) == 0);
+  if (fast) {
+    __syncthreads();     // every wave is done with the operand image (and has drained its own LDS-DMA loads above)
+    if (!p.out_fp32 && p.R == nullptr && p.bias == nullptr) {
+#pragma unroll
+      for (int ri = 0; ri < 8; ++ri) {
+        const int ml = (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const int nl = (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
+          u32x2_t o;
+          o[0] = pack2bf(acc[ri][ci][0] * p.alpha, acc[ri][ci][1] * p.alpha);
+          o[1] = pack2bf(acc[ri][ci][2] * p.alpha, acc[ri][ci][3] * p.alpha);
+          *(u32x2_t*)(smem + ml * 512 + ((((nl >> 3) ^ (ml & 31))) << 4) + ((nl >> 2) & 1) * 8) = o;
+        }
+      }
+      __syncthreads();
+      const int ch = lane & 31;
+      const int n = n0 + ch * 8;
+      if (n < p.N) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int row = wave * 32 + it * 2 + (lane >> 5);
+          const int m = m0 + row;
+          if (m < p.M)
+            *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = *(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4));
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if (hf) __syncthreads();                     // the readers of the first half are done
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int ri = hf * 4 + r4;
+        const int ml = wr * 64 + r4 * 16 + li;     // row inside this half
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+          const int nl = (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
+          *(f32x4_t*)(smem + ml * 1024 + (((nl >> 2) ^ (ml & 63)) << 4)) = acc[ri][ci] * p.alpha;
+        }
+      }
+      __syncthreads();
+      if (p.out_fp32) {
+        const int n = n0 + lane * 4;
+        if (n < p.N) {
+#pragma unroll
+          for (int it = 0; it < 16; ++it) {
+            const int row = wave * 16 + it;
+            const int m = m0 + hf * 128 + row;
+            if (m < p.M) {
+              f32x4_t o = *(const f32x4_t*)(smem + row * 1024 + ((lane ^ (row & 63)) << 4));
+              if (p.bias) {
+                const u32x2_t bb = *(const u32x2_t*)(p.bias + n);
+                o[0] += bflo(bb[0]); o[1] += bfhi(bb[0]); o[2] += bflo(bb[1]); o[3] += bfhi(bb[1]);
+              }
+              if (p.R) {
+                const u32x2_t rr = *(const u32x2_t*)(p.R + (size_t)m * p.ldr + n);
+                o[0] += bflo(rr[0]); o[1] += bfhi(rr[0]); o[2] += bflo(rr[1]); o[3] += bfhi(rr[1]);
+              }
+              float* c = (float*)p.C + (size_t)m * p.ldc + n;
+              if (p.accumulate) o += *(const f32x4_t*)c;
+              *(f32x4_t*)c = o;
+            }
+          }
+        }
+      } else {
+        const int ch = lane & 31;
+        const int n = n0 + ch * 8;
+        if (n < p.N) {
+          float bv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+          if (p.bias) unpack8(*(const u32x4_t*)(p.bias + n), bv);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int row = wave * 16 + it * 2 + (lane >> 5);
+            const int m = m0 + hf * 128 + row;
+            if (m < p.M) {
+              const f32x4_t a = *(const f32x4_t*)(smem + row * 1024 + (((2 * ch) ^ (row & 63)) << 4));
+              const f32x4_t b = *(const f32x4_t*)(smem + row * 1024 + (((2 * ch + 1) ^ (row & 63)) << 4));
+              float v[8] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3], b[0] + bv[4], b[1] + bv[5], b[2] + bv[6], b[3] + bv[7]};
+              if (p.R) {
+                float rv[8];
+                unpack8(*(const u32x4_t*)(p.R + (size_t)m * p.ldr + n), rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rv[j];
+              }
+              *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8(v);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ri = 0; ri < 8; ++ri) {
     const int m = m0 + (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
     if (m >= p.M) continue;
+
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
       const int n = n0 + (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
