@@ -49,18 +49,19 @@ __device__ __forceinline__ void stage_rows64(const bf16_t* __restrict__ base, lo
 
 // Same staging with the per-lane source pointers of tile 0 precomputed (no row clamp): for tiles that lie fully inside the
 // sequence the address is just ptr + tile * 64 * ld -- keeps ~40 integer VALU instructions per tile out of the main loops.
-template <int SW>
+template <int SW, int NW = 4>
 __device__ __forceinline__ void stage_offs(long long ld, int wave, int lane, unsigned* off) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int p = (wave * 4 + it) * 64 + lane;
+  for (int it = 0; it < 16 / NW; ++it) {
+    const int p = (wave * (16 / NW) + it) * 64 + lane;
     const int row = p >> 4, cp = p & 15;
     off[it] = (unsigned)row * (unsigned)ld + (unsigned)(swz<SW>(row, cp) * 8);     // elements; < 64 * ld
   }
 }
+template <int NW = 4>
 __device__ __forceinline__ void stage_fast(const bf16_t* __restrict__ tile_base, const unsigned* off, char* tile, int wave) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) glds16(tile_base + off[it], tile + (wave * 4 + it) * 1024);
+  for (int it = 0; it < 16 / NW; ++it) glds16(tile_base + off[it], tile + (wave * (16 / NW) + it) * 1024);
 }
 
 // A/B fragment of 16 tile rows (rb) x 32 d (ks): lane (i = lane&15 -> row, g = lane>>4 -> d group of 8)
@@ -146,11 +147,22 @@ struct AttnArgs {
 // Granularity of the remaining waste: 16 rows x 64 keys on the diagonal.
 template <int RB>
 __device__ __forceinline__ int row_group(int wave, int rb) { return RB == 2 ? (rb == 0 ? wave : 7 - wave) : wave; }
+// Forward / dQ block shape: 8 waves x ONE 16-row group (126 VGPRs -> 4 waves per SIMD, 16 per CU) instead of 4 waves x 2 groups
+// (220-256 VGPRs -> 2 per SIMD). The cycle stamps of tools/exp_attn_trace.py show every phase of a key tile (QK^T, softmax, PV)
+// taking ~3x its issue time with 2 waves per SIMD plus 25 % in vmcnt / barrier waits: the loop is latency-bound, and twice the
+// resident waves hide more of it than the halved fragment reads per MFMA of the 2-group shape saved (S = 548: 230 -> 196 us,
+// S = 2048: 563 -> 492 us). The dQ kernel keeps 4 waves x 2 groups: its 8-wave form needs 156 VGPRs, and forced to 128 it spills
+// (measured 270 -> 310 us at S = 548). -DMLA_ATTN_FWD_NW=4 / -DMLA_ATTN_DQ_NW=8 select the other shapes for A/B runs.
 #ifndef MLA_ATTN_FWD_NW
-#define MLA_ATTN_FWD_NW 4
+#define MLA_ATTN_FWD_NW 8
+#endif
+#ifndef MLA_ATTN_DQ_NW
+#define MLA_ATTN_DQ_NW 4
 #endif
 constexpr int FWD_NW = MLA_ATTN_FWD_NW;          // waves per forward block: 4 (x RB = 2 row groups) or 8 (x RB = 1)
 constexpr int FWD_RB = FWD_NW == 8 ? 1 : MLA_ATTN_RB;
+constexpr int DQ_NW = MLA_ATTN_DQ_NW;
+constexpr int DQ_RB = DQ_NW == 8 ? 1 : MLA_ATTN_RB;
 
 template <int RB, int MASK>
 __device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], f32x4_t (&ot)[RB][8],
@@ -223,7 +235,7 @@ __device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const
 }
 
 template <int RB, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(AttnArgs p) {   // 2nd argument = waves per SIMD
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BQ = 16 * NW * RB;
   const int lane = threadIdx.x & 63;
@@ -276,8 +288,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs p) {
   const float sc2 = p.scale * LOG2E;
 
   unsigned koff[4], voff[4];
-  stage_offs<0>(p.ld, wave, lane, koff);
-  stage_offs<1>(p.ld, wave, lane, voff);
+  stage_offs<0, NW>(p.ld, wave, lane, koff);
+  stage_offs<1, NW>(p.ld, wave, lane, voff);
   stage_rows64<0, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
   stage_rows64<1, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -288,8 +300,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnArgs p) {
     if (kt + 1 < nkt) {
       char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
       if ((kt + 2) * 64 <= p.S) {
-        stage_fast(kb_ + (long long)(kt + 1) * 64 * p.ld, koff, nx, wave);
-        stage_fast(vb_ + (long long)(kt + 1) * 64 * p.ld, voff, nx + TILE_BYTES, wave);
+        stage_fast<NW>(kb_ + (long long)(kt + 1) * 64 * p.ld, koff, nx, wave);
+        stage_fast<NW>(vb_ + (long long)(kt + 1) * 64 * p.ld, voff, nx + TILE_BYTES, wave);
       } else {
         stage_rows64<0, NW>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
         stage_rows64<1, NW>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
@@ -409,10 +421,10 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
     }
 }
 
-template <int RB>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+template <int RB, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(AttnArgs p) {   // 2nd argument = waves per SIMD
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BQ = 64 * RB;
+  constexpr int BQ = 16 * NW * RB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nqb = (p.S + BQ - 1) / BQ;
@@ -463,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   }
   const float sc2 = p.scale * LOG2E;
 
-  stage_rows64<0>(kb_, p.ld, 0, p.S, smem, wave, lane);
-  stage_rows64<0>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
+  stage_rows64<0, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
+  stage_rows64<0, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -472,8 +484,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const char* vt_ = kt_ + TILE_BYTES;
     if (kt + 1 < nkt) {
       char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-      stage_rows64<0>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);       // (register budget: no precomputed offsets here)
-      stage_rows64<0>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+      stage_rows64<0, NW>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);       // (register budget: no precomputed offsets here)
+      stage_rows64<0, NW>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
     }
     int mask = 0;
 #pragma unroll
@@ -656,14 +668,15 @@ extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const v
   if (check_common(p, "mla_attn_bwd")) return -1;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<ATTN_RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_RB, DQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
     attr = true;
   }
   const long long items = (long long)B * S * H * 16;
   long long nb = (items + 255) / 256; if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((int)nb), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta, B, S, H, ld_o);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<ATTN_RB>, dim3(grid_blocks((S + 64 * ATTN_RB - 1) / (64 * ATTN_RB), H, B)), dim3(256), 4 * TILE_BYTES, stream, p);
+  constexpr int BQ = 16 * DQ_NW * DQ_RB;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DQ_RB, DQ_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * DQ_NW), 4 * TILE_BYTES, stream, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
   MLA_LAUNCH_CHECK();
 }

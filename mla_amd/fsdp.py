@@ -281,7 +281,9 @@ class ShardedModel:
         region = u.flat16[:u.n_train]
         shard = region[self.rank * u.shard_train:(self.rank + 1) * u.shard_train]
         if dist.get_backend(self.pg) == "nccl":
-            dist.all_gather_into_tensor(region, shard.clone(), group=self.pg)   # separate input: no reliance on in-place support
+            # in place: the input is this rank's slice of the output (NCCL/RCCL in-place all-gather: sendbuff == recvbuff +
+            # rank * count) -- no per-unit shard copy / allocation on the side stream every step
+            dist.all_gather_into_tensor(region, shard, group=self.pg)
         else:
             parts = [torch.empty_like(shard) for _ in range(self.world)]
             dist.all_gather(parts, shard.clone(), group=self.pg)
