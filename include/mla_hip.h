@@ -95,6 +95,9 @@ int mla_transpose_bf16(const void* src, void* dst, long long R, int C, long long
 int mla_rmsnorm_apply_t(const void* x, const void* w, const float* rstd, void* dst, long long rows, int H, long long ldt,
                         mla_stream_t stream);
 int mla_swiglu_fwd_t(const void* gu, void* dst, long long rows, int I, long long ldt, mla_stream_t stream);
+/* SwiGLU forward (LlamaMLP.forward modeling_llama.py:240) writing the product in both layouts in one pass: act [rows, I] for the
+ * down projection and actT [I, ldt] kept for the backward's wgrad GEMM (instead of recomputing it from gu there) */
+int mla_swiglu_fwd_dual(const void* gu, void* act, void* actT, long long rows, int I, long long ldt, mla_stream_t stream);
 /* SwiGLU backward writing both layouts in one pass: dgu [rows, 2I] for the dgrad GEMM and dguT [2I, ldt] for the wgrad GEMM
  * (modeling_llama.py:241 LlamaMLP backward; saves re-reading the 2I-wide gradient for a separate transpose) */
 int mla_swiglu_bwd_t(const void* dact, const void* gu, void* dgu, void* dguT, long long rows, int I, long long ldt, mla_stream_t stream);

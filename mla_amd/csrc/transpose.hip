@@ -128,6 +128,46 @@ __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const bf16_t* __restr
   }
 }
 
+// SwiGLU forward writing BOTH layouts in one pass: act[t][i] (row-major, feeds the down-projection GEMM) and actT[i][t]
+// (token-contiguous, the wgrad operand of the backward). The backward used to recompute the product from gu straight into the
+// transposed layout (swiglu_fwd_t: read 2 I-wide streams, write 1): forward + recompute = 6 I-wide passes per layer, this = 4.
+__global__ __launch_bounds__(256) void swiglu_fwd_dual_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
+                                                              bf16_t* __restrict__ actT, long long R, int I, long long ldt) {
+  __shared__ unsigned short t[64][66];
+  const long long r0 = (long long)blockIdx.y * 64;
+  const int c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rr = (tid >> 3) + it * 32, cc = (tid & 7) * 8;
+    const long long r = r0 + rr;
+    const int c = c0 + cc;
+    if (r < R && c < I) {
+      float g[8], u[8], o[8];
+      unpack8(*(const u32x4_t*)(gu + r * 2 * I + c), g);
+      unpack8(*(const u32x4_t*)(gu + r * 2 * I + I + c), u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float sg = 1.f / (1.f + __expf(-g[j])); o[j] = (g[j] * sg) * u[j]; }   // = swiglu_fwd_kernel
+      const u32x4_t pk = pack8(o);
+      *(u32x4_t*)(act + r * I + c) = pk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[cc + 2 * j][rr] = (unsigned short)(pk[j] & 0xffffu);
+        t[cc + 2 * j + 1][rr] = (unsigned short)(pk[j] >> 16);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int cc = (tid >> 3) + it * 32, rr = (tid & 7) * 8;
+    if (c0 + cc < I && r0 + rr < R) {
+      const uint32_t* q = (const uint32_t*)&t[cc][rr];
+      *(u32x4_t*)(actT + (long long)(c0 + cc) * ldt + r0 + rr) = u32x4_t{q[0], q[1], q[2], q[3]};
+    }
+  }
+}
+
 template <typename OP>
 int launch_tt(const void* src, void* dst, long long R, int C, long long ld, long long ldt, OP op, hipStream_t stream, const char* who) {
   if (!(src && dst && R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0 && ld % 8 == 0 && ldt % 8 == 0)) {
@@ -156,6 +196,20 @@ extern "C" int mla_rmsnorm_apply_t(const void* x, const void* w, const float* rs
 // dst[i][t] = silu(gu[t][i]) * gu[t][I + i]
 extern "C" int mla_swiglu_fwd_t(const void* gu, void* dst, long long rows, int I, long long ldt, hipStream_t stream) {
   return launch_tt(gu, dst, rows, I, 2LL * I, ldt, SwigluOp{I}, stream, "mla_swiglu_fwd_t");
+}
+
+// act = silu(gate) * up [rows, I] and actT = its transpose [I, ldt >= rows], in one pass
+extern "C" int mla_swiglu_fwd_dual(const void* gu, void* act, void* actT, long long rows, int I, long long ldt, hipStream_t stream) {
+  if (!(gu && act && actT && rows > 0 && I > 0 && rows % 8 == 0 && I % 8 == 0 && ldt % 8 == 0 && ldt >= rows)) {
+    mla_set_error("mla_swiglu_fwd_dual: need rows, I, ldt multiples of 8 and ldt >= rows");
+    return -1;
+  }
+  if ((((uintptr_t)gu | (uintptr_t)act | (uintptr_t)actT) & 15) != 0) { mla_set_error("mla_swiglu_fwd_dual: 16-B alignment"); return -1; }
+  dim3 grid((I + 63) / 64, (unsigned)((rows + 63) / 64));
+  hipLaunchKernelGGL(swiglu_fwd_dual_kernel, grid, dim3(256), 0, stream, (const bf16_t*)gu, (bf16_t*)act, (bf16_t*)actT, rows, I, ldt);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mla_set_error("mla_swiglu_fwd_dual: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
 }
 
 // dgu = SwiGLU backward of dact (row-major [rows, 2I]) and dguT = its transpose [2I, ldt >= rows], in one pass

@@ -452,6 +452,7 @@ register_signatures({
     "mla_transpose_bf16": [c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_longlong, c_void_p],
     "mla_rmsnorm_apply_t": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p],
     "mla_swiglu_fwd_t": [c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p],
+    "mla_swiglu_fwd_dual": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p],
 })
 
 
@@ -470,6 +471,15 @@ def rmsnorm_apply_t(x2d, w, rstd):
     out = torch.empty((H, rows), dtype=torch.bfloat16, device=x2d.device)
     call("mla_rmsnorm_apply_t", _p(x2d), _p(w), _p(rstd), _p(out), rows, H, rows)
     return out
+
+
+def swiglu_fwd_dual(gu2d):
+    """(act [rows, I], actT [I, rows]) in one pass over gu."""
+    rows, two_i = gu2d.shape
+    act = torch.empty((rows, two_i // 2), dtype=torch.bfloat16, device=gu2d.device)
+    actT = torch.empty((two_i // 2, rows), dtype=torch.bfloat16, device=gu2d.device)
+    call("mla_swiglu_fwd_dual", _p(gu2d), _p(act), _p(actT), rows, two_i // 2, rows)
+    return act, actT
 
 
 def swiglu_fwd_t(gu2d):
