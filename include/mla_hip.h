@@ -47,6 +47,12 @@ int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const
                      int ldc, int ldr, int a_mode, int b_mode, int out_fp32, int accumulate, float alpha, int force_generic,
                      float* workspace, size_t workspace_bytes, mla_stream_t stream);
 
+/* fused q|k|v projection + rotary embedding (LlamaAttention.forward modeling_llama.py:351-361 + apply_rotary_pos_emb :184-208):
+ * C[M, N] = A[M, K] B[N, K]^T in bf16 with columns [0, rope_cols) rotated per head of 128 (position = row % S, tables [S, 64]
+ * fp32) in the GEMM epilogue; bit-identical to mla_gemm_bf16 followed by mla_rope_inplace. M, N >= 256, K % 64 == 0. */
+int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const float* rope_cos,
+                      const float* rope_sin, int S, int rope_cols, mla_stream_t stream);
+
 /* ---- RMSNorm: LlamaRMSNorm.forward modeling_llama.py:76-90; timm RmsNorm in FinalLayer (models/diffusion/models.py:177) */
 int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int H, float eps, mla_stream_t stream);
 int mla_rmsnorm_bwd_blocks(int rows);
@@ -122,9 +128,11 @@ int mla_q_sample(const float* x0, const float* noise, const long long* t, const 
  * seqlens (int32 [B] or NULL): right-padded rows q >= seqlens[b] give zero output / zero gradients. */
 int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B, int S, int H,
                  int head_dim, long long ld_qkv, long long ld_o, float scale, mla_stream_t stream);
+/* rope_cos / rope_sin ([S, 64] fp32, both or neither): when given, dq and dk are written with the backward of apply_rotary_pos_emb
+ * (modeling_llama.py:184-208) already applied -- the same values mla_rope_inplace(backward = 1) would produce on them afterwards */
 int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
                  void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
-                 float scale, mla_stream_t stream);
+                 float scale, const float* rope_cos, const float* rope_sin, mla_stream_t stream);
 
 /* ---- losses: CrossEntropyLoss modeling_llama.py:1258-1269; InfoNCE models/mla/fuser/contrastive.py:208-215 */
 int mla_ce_fwd(const void* logits, int logits_fp32, long long ld, const long long* labels, float* loss, float* lse, int rows,

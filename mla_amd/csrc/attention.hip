@@ -132,7 +132,28 @@ struct AttnArgs {
   int B, S, H;
   long long ld, ld_o;
   float scale;
+  const float* rope_cos; const float* rope_sin;        // backward only: [S, 64] fp32 tables; non-null = dq / dk leave the kernels with
+                                                       // the RoPE backward already applied (replaces a separate in-place pass)
 };
+
+// RoPE backward of one gradient row held as 8 x f32x4 (d = fd*16 + g*4 + r): pairs (d, d + 64) sit in the SAME lane (fd, fd + 4).
+// Same arithmetic as rope_kernel(sign = -1) on the bf16-rounded values, so fused and unfused results are bit-identical:
+//   out_lo = a cos + b sin,  out_hi = b cos - a sin    (a = first half, b = second half of the head)
+__device__ __forceinline__ void rope_bwd_row(f32x4_t (&v)[8], const float* __restrict__ cos_t, const float* __restrict__ sin_t, int pos,
+                                             int g) {
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd) {
+    const f32x4_t c = *(const f32x4_t*)(cos_t + (size_t)pos * 64 + fd * 16 + g * 4);
+    const f32x4_t sn = *(const f32x4_t*)(sin_t + (size_t)pos * 64 + fd * 16 + g * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = bf2f(f2bf(v[fd][r])), b = bf2f(f2bf(v[fd + 4][r]));
+      const float s_ = -sn[r];
+      v[fd][r] = fmaf(a, c[r], -(b * s_));
+      v[fd + 4][r] = fmaf(b, c[r], a * s_);
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 // RB = 16-row query groups per wave (block = 4 waves x RB x 16 query rows). RB = 2 reads every K / V^T fragment once for two
@@ -505,10 +526,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
       bf16_t* dqrow = p.dq + ((long long)b * p.S + myq[rb]) * p.ld + h * D;
       const float sc = padq[rb] ? 0.f : p.scale;
 #pragma unroll
+      for (int fd = 0; fd < 8; ++fd) dqt[rb][fd] *= sc;
+      if (p.rope_cos) rope_bwd_row(dqt[rb], p.rope_cos, p.rope_sin, myq[rb], g);
+#pragma unroll
       for (int fd = 0; fd < 8; ++fd) {
         u32x2_t w;
-        w[0] = pack2bf(dqt[rb][fd][0] * sc, dqt[rb][fd][1] * sc);
-        w[1] = pack2bf(dqt[rb][fd][2] * sc, dqt[rb][fd][3] * sc);
+        w[0] = pack2bf(dqt[rb][fd][0], dqt[rb][fd][1]);
+        w[1] = pack2bf(dqt[rb][fd][2], dqt[rb][fd][3]);
         *(u32x2_t*)(dqrow + fd * 16 + g * 4) = w;
       }
     }
@@ -614,10 +638,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     bf16_t* dkrow = p.dk + ((long long)b * p.S + mykey) * p.ld + h * D;
     bf16_t* dvrow = p.dv + ((long long)b * p.S + mykey) * p.ld + h * D;
 #pragma unroll
+    for (int fd = 0; fd < 8; ++fd) dkt[fd] *= p.scale;
+    if (p.rope_cos) rope_bwd_row(dkt, p.rope_cos, p.rope_sin, mykey, g);
+#pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
       u32x2_t w;
-      w[0] = pack2bf(dkt[fd][0] * p.scale, dkt[fd][1] * p.scale);
-      w[1] = pack2bf(dkt[fd][2] * p.scale, dkt[fd][3] * p.scale);
+      w[0] = pack2bf(dkt[fd][0], dkt[fd][1]);
+      w[1] = pack2bf(dkt[fd][2], dkt[fd][3]);
       *(u32x2_t*)(dkrow + fd * 16 + g * 4) = w;
       w[0] = pack2bf(dvt[fd][0], dvt[fd][1]);
       w[1] = pack2bf(dvt[fd][2], dvt[fd][3]);
@@ -656,7 +683,10 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
 // delta: workspace [B,H,S] fp32 (caller-allocated)
 extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                             const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
-                            int head_dim, long long ld_qkv, long long ld_o, float scale, hipStream_t stream) {
+                            int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
+                            const float* rope_sin, hipStream_t stream) {
+  MLA_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "mla_attn_bwd: rope_cos / rope_sin must both be given or both be null");
+  MLA_CHECK_ARG(!rope_cos || (AL16(rope_cos) && AL16(rope_sin)), "mla_attn_bwd: rope tables must be 16-B aligned");
   MLA_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta, "mla_attn_bwd: null pointer");
   MLA_CHECK_ARG(head_dim == D, "mla_attn_bwd: head_dim must be 128 (got %d)", head_dim);
   MLA_CHECK_ARG(AL16(q) && AL16(k) && AL16(v) && AL16(o) && AL16(dout) && AL16(dq) && AL16(dk) && AL16(dv),
@@ -665,6 +695,7 @@ extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const v
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.lse = (float*)lse; p.seqlens = seqlens;
   p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
   p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   if (check_common(p, "mla_attn_bwd")) return -1;
   static bool attr = false;
   if (!attr) {

@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ buf, con
     for (int j = 0; j < 4; ++j) { c[j] = c0[j]; c[j + 4] = c1[j]; s[j] = s0[j] * sign; s[j + 4] = s1[j] * sign; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      oa[j] = a[j] * c[j] - b[j] * s[j];
-      ob[j] = b[j] * c[j] + a[j] * s[j];
+      oa[j] = fmaf(a[j], c[j], -(b[j] * s[j]));    // explicit contraction: the fused forms (gemm256 epilogue, attention backward)
+      ob[j] = fmaf(b[j], c[j], a[j] * s[j]);       // use the same two expressions and stay bit-identical to this kernel
     }
     *(u32x4_t*)p = pack8(oa);
     *(u32x4_t*)(p + half) = pack8(ob);

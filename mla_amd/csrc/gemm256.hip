@@ -308,6 +308,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       __syncthreads();
       const int ch = lane & 31;
       const int n = n0 + ch * 8;
+      if (p.rope_cos && n0 < p.rope_cols) {
+        // fused rotary embedding (apply_rotary_pos_emb, modeling_llama.py:184-208) on the bf16-rounded projection: the tile is two
+        // whole heads; a lane's 8 columns pair with the chunk 8 positions away in the same row (d <-> d + 64). Same arithmetic as
+        // rope_kernel (elementwise.hip), so the result is bit-identical to GEMM + mla_rope_inplace.
+        if (n < p.N) {
+          const bool lo = (ch & 8) == 0;
+#pragma unroll 4
+          for (int it = 0; it < 16; ++it) {
+            const int row = wave * 32 + it * 2 + (lane >> 5);
+            const int m = m0 + row;
+            if (m < p.M) {
+              float own[8], par[8], c[8], sn[8], o[8];
+              unpack8(*(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)), own);
+              unpack8(*(const u32x4_t*)(smem + row * 512 + (((ch ^ 8) ^ (row & 31)) << 4)), par);
+              const float* ct = p.rope_cos + (size_t)(m % p.rope_S) * 64 + (ch & 7) * 8;
+              const float* st = p.rope_sin + (size_t)(m % p.rope_S) * 64 + (ch & 7) * 8;
+              const f32x4_t c0 = *(const f32x4_t*)ct, c1 = *(const f32x4_t*)(ct + 4), s0 = *(const f32x4_t*)st, s1 = *(const f32x4_t*)(st + 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { c[j] = c0[j]; c[j + 4] = c1[j]; sn[j] = s0[j]; sn[j + 4] = s1[j]; }
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                o[j] = lo ? fmaf(own[j], c[j], -(par[j] * sn[j])) : fmaf(own[j], c[j], par[j] * sn[j]);
+              *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8(o);
+            }
+          }
+        }
+        return;
+      }
       if (n < p.N) {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -822,6 +850,25 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
 }
 
 }  // namespace
+
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream);
+
+// Fused QKV projection + rotary embedding: C[M, N] = A[M, K] B[N, K]^T (bf16), columns [0, rope_cols) rotated per head of 128 with
+// position = row % S. Replaces hip.gemm + mla_rope_inplace on the packed q|k|v buffer (LlamaAttention.forward :351-361).
+extern "C" int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                 const float* rope_cos, const float* rope_sin, int S, int rope_cols, hipStream_t stream) {
+  MLA_CHECK_ARG(A && B && C && rope_cos && rope_sin, "mla_gemm_qkv_rope: null pointer");
+  MLA_CHECK_ARG(M >= 256 && N >= 256 && K > 0 && K % 64 == 0 && N % 8 == 0, "mla_gemm_qkv_rope: needs M, N >= 256, K %% 64 == 0, N %% 8 == 0");
+  MLA_CHECK_ARG(S > 0 && rope_cols > 0 && rope_cols % 256 == 0 && rope_cols <= N, "mla_gemm_qkv_rope: rope_cols must be a multiple of 256 (two heads of 128) and <= N");
+  MLA_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "mla_gemm_qkv_rope: leading dimensions must be multiples of 8");
+  MLA_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15) == 0,
+                "mla_gemm_qkv_rope: 16-B alignment required");
+  GemmArgs p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.alpha = 1.f;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_S = S; p.rope_cols = rope_cols;
+  return mla_gemm256_dispatch(&p, 0, 0, 0, stream);     // no split-K tail (its fix-up pass has no rotary epilogue)
+}
 
 // called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>
 // instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.

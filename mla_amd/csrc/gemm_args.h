@@ -21,4 +21,9 @@ struct GemmArgs {
   // sk_split K-slices whose fp32 partial tiles go to sk_ws [unit][256][256]; a fix-up kernel sums them and applies the epilogue
   int sk_full, sk_split;
   float* sk_ws;
+  // gemm256 bf16 fast epilogue only: rotary embedding applied to output columns [0, rope_cols) on the way out (heads of 128 columns,
+  // pairs (d, d + 64), position = output row % rope_S; tables [rope_S, 64] fp32) -- the fused QKV projection (mla_gemm_qkv_rope)
+  const float* rope_cos;
+  const float* rope_sin;
+  int rope_S, rope_cols;
 };

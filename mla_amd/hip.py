@@ -33,6 +33,8 @@ _SIGNATURES = {
                       c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "mla_gemm_bf16_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p],
+    "mla_gemm_qkv_rope": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                          c_void_p],
     "mla_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "mla_rmsnorm_bwd_blocks": [c_int],
     "mla_timm_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
@@ -61,7 +63,7 @@ _SIGNATURES = {
     "mla_attn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong,
                      c_longlong, c_float, c_void_p],
     "mla_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                     c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p],
+                     c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p, c_void_p],
     "mla_ce_fwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p],
     "mla_ce_bwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong, c_int, c_int,
                    c_longlong, c_void_p],
@@ -201,6 +203,30 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (a_mode, b_mode, M, N, K)))
     return out
+
+
+def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols):
+    """out[T, N] = x2d @ wqkv^T with RoPE applied to columns [0, rope_cols) in the GEMM epilogue (bit-identical to gemm + rope_inplace).
+    Returns False when the shape is outside the fused kernel's contract (the caller then runs the two separate launches)."""
+    T, K = x2d.shape
+    N = wqkv.shape[0]
+    ok = (T >= 256 and N >= 256 and K % 64 == 0 and N % 8 == 0 and rope_cols % 256 == 0 and x2d.stride(0) % 8 == 0 and
+          wqkv.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and cos.dtype == torch.float32 and cos.is_contiguous() and
+          sin.is_contiguous() and cos.shape == (S, 64) and all(t.data_ptr() % 16 == 0 for t in (x2d, wqkv, out, cos, sin)))
+    if not ok:
+        return False
+    _req(x2d, torch.bfloat16, "gemm_qkv_rope x")
+    _req(wqkv, torch.bfloat16, "gemm_qkv_rope w")
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("mla_gemm_qkv_rope", _p(x2d), _p(wqkv), _p(out), T, N, K, x2d.stride(0), wqkv.stride(0), out.stride(0), _p(cos), _p(sin),
+         int(S), int(rope_cols))
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * T * N * K, (0, 0, T, N, K)))
+    return True
 
 
 # --------------------------------------------------------------------------------------------- norms
@@ -369,10 +395,15 @@ def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale):
+def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale, rope_cos=None, rope_sin=None):
+    """rope_cos / rope_sin ([S, D/2] fp32): dq / dk come out with the RoPE backward already applied (no separate pass)."""
     delta = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    if rope_cos is not None:
+        _req(rope_cos, torch.float32, "rope cos")
+        _req(rope_sin, torch.float32, "rope sin")
+        assert rope_cos.shape == (S, D // 2) and rope_sin.shape == (S, D // 2) and rope_cos.is_contiguous() and rope_sin.is_contiguous()
     call("mla_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
-         H, D, ld_qkv, H * D, float(scale))
+         H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin))
 
 
 # --------------------------------------------------------------------------------------------- losses

@@ -453,6 +453,7 @@ def info_nce(a, b, M, temperature):
 
 
 # ------------------------------------------------------------------------------------------------- decoder layer
+_ROPE_EPILOGUE = os.environ.get("MLA_ROPE_EPILOGUE", "1") != "0"   # A/B switch (tools): 0 = separate RoPE pass after the QKV GEMM
 _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (tools): 0 = recompute act^T in the backward
 
 
@@ -476,12 +477,16 @@ class DecoderLayerFn(torch.autograd.Function):
         xn1, rstd1 = hip.rmsnorm_fwd(h2, ln1, eps)
         qkv = torch.empty((h2.shape[0], 3 * H), dtype=BF16, device=h2.device)
         wqkv = cat_view((wq, wk, wv))
-        if wqkv is not None:
-            hip.gemm(xn1, wqkv, out=qkv)
-        else:
-            for i, wi in enumerate((wq, wk, wv)):
-                hip.gemm(xn1, wi, out=qkv[:, i * H:(i + 1) * H])
-        hip.rope_inplace(qkv, cos, sin, S, nheads, D, 0, H)
+        # fused RMSNorm-output x [Wq|Wk|Wv]^T + RoPE: the rotary embedding of q and k happens in the GEMM epilogue (north_star's
+        # "fused RoPE + QKV"); shapes outside the fused kernel's contract take the two separate launches
+        if not (wqkv is not None and D == 128 and _ROPE_EPILOGUE and cos.shape[0] == S and
+                hip.gemm_qkv_rope(xn1, wqkv, qkv, cos, sin, S, 2 * H)):
+            if wqkv is not None:
+                hip.gemm(xn1, wqkv, out=qkv)
+            else:
+                for i, wi in enumerate((wq, wk, wv)):
+                    hip.gemm(xn1, wi, out=qkv[:, i * H:(i + 1) * H])
+            hip.rope_inplace(qkv, cos, sin, S, nheads, D, 0, H)
         o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
                               rows=h2.shape[0])
         h1 = hip.gemm(o, wo, residual=h2)
@@ -611,10 +616,14 @@ class DecoderLayerFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         if T != Tr:
             dqkv[Tr:].zero_()
+        # the RoPE backward of dq / dk is applied in the attention-backward epilogues (no separate in-place pass over dqkv)
+        fuse_rope = cos.shape[0] == S and cos.is_contiguous() and sin.is_contiguous() and cos.dtype == torch.float32
         hip.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, seqlens, dqkv[:, :H], dqkv[:, H:2 * H],
-                     dqkv[:, 2 * H:], B, S, nheads, D, 3 * H, 1.0 / math.sqrt(D))
+                     dqkv[:, 2 * H:], B, S, nheads, D, 3 * H, 1.0 / math.sqrt(D), rope_cos=cos if fuse_rope else None,
+                     rope_sin=sin if fuse_rope else None)
         del do
-        hip.rope_inplace(dqkv, cos, sin, S, nheads, D, 0, H, backward=True)
+        if not fuse_rope:
+            hip.rope_inplace(dqkv, cos, sin, S, nheads, D, 0, H, backward=True)
         # ---- q | k | v projection
         dxn1 = hip.gemm(dqkv, wT((wq, wk, wv)))                          # [T, H], K = 3H
         if need[1] or need[2] or need[3]:

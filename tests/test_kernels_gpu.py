@@ -260,6 +260,53 @@ def test_attention_fwd_bwd(dev, B, S, H, lens):
             assert float(dqkv[rows].float().abs().max() if int(seqlens[b_]) < S else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("T,S,nh", [(548 * 2, 548, 4), (300, 100, 2), (2048, 2048, 2)])
+def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, T, S, nh):
+    """mla_gemm_qkv_rope == mla_gemm_bf16 + mla_rope_inplace on the packed q|k|v buffer, bit for bit (ragged tile edges: T % 256 != 0,
+    N = 3 * nh * 128 not a multiple of 256 when nh is odd -> covered by nh = 2, 4 and the v-columns boundary at 2 * nh * 128)."""
+    from mla_amd import hip
+    D, H = 128, nh * 128
+    K = 256
+    x = bfr(T, K, seed=31).to(dev)
+    w = bfr(3 * H, K, seed=32, scale=0.2).to(dev)
+    cos, sin = O.rope_tables(S, D)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    ref = hip.gemm(x, w)
+    hip.rope_inplace(ref, cos, sin, S, nh, D, 0, H)
+    out = torch.full((T, 3 * H), float("nan"), dtype=BF, device=dev)
+    assert hip.gemm_qkv_rope(x, w, out, cos, sin, S, 2 * H)
+    assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+    # and against the oracle (loose: bf16 GEMM output)
+    qk = (x.float().cpu() @ w.float().cpu().t()).to(BF).float()
+    B = T // S
+    q = qk[:B * S, :H].view(B, S, nh, D).transpose(1, 2)
+    k = qk[:B * S, H:2 * H].view(B, S, nh, D).transpose(1, 2)
+    qr, kr = O.apply_rope(q, k, cos.cpu(), sin.cpu())
+    got = out[:B * S, :H].float().cpu().view(B, S, nh, D).transpose(1, 2)
+    assert fro_rel(got, qr) < 6e-3
+
+
+def test_attention_bwd_fused_rope_is_bit_identical(dev):
+    """mla_attn_bwd with the RoPE tables == mla_attn_bwd followed by mla_rope_inplace(backward=True) on dq | dk, bit for bit
+    (full and ragged sequences; apply_rotary_pos_emb backward, modeling_llama.py:184-208)."""
+    from mla_amd import hip
+    B, S, H, D = 2, 200, 3, 128
+    qkv = bfr(B * S, 3 * H * D, seed=21, scale=0.7).to(dev)
+    do = bfr(B * S, H * D, seed=22).to(dev)
+    cos, sin = O.rope_tables(S, D)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    for lens in (None, [200, 77]):
+        sl = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+        o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, sl, 1 / math.sqrt(D))
+        a, b = torch.zeros_like(qkv), torch.zeros_like(qkv)
+        hip.attn_bwd(q, k, v, o, do, lse, sl, a[:, :H * D], a[:, H * D:2 * H * D], a[:, 2 * H * D:], B, S, H, D, 3 * H * D, 1 / math.sqrt(D))
+        hip.rope_inplace(a, cos, sin, S, H, D, 0, H * D, backward=True)
+        hip.attn_bwd(q, k, v, o, do, lse, sl, b[:, :H * D], b[:, H * D:2 * H * D], b[:, 2 * H * D:], B, S, H, D, 3 * H * D, 1 / math.sqrt(D),
+                     rope_cos=cos, rope_sin=sin)
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+
+
 def test_ce_and_l2norm_and_infonce(dev):
     from mla_amd import hip
     rows, V = 50, 32064
