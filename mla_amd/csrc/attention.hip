@@ -382,6 +382,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
+#ifndef MLA_ATTN_BWD_SW
+#define MLA_ATTN_BWD_SW 0
+#endif
+constexpr int ASW = MLA_ATTN_BWD_SW;   // LDS swizzle of the backward kernels' tiles, which are read BOTH as row fragments and transposed
+                                       // (0 leaves 25-30 % bank-conflict cycles on the transposed reads, 1 is conflict-free for both read
+                                       // forms -- and measures the same: 410 / 268 us at S = 548; the loops are latency-bound)
+
 // ------------------------------------------------------------------------------------------------ dQ
 // Same row-group pairing and per-(wave, group, tile) skipping as the forward kernel.
 template <int RB, int MASK>
@@ -401,7 +408,7 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t kf = frag_rows<0>(kt_, f, ks, lane), vf = frag_rows<0>(vt_, f, ks, lane);
+        const bf16x8_t kf = frag_rows<ASW>(kt_, f, ks, lane), vf = frag_rows<ASW>(vt_, f, ks, lane);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
           if ((MASK >> rb) & 1) {
@@ -435,7 +442,7 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
   for (int fd = 0; fd < 8; ++fd)
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ++ks2) {
-      const bf16x8_t ktf = frag_tr<0>(kt_, fd, ks2, lane);
+      const bf16x8_t ktf = frag_tr<ASW>(kt_, fd, ks2, lane);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
         if ((MASK >> rb) & 1) dqt[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, ds[rb][ks2], dqt[rb][fd], 0, 0, 0);
@@ -496,8 +503,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   }
   const float sc2 = p.scale * LOG2E;
 
-  stage_rows64<0, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
-  stage_rows64<0, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
+  stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
+  stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -505,8 +512,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
     const char* vt_ = kt_ + TILE_BYTES;
     if (kt + 1 < nkt) {
       char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-      stage_rows64<0, NW>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);       // (register budget: no precomputed offsets here)
-      stage_rows64<0, NW>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+      stage_rows64<ASW, NW>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);       // (register budget: no precomputed offsets here)
+      stage_rows64<ASW, NW>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
     }
     int mask = 0;
 #pragma unroll
@@ -570,11 +577,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   const int nqt_end = (qend + 63) / 64;
   const int qt0 = kb;
   unsigned qoff[4], dooff[4];
-  stage_offs<0>(p.ld, wave, lane, qoff);
-  stage_offs<0>(p.ld_o, wave, lane, dooff);
+  stage_offs<ASW>(p.ld, wave, lane, qoff);
+  stage_offs<ASW>(p.ld_o, wave, lane, dooff);
   if (qt0 < nqt_end) {
-    stage_rows64<0>(qb_, p.ld, qt0 * 64, p.S, smem, wave, lane);
-    stage_rows64<0>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
+    stage_rows64<ASW>(qb_, p.ld, qt0 * 64, p.S, smem, wave, lane);
+    stage_rows64<ASW>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
   }
   for (int qt = qt0; qt < nqt_end; ++qt) {
     const int bufi = (qt - qt0) & 1;
@@ -595,8 +602,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         stage_fast(qb_ + (long long)(qt + 1) * 64 * p.ld, qoff, nx, wave);
         stage_fast(dob_ + (long long)(qt + 1) * 64 * p.ld_o, dooff, nx + TILE_BYTES, wave);
       } else {
-        stage_rows64<0>(qb_, p.ld, (qt + 1) * 64, p.S, nx, wave, lane);
-        stage_rows64<0>(dob_, p.ld_o, (qt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+        stage_rows64<ASW>(qb_, p.ld, (qt + 1) * 64, p.S, nx, wave, lane);
+        stage_rows64<ASW>(dob_, p.ld_o, (qt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
       }
     }
     f32x4_t s[4], dp[4];
@@ -606,8 +613,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       dp[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<0>(qt_, f, ks, lane), kf[ks], s[f], 0, 0, 0);
-        dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<0>(dot_, f, ks, lane), vf[ks], dp[f], 0, 0, 0);
+        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<ASW>(qt_, f, ks, lane), kf[ks], s[f], 0, 0, 0);
+        dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<ASW>(dot_, f, ks, lane), vf[ks], dp[f], 0, 0, 0);
       }
     }
     f32x4_t pr[4];
@@ -628,10 +635,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const bf16x8_t ds0 = pack_frag(s[0], s[1]), ds1 = pack_frag(s[2], s[3]);
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
-      dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(dot_, fd, 0, lane), p0, dvt[fd], 0, 0, 0);
-      dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(dot_, fd, 1, lane), p1, dvt[fd], 0, 0, 0);
-      dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(qt_, fd, 0, lane), ds0, dkt[fd], 0, 0, 0);
-      dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<0>(qt_, fd, 1, lane), ds1, dkt[fd], 0, 0, 0);
+      dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(dot_, fd, 0, lane), p0, dvt[fd], 0, 0, 0);
+      dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(dot_, fd, 1, lane), p1, dvt[fd], 0, 0, 0);
+      dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(qt_, fd, 0, lane), ds0, dkt[fd], 0, 0, 0);
+      dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(qt_, fd, 1, lane), ds1, dkt[fd], 0, 0, 0);
     }
   }
   if (mykey < p.S) {

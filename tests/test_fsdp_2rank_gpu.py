@@ -43,7 +43,7 @@ def _run(rank, world, dev, accumulate=False):
     R = 2
     m = _build(dev)
     split = world > 1 or accumulate
-    strat = FSDPStrategy(m, 0, global_batch_size=2, per_device_batch_size=1 if split else 2, learning_rate=1e-3, weight_decay=0.01,
+    strat = FSDPStrategy(m, dev.index or 0, global_batch_size=2, per_device_batch_size=1 if split else 2, learning_rate=1e-3, weight_decay=0.01,
                          max_grad_norm=1.0, lr_scheduler_type="constant", enable_gradient_checkpointing=False, repeated_diffusion_steps=R)
     assert strat.grad_accumulation_steps == (2 if accumulate else 1)
     strat.run_setup(100)
@@ -79,31 +79,58 @@ def _run(rank, world, dev, accumulate=False):
                 compute={k: compute[k].detach().float().cpu().numpy() for k in keys})
 
 
-def _worker(rank, world, port, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, ret, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    local = rank if backend == "nccl" else 0          # RCCL: one device per rank; gloo: both ranks share device 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ret[rank] = _run(rank, world, torch.device("cuda", 0))
+        ret[rank] = _run(rank, world, dev)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(dev):
-    from oracle import recipe
-    single = _run(0, 1, dev)
+def _two_ranks(backend):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret, backend)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0, f"rank process failed (exit code {p.exitcode})"
-    r0, r1 = ret[0], ret[1]
+    return ret[0], ret[1]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device (the 1-GPU box runs the gloo variant)")
+def test_two_rccl_ranks_match_single_process(dev):
+    """The same comparison over the REAL collective path: two processes, one MI355X each, backend nccl (= RCCL over xGMI):
+    reduce_scatter_tensor(AVG) launched from the backward on the side stream, in-place all_gather_into_tensor behind the optimizer,
+    scalar all-reduce of the gradient norm (training/strategies/fsdp.py:181-209, 308-310)."""
+    _compare(_run(0, 1, dev), *_two_ranks("nccl"), tag="rccl")
+
+
+def test_two_ranks_match_single_process(dev):
+    _compare(_run(0, 1, dev), *_two_ranks("gloo"), tag="gloo")
+
+
+# Bounds = 1.5 x the values measured on MI355X (printed on every run). Rank-averaged and single-process runs execute DIFFERENT kernel
+# paths on purpose (half the rows per rank: other tile counts, other split-K tails, other attention grids), so individual bf16
+# activations move by one ulp and the comparison is at bf16 level, not bit level; AdamW's first steps are sign-like (update ~ lr * sign(g)
+# while v is small), which turns a gradient entry that flips sign within that noise into a 2 * lr difference of the weight.
+# Measured (round 2): loss 3.18e-3, grad norm 2.95e-3, min cos(update) 0.9913, update norm 1.8e-3.
+DP_LOSS_REL, DP_NORM_REL, DP_COS_MIN, DP_UPD_NORM_REL = 4.8e-3, 4.5e-3, 0.987, 2.7e-3
+
+
+def _compare(single, r0, r1, tag):
+    from oracle import recipe
     # every rank ends with the same weights (fp32 masters after gathering the shards, and the bf16 compute copies)
     for k in r0["weights"]:
         assert np.array_equal(r0["weights"][k], r1["weights"][k]), k
@@ -111,30 +138,25 @@ def test_two_ranks_match_single_process(dev):
         assert np.allclose(r0["compute"][k], r0["weights"][k], rtol=1e-2, atol=1e-3), k     # bf16 copy of the master
     assert r0["norms"] == r1["norms"]
     # data-parallel == single process: mean of the per-rank losses, global gradient norm, updated weights
+    worst = dict(loss=0.0, norm=0.0, cos=1.0, upd=0.0)
     for st in range(STEPS):
         dp_loss = 0.5 * (r0["losses"][st] + r1["losses"][st])
-        assert abs(dp_loss - single["losses"][st]) < 1e-2 * max(1.0, abs(single["losses"][st])), (st, dp_loss, single["losses"][st])
-        assert abs(r0["norms"][st] - single["norms"][st]) < 5e-2 * single["norms"][st], (st, r0["norms"][st], single["norms"][st])
+        worst["loss"] = max(worst["loss"], abs(dp_loss - single["losses"][st]) / max(1.0, abs(single["losses"][st])))
+        worst["norm"] = max(worst["norm"], abs(r0["norms"][st] - single["norms"][st]) / single["norms"][st])
     init = {k: recipe.det_weight(k, v.shape).numpy() for k, v in r0["weights"].items()}
     for k in r0["weights"]:
         du2, du1 = r0["weights"][k] - init[k], single["weights"][k] - init[k]
         cos = float((du2 * du1).sum() / (np.linalg.norm(du2) * np.linalg.norm(du1) + 1e-30))
-        assert cos > 0.9, (k, cos)                 # AdamW's first steps are sign-like: bf16-level gradient noise flips tiny entries
-        assert abs(np.linalg.norm(du2) / np.linalg.norm(du1) - 1) < 0.1, k
+        worst["cos"] = min(worst["cos"], cos)
+        worst["upd"] = max(worst["upd"], abs(np.linalg.norm(du2) / np.linalg.norm(du1) - 1))
+    print(f"2 ranks ({tag}) vs single process over {STEPS} steps: loss rel {worst['loss']:.2e}, grad-norm rel {worst['norm']:.2e}, "
+          f"min cos(update) {worst['cos']:.4f}, update-norm rel {worst['upd']:.2e}")
+    assert worst["loss"] < DP_LOSS_REL and worst["norm"] < DP_NORM_REL and worst["cos"] > DP_COS_MIN and worst["upd"] < DP_UPD_NORM_REL, worst
 
 
 def test_gradient_accumulation_matches_one_big_batch(dev):
     """grad_accumulation_steps = 2 (base_strategy_mla.py:100, :365-377): two micro-batches of one sample, loss / 2, one clip + AdamW
     step per window == one step on both samples, up to bf16 rounding (same bounds as the data-parallel comparison above)."""
-    from oracle import recipe
     single = _run(0, 1, dev)
     acc = _run(0, 1, dev, accumulate=True)
-    for st in range(STEPS):
-        assert abs(acc["losses"][st] - single["losses"][st]) < 1e-2 * max(1.0, abs(single["losses"][st]))
-        assert abs(acc["norms"][st] - single["norms"][st]) < 5e-2 * single["norms"][st], (st, acc["norms"][st], single["norms"][st])
-    init = {k: recipe.det_weight(k, v.shape).numpy() for k, v in acc["weights"].items()}
-    for k in acc["weights"]:
-        du2, du1 = acc["weights"][k] - init[k], single["weights"][k] - init[k]
-        cos = float((du2 * du1).sum() / (np.linalg.norm(du2) * np.linalg.norm(du1) + 1e-30))
-        assert cos > 0.9, (k, cos)
-        assert abs(np.linalg.norm(du2) / np.linalg.norm(du1) - 1) < 0.1, k
+    _compare(single, acc, acc, tag="accumulation window of 2")
