@@ -163,31 +163,48 @@ __global__ __launch_bounds__(256) void timm_rmsnorm_bwd_kernel(const bf16_t* __r
 }
 
 // dx = dres + rstd * (dy*w - n * mean(dy*w*n)),  n = x*rstd ;  dw partial[blockIdx][h] = sum_rows dy*n
+// Each workgroup walks its rows with the NEXT row's three streams (x, dy, dres) already in flight while the current row is reduced
+// and written: one row at a time left the loop waiting on HBM latency twice per row (load, then the block reduction's barrier).
+template <int MAXC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                           float* __restrict__ dw_partial, int rows, int H) {
   __shared__ float scratch[16];
   const int nchunk = H >> 3;
-  float wv[NORM_MAXC][8], dwacc[NORM_MAXC][8];
+  float wv[MAXC][8], dwacc[MAXC][8];
 #pragma unroll
-  for (int c = 0; c < NORM_MAXC; ++c) {
+  for (int c = 0; c < MAXC; ++c) {
     const int ch = threadIdx.x + c * 256;
 #pragma unroll
     for (int j = 0; j < 8; ++j) dwacc[c][j] = 0.f;
     if (ch < nchunk) unpack8(*(const u32x4_t*)(w + ch * 8), wv[c]);
   }
+  u32x4_t nx[MAXC], ndy[MAXC], nres[MAXC];     // raw 16-B pieces of the row being prefetched
+  auto fetch = [&](int row) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = threadIdx.x + c * 256;
+      if (ch < nchunk && row < rows) {
+        nx[c] = *(const u32x4_t*)(x + (size_t)row * H + ch * 8);
+        ndy[c] = *(const u32x4_t*)(dy + (size_t)row * H + ch * 8);
+        if (dres) nres[c] = *(const u32x4_t*)(dres + (size_t)row * H + ch * 8);
+      }
+    }
+  };
+  fetch(blockIdx.x);
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     const float rs = rstd[row];
-    float nv[NORM_MAXC][8], dn[NORM_MAXC][8];
+    float nv[MAXC][8], dn[MAXC][8], rv[MAXC][8];
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < NORM_MAXC; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
       const int ch = threadIdx.x + c * 256;
       if (ch < nchunk) {
         float xv[8], dyv[8];
-        unpack8(*(const u32x4_t*)(x + (size_t)row * H + ch * 8), xv);
-        unpack8(*(const u32x4_t*)(dy + (size_t)row * H + ch * 8), dyv);
+        unpack8(nx[c], xv);
+        unpack8(ndy[c], dyv);
+        if (dres) unpack8(nres[c], rv[c]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           nv[c][j] = xv[j] * rs;
@@ -197,26 +214,22 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         }
       }
     }
+    fetch(row + gridDim.x);                     // next row's loads fly during the reduction + stores of this one
     dot = block_sum(dot, scratch) / (float)H;
 #pragma unroll
-    for (int c = 0; c < NORM_MAXC; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
       const int ch = threadIdx.x + c * 256;
       if (ch < nchunk) {
         float o[8];
-        if (dres) unpack8(*(const u32x4_t*)(dres + (size_t)row * H + ch * 8), o);
-        else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] += rs * (dn[c][j] - nv[c][j] * dot);
+        for (int j = 0; j < 8; ++j) o[j] = (dres ? rv[c][j] : 0.f) + rs * (dn[c][j] - nv[c][j] * dot);
         *(u32x4_t*)(dx + (size_t)row * H + ch * 8) = pack8(o);
       }
     }
   }
   if (dw_partial) {
 #pragma unroll
-    for (int c = 0; c < NORM_MAXC; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
       const int ch = threadIdx.x + c * 256;
       if (ch < nchunk) {
         float* o = dw_partial + (size_t)blockIdx.x * H + ch * 8;
@@ -228,19 +241,31 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
 }
 
 // out[n] (+)= sum_p partial[p][n]   (deterministic second stage for dw / bias-grad reductions)
-// 64 columns x 4 row-lanes per block: 4x the lanes of a column-per-thread layout (P is up to 512, N ~ 4096)
+// 16 columns x 16 row-lanes per block and four independent loads in flight per thread: with P up to 512 partial rows the old
+// 64-column x 4-lane shape was a chain of 128 dependent-latency loads per thread on only N / 64 workgroups (27 us for N = 4096).
+constexpr int RP_COLS = 16, RP_LANES = 16;
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                               int P, int N, int accumulate) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (n < N)
-    for (int p = rl; p < P; p += 4) s += partial[(size_t)p * N + n];
-  red[rl][c] = s;
+  __shared__ float red[RP_LANES][RP_COLS + 1];
+  const int c = threadIdx.x & (RP_COLS - 1), rl = threadIdx.x / RP_COLS;
+  const int n = blockIdx.x * RP_COLS + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int p = rl;
+    for (; p + 3 * RP_LANES < P; p += 4 * RP_LANES) {
+      s0 += partial[(size_t)p * N + n];
+      s1 += partial[(size_t)(p + RP_LANES) * N + n];
+      s2 += partial[(size_t)(p + 2 * RP_LANES) * N + n];
+      s3 += partial[(size_t)(p + 3 * RP_LANES) * N + n];
+    }
+    for (; p < P; p += RP_LANES) s0 += partial[(size_t)p * N + n];
+  }
+  red[rl][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rl == 0 && n < N) {
-    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < RP_LANES; ++i) t += red[i][c];      // fixed order: deterministic
     out[n] = accumulate ? out[n] + t : t;
   }
 }
@@ -645,7 +670,7 @@ extern "C" int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
 }
 
 // workspace: nblocks*H floats (nblocks = mla_rmsnorm_bwd_blocks(rows)); dw may be null (frozen weight)
-extern "C" int mla_rmsnorm_bwd_blocks(int rows) { return rows < 512 ? rows : 512; }
+extern "C" int mla_rmsnorm_bwd_blocks(int rows) { return rows < 1024 ? rows : 1024; }
 extern "C" int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                                float* dw, int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes,
                                hipStream_t stream) {
@@ -653,10 +678,15 @@ extern "C" int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, con
   MLA_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 8192, "mla_rmsnorm_bwd: need H%%8==0, H<=8192 (H=%d)", H);
   const int nb = mla_rmsnorm_bwd_blocks(rows);
   MLA_CHECK_ARG(!dw || (workspace && workspace_bytes >= (size_t)nb * H * sizeof(float)), "mla_rmsnorm_bwd: workspace too small");
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
+  // register arrays sized for the row length: H <= 4096 needs 2 chunks of 8 per thread (half the VGPRs -> twice the resident waves)
+  if (H <= 4096)
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<2>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
+  else
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<NORM_MAXC>, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
   if (dw)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + RP_COLS - 1) / RP_COLS), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
   MLA_LAUNCH_CHECK();
 }
 
@@ -680,7 +710,7 @@ extern "C" int mla_timm_rmsnorm_bwd(const void* dy, const void* x, const void* w
   hipLaunchKernelGGL(timm_rmsnorm_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
                      (const bf16_t*)w, mean, rstd, (bf16_t*)dx, dw ? workspace : nullptr, rows, H);
   if (dw)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H + RP_COLS - 1) / RP_COLS), dim3(256), 0, stream, workspace, dw, nb, H, dw_accumulate);
   MLA_LAUNCH_CHECK();
 }
 
@@ -692,7 +722,7 @@ extern "C" int mla_colsum_bf16(const void* dy, float* out, int accumulate, int r
   const int rs = mla_colsum_blocks(rows);
   MLA_CHECK_ARG(workspace_bytes >= (size_t)rs * N * sizeof(float), "mla_colsum_bf16: workspace too small");
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, (const bf16_t*)dy, workspace, rows, N, ld);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, workspace, out, rs, N, accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + RP_COLS - 1) / RP_COLS), dim3(256), 0, stream, workspace, out, rs, N, accumulate);
   MLA_LAUNCH_CHECK();
 }
 
