@@ -236,6 +236,15 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B_PER_GPU * args.steps / elapsed
         dec_fl, tot_fl = model_flops_per_sample(S)
+        heads_fl = 0.0
+        if prof and args.config == 3 and not args.tiny:
+            # configs[3]: the generation heads' GEMM work is not in the decoder formula -- take it from the launches themselves:
+            # (sum of 2MNK over every GEMM launch of a step) - (the decoder's + lm_head's linear layers, forward + backward)
+            H_, I_, L_, V_ = 4096, 11008, 32, 32064
+            tok = B_PER_GPU * R_DIFF * S
+            dec_gemm = 3.0 * (8 * H_ * H_ + 6 * H_ * I_) * L_ * tok + 2.0 * H_ * V_ * tok
+            heads_fl = max(0.0, sum(fl for _, _, fl, _ in prof) / args.steps - dec_gemm) / B_PER_GPU
+            tot_fl += heads_fl
         roof = None
         if prof:
             big = [(e0.elapsed_time(e1), fl, key) for e0, e1, fl, key in prof if fl > 1e11]
@@ -245,10 +254,15 @@ def main():
             # HBM bytes per launch come from separate rocprofv3 --pmc passes over this same command (PMC collection perturbs timing,
             # so it is not done inline): profiles/r1_gemm256_hbm_traffic.json, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r1_gemm256_hbm_traffic.json")
-            if os.path.exists(tpath) and args.config == 1 and not args.tiny:
-                with open(tpath) as fh:
-                    traffic = round(json.load(fh)["hbm_bytes_per_launch"])
+            tprov = None
+            for tname in ("r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if os.path.exists(tpath) and args.config == 1 and not args.tiny:
+                    with open(tpath) as fh:
+                        tj = json.load(fh)
+                    traffic = round(tj["hbm_bytes_per_launch"])
+                    tprov = f"profiles/{tname} (collected {tj.get('collected', 'round 1')}; separate --pmc passes over this command, not this run)"
+                    break
             if os.environ.get("MLA_BENCH_GEMM_SHAPES"):
                 by = {}
                 for t, fl, key in big:
@@ -261,7 +275,7 @@ def main():
             abytes = sum(2.0 * (k[2] * k[4] + k[3] * k[4]) + 2.0 * k[2] * k[3] for _, _, k in big) / len(big)
             roof = {"bound": "mfma", "kernel": "gemm256_kernel<0,0> (+ gemm128_kernel for small shapes): bf16 MFMA GEMM launches >= 0.1 TFLOP",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "traffic_unit": "HBM+MALL bytes per launch (fabric-side counters), avg over the same launches",
+                    "traffic": traffic, "traffic_source": tprov, "traffic_unit": "HBM+MALL bytes per launch (fabric-side counters), avg over the same launches",
                     "algorithmic_bytes_per_launch_2B_outputs": round(abytes), "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
                     "gemm_ms_per_step": round(tsum / args.steps * 1e3, 1)}
         out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
@@ -278,6 +292,7 @@ def main():
                           "parallelism": f"fsdp-rccl x{world}" if world > 1 else "single-gpu", "activation_save_level": args.save_level,
                           "optimizer": "fused AdamW + grad clip inside the timed region"},
                "model_tflop_per_sample": round(tot_fl / 1e12, 2),
+               **({"heads_encoders_tflop_per_sample_from_gemm_launches": round(heads_fl / 1e12, 2)} if heads_fl else {}),
                "model_tflops_per_gpu": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12, 1),
                "mfu_vs_2.5PF": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                "loss": {k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1},

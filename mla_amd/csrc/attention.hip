@@ -97,13 +97,21 @@ __device__ __forceinline__ void load_row_frags(const bf16_t* __restrict__ rowptr
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8_t*)(rowptr + ks * 32 + g * 8);
 }
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row / half swaps: v_permlane16_swap
+// exchanges the odd rows of one register with the even rows of another, v_permlane32_swap the upper half with the lower half, so
+// swap(v, v) leaves {partner value, own value} in the two results -- two VALU instructions per step instead of a ds_bpermute_b32
+// round trip through the LDS pipe (two dependent ~100-cycle latencies per reduction, four reductions per key tile).
 __device__ __forceinline__ float group_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // XCD-aware block decode: hardware hands consecutive workgroup ids to the 8 XCDs round-robin (id % 8). All row blocks of one

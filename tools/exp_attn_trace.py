@@ -11,7 +11,7 @@ qkv = (torch.randn(B * S, 3 * H * D, device=dev) * 0.5).to(torch.bfloat16)
 q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
 o = torch.empty(B * S, H * D, dtype=torch.bfloat16, device=dev)
 lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-ts = torch.zeros(4 * 256, dtype=torch.int64, device=dev)
+ts = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
 L = hip.lib()
 from ctypes import c_void_p, c_int, c_longlong, c_float
 L.mla_attn_fwd_trace.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_longlong, c_longlong, c_float, c_void_p, c_void_p]
@@ -19,8 +19,8 @@ for it in range(3):
     ts.zero_()
     L.mla_attn_fwd_trace(hip._p(q), hip._p(k), hip._p(v), hip._p(o), hip._p(lse), None, B, S, H, D, 3 * H * D, H * D, D ** -0.5, hip._p(ts), hip._stream())
     torch.cuda.synchronize()
-t = ts.cpu().view(4, 256)
-for w in range(4):
+t = ts.cpu().view(8, 256)
+for w in (0, 3, 7):
     r = t[w]
     print(f"wave {w}: block start->loop end {int(r[251] - r[250])} cycles")
     for kt in range(12):

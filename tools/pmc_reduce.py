@@ -1,0 +1,28 @@
+"""Reduce the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) to fabric bytes per GEMM launch.
+Usage: python tools/pmc_reduce.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [min_us]
+Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is in KiB and reports half the bytes of wide coalesced reads on gfx950 -> x 1024 x 2;
+WRITE_SIZE x 1024 (uncalibrated). Both are fabric-side (L2 <-> Infinity Cache / HBM) counters: Infinity-Cache hits are included."""
+import csv, json, re, sys, datetime
+
+def load(path, counter, min_us):
+    n = 0; tot = 0.0; dur = 0.0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or not re.search(r"gemm256_kernel", r["Kernel_Name"]):
+            continue
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        if us < min_us:
+            continue
+        n += 1; tot += float(r["Counter_Value"]); dur += us
+    return n, tot / max(n, 1), dur / max(n, 1)
+
+min_us = float(sys.argv[4]) if len(sys.argv) > 4 else 300.0
+nf, fkb, fus = load(sys.argv[1], "FETCH_SIZE", min_us)
+nw, wkb, wus = load(sys.argv[2], "WRITE_SIZE", min_us)
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 1 --warmup 1`, gemm256_kernel launches >= {min_us:.0f} us",
+       "collected": datetime.date.today().isoformat(),
+       "corrections": "FETCH_SIZE x 1024 B x 2 (gfx950 counts 128-B requests as 64 B); WRITE_SIZE x 1024 B (uncalibrated)",
+       "launches": nf, "avg_launch_us": fus, "fetch_size_kb_avg": fkb, "write_size_kb_avg": wkb,
+       "hbm_read_bytes_per_launch": fkb * 1024 * 2, "hbm_write_bytes_per_launch": wkb * 1024,
+       "hbm_bytes_per_launch": fkb * 1024 * 2 + wkb * 1024}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out))

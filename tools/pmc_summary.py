@@ -10,7 +10,7 @@ for r in rows:
     agg[key]['_dur_us'].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
 names = sorted({n for d in agg.values() for n in d})
 for k in sorted(agg):
-    print(k)
+    print(k, "launches=%d" % len(agg[k]['_dur_us']))
     for n in names:
         v = agg[k][n]
         if v: print(f"    {n:30s} {sum(v)/len(v):16.4g}")
