@@ -39,7 +39,14 @@ class SyntheticLlamaTokenizer:
         self.added += new
         return len(new)
 
+    _warned = False
+
     def encode(self, s, add_special_tokens=False):
+        if not SyntheticLlamaTokenizer._warned:
+            SyntheticLlamaTokenizer._warned = True
+            import warnings
+            warnings.warn("SyntheticLlamaTokenizer.encode is a hash, not the Llama-2 vocabulary: pass `tokenizer=` or `tokenizer_path=` "
+                          "to LLaMa2LLMBackbone for real prompts")
         return [3 + (sum(map(ord, s)) % 1000)]
 
 
@@ -57,11 +64,22 @@ class LLMBackbone(nn.Module):
 class LLaMa2LLMBackbone(LLMBackbone):
     def __init__(self, llm_backbone_id: str = "llama2-7b-pure", llm_max_length: int = 2048, hf_token: Optional[str] = None,
                  inference_mode: bool = False, use_flash_attention_2: bool = True, llm_vision_layers: int = 1,
-                 config: Optional[LlamaConfig] = None, pad_to_multiple_of: int = 64, **kwargs) -> None:
+                 config: Optional[LlamaConfig] = None, pad_to_multiple_of: int = 64, tokenizer=None,
+                 tokenizer_path: Optional[str] = None, **kwargs) -> None:
+        """``tokenizer``: a ready tokenizer object (the reference's `AutoTokenizer.from_pretrained(hf_hub_path, ...)`,
+        base_llm.py:138-150); ``tokenizer_path``: a local directory with the Llama-2 tokenizer files, loaded with the vendored
+        `transformers.AutoTokenizer` (`model_max_length=llm_max_length, padding_side="right"`), after which `<PAD>` is added like
+        llama2.py:75. With neither, a SYNTHETIC stand-in is installed (hash `encode`, 32000 + `<PAD>` ids): right for the benchmark
+        and the tests, wrong for real prompts -- `string2idx`, the embedding resize and `predict_action_diff` prompts depend on the
+        real vocabulary, so `get_tokenizer()` / `encode` warn once when the stand-in is used."""
         super().__init__(llm_backbone_id)
         self.llm_max_length, self.inference_mode = llm_max_length, inference_mode
         cfg = config or LlamaConfig()
-        self.tokenizer = SyntheticLlamaTokenizer(cfg.vocab_size)
+        if tokenizer is None and tokenizer_path is not None:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(tokenizer_path, model_max_length=llm_max_length, padding_side="right")
+            tokenizer.add_special_tokens({"pad_token": "<PAD>"})                       # llama2.py:75
+        self.tokenizer = tokenizer if tokenizer is not None else SyntheticLlamaTokenizer(cfg.vocab_size)
         self.llm = LlamaForCausalLM(cfg)
         # llama2.py:75-77: add <PAD>, resize embeddings padded to a multiple of 64 (32001 -> 32064)
         self.llm.resize_token_embeddings(len(self.tokenizer), pad_to_multiple_of=pad_to_multiple_of)

@@ -127,6 +127,8 @@ class FlatUnit:
         for _, p, _ in self.params:
             if p.requires_grad:
                 p._mg_touched = False
+                if hasattr(p, "_mg_regions"):
+                    p._mg_regions = {}       # per-region state of parameters used through ops.param_view
 
     def collect_autograd_grads(self):
         """Gradients delivered by autograd into ``.grad`` (small broadcast parameters: queries, mask token, position tables) move
@@ -146,6 +148,8 @@ class FlatUnit:
         self.collect_autograd_grads()
         for _, p, _ in self.params:
             if p.requires_grad:
+                if not p._mg_touched and any(getattr(p, "_mg_regions", {}).values()):
+                    p._mg_touched = True     # written through its views (packed in_proj weights, conv weights used as matrices)
                 if not p._mg_touched and p._mg_dirty:
                     p.main_grad.zero_()
                     p._mg_dirty = False

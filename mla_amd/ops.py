@@ -711,10 +711,11 @@ def param_view(param: torch.Tensor, lo: Optional[int] = None, hi: Optional[int] 
     if mg is not None:
         g = mg if lo is None else mg[lo:hi]
         v.main_grad = g.view(shape) if shape is not None else g
-        if not hasattr(param, "_mg_regions") or not getattr(param, "_mg_touched", False):
-            param._mg_regions = {}    # first view of this accumulation window (FlatUnit.begin_step cleared _mg_touched)
+        if not hasattr(param, "_mg_regions"):
+            param._mg_regions = {}    # region -> "main_grad region holds a contribution from this accumulation window"; cleared by
+                                      # FlatUnit.begin_step, set only INSIDE the backward that writes the region (_mark_touched), so an
+                                      # eval / no_grad forward or an unused branch leaves the parameter untouched
         v._mg_region = (param, (lo, hi))
-        param._mg_touched = True      # every region of the parameter is written each step by its views
     return v
 
 

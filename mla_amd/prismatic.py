@@ -321,6 +321,9 @@ class PrismaticVLM(nn.Module):
         x = x.to(bf16) if x is not None else None
         t = t.to(bf16) if t is not None else None
         tag_0 = 2 if self.training else 29871                              # :882-887
+        # every row must contain the splice tag: the reference's `torch.where(mask)[0][-1]` raises IndexError otherwise
+        # (prismatic.py:983); the verdict is read back behind the synchronisation point below, like the pixel-mask one
+        tag_present = (input_ids == tag_0).any(dim=1).all()
 
         parts, patch_indices, valid_mask, pos_pc_tac, lin_img_tac, _ = self.get_fused_tokens(images, point_cloud, tactile, gripper_xyz,
                                                                                         camera_name)
@@ -330,6 +333,9 @@ class PrismaticVLM(nn.Module):
             # barely started the step, instead of after the decoder forward where the same sync drains a full launch queue
             valid_mask._mla_valid_index = torch.nonzero(valid_mask.reshape(-1), as_tuple=False).squeeze(-1)
         self.vision_tower_2d.assert_masks_ok()      # pixel-mask verdict of the vision tokenizer (free behind the sync above)
+        if not bool(tag_present):
+            raise IndexError(f"input_ids row without the splice tag {tag_0}: the reference indexes the last occurrence "
+                             "(models/vlm/prismatic.py:983) and fails the same way")
         n_fused = sum(p.shape[1] for p in parts)
         N_pc = N_img = 256
         pc_idx = (1, 1 + N_pc)
