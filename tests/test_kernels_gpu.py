@@ -307,6 +307,50 @@ def test_attention_bwd_fused_rope_is_bit_identical(dev):
         assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
 
 
+def test_attention_full_size_config4_properties(dev):
+    """BASELINE configs[4] attention at FULL size (S = 2048, 32 heads x 128; 2 sequences, one ragged) through size-independent
+    properties, no CPU reference needed:
+      * causality: changing q / k / v at positions >= t0 leaves outputs, lse and dq / dk / dv of positions < t0 BIT-identical;
+      * padding: rows >= seqlen give zero output and zero dq / dk / dv (flash / varlen semantics, modeling_llama.py:531-553);
+      * linearity of the backward in dout: bwd(2 * dout) == 2 * bwd(dout) exactly (power-of-two scaling commutes with every rounding)."""
+    from mla_amd import hip
+    B, S, H, D = 2, 2048, 32, 128
+    t0 = 1234
+    qkv = bfr(B * S, 3 * H * D, seed=41, scale=0.6).to(dev)
+    do = bfr(B * S, H * D, seed=42).to(dev)
+    sl = torch.tensor([2048, 1531], dtype=torch.int32, device=dev)
+    sc = 1 / math.sqrt(D)
+
+    def run(x, d):
+        q, k, v = x[:, :H * D], x[:, H * D:2 * H * D], x[:, 2 * H * D:]
+        o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, sl, sc)
+        g = torch.zeros_like(x)
+        hip.attn_bwd(q, k, v, o, d, lse, sl, g[:, :H * D], g[:, H * D:2 * H * D], g[:, 2 * H * D:], B, S, H, D, 3 * H * D, sc)
+        return o, lse, g
+    o1, lse1, g1 = run(qkv, do)
+    assert torch.isfinite(o1.float()).all() and torch.isfinite(g1.float()).all()
+    # padding rows of the ragged sequence
+    pad = slice(S + 1531, 2 * S)
+    assert float(o1[pad].float().abs().max()) == 0.0 and float(g1[pad].float().abs().max()) == 0.0
+    # causality of the forward: perturb everything at positions >= t0 (both sequences)
+    x2 = qkv.clone()
+    late = torch.zeros(B * S, dtype=torch.bool, device=dev)
+    late.view(B, S)[:, t0:] = True
+    x2[late] = bfr(int(late.sum()), 3 * H * D, seed=43, scale=0.6).to(dev)
+    o2, lse2, _ = run(x2, do)
+    early = ~late
+    assert torch.equal(o1[early], o2[early]) and torch.equal(lse1[:, :, :t0], lse2[:, :, :t0])
+    # causality of the backward: gradients flowing only into late rows leave dq of early rows at zero, and a dout change on late
+    # rows cannot change dq of early rows at all
+    d3 = do.clone()
+    d3[late] = bfr(int(late.sum()), H * D, seed=44).to(dev)
+    _, _, g3 = run(qkv, d3)
+    assert torch.equal(g1[early][:, :H * D], g3[early][:, :H * D])           # dq of early queries sees only their own dout row
+    # linearity in dout (exact for a power-of-two factor)
+    _, _, g4 = run(qkv, do * 2)
+    assert torch.equal(g4.float(), g1.float() * 2)
+
+
 def test_ce_and_l2norm_and_infonce(dev):
     from mla_amd import hip
     rows, V = 50, 32064

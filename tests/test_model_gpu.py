@@ -182,6 +182,43 @@ def test_decoder_layer_at_7b_dimensions(dev):
         assert v < bounds.get(k, bounds["default"]), (k, v)
 
 
+def test_decoder_layer_config4_recompute_is_bit_identical(dev):
+    """BASELINE configs[4] shape on one decoder layer at 7B dimensions (S = 2048, one ragged sequence of two): activation
+    checkpointing (save level 0 = recompute the whole forward in the backward, training/strategies/fsdp.py:211-223) must give
+    BIT-identical outputs and gradients to keeping every intermediate (level 2) and to the default level 1 -- the recompute runs
+    the same kernels on the same inputs, so any difference is a bug in what is saved or re-derived."""
+    from mla_amd import ops
+    H, I, nh, B, S = 4096, 11008, 32, 2, 2048
+    g = torch.Generator().manual_seed(11)
+    shapes = [(H,), (H, H), (H, H), (H, H), (H, H), (H,), (I, H), (I, H), (H, I)]
+    w32 = [((torch.ones(s) + 0.1 * torch.randn(s, generator=g)) if len(s) == 1 else 0.02 * torch.randn(s, generator=g)) for s in shapes]
+    # q|k|v and gate|up contiguous, like the flat unit buffers, so the fused GEMM paths are the ones exercised
+    flat = torch.cat([t.reshape(-1) for t in w32]).to(BF).to(dev)
+    x = torch.randn(B, S, H, generator=g).to(BF).to(dev)
+    dy = torch.randn(B, S, H, generator=g).to(BF).to(dev)
+    seqlens = torch.tensor([S, 1777], dtype=torch.int32, device=dev)
+    cos, sin = O.rope_tables(S, H // nh)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    res = {}
+    for lvl in (2, 1, 0):
+        ws, off = [], 0
+        for sshape in shapes:
+            n = int(np.prod(sshape))
+            ws.append(flat[off:off + n].view(sshape).detach().requires_grad_(True))
+            off += n
+        xd = x.clone().requires_grad_(True)
+        out = ops.decoder_layer(xd, seqlens, cos, sin, nh, 1e-5, lvl, ws)
+        out.backward(dy)
+        res[lvl] = (out.detach(), xd.grad, [w.grad for w in ws])
+        assert torch.isfinite(out.float()).all() and torch.isfinite(xd.grad.float()).all()
+    for lvl in (1, 0):
+        assert torch.equal(res[lvl][0], res[2][0]) and torch.equal(res[lvl][1], res[2][1]), lvl
+        for a, b in zip(res[lvl][2], res[2][2]):
+            assert torch.equal(a, b), lvl
+    # ragged sequence: padded rows produce no gradient for their inputs through attention, and the output there is finite
+    assert float(res[2][1][1, 1777:].float().abs().max()) < 1e4
+
+
 def _run_hip_e2e(dev, save_level=2):
     m = build_tiny_mla(dev, save_level)
     batch, draws = recipe.make_batch(R=2)
