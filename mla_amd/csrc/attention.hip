@@ -195,7 +195,7 @@ constexpr int DQ_RB = DQ_NW == 8 ? 1 : MLA_ATTN_RB;
 
 template <int RB, int MASK>
 __device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], f32x4_t (&ot)[RB][8],
-                                         float (&m)[RB], float (&l)[RB], const int (&myq)[RB], const int (&grow0)[RB], int kt,
+                                         float (&m)[RB], f32x4_t (&l)[RB], const int (&myq)[RB], const int (&grow0)[RB], int kt,
                                          int lane, float sc2) {
   const int g = lane >> 4;
   f32x4_t st[RB][4];
@@ -231,26 +231,30 @@ __device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const
     const float mnew = fmaxf(m[rb], mx);
     const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
     const float alpha = __builtin_amdgcn_exp2f(m[rb] - msafe);
-    float rs = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(st[rb][f][r], sc2, -msafe));   // scale folded into the exponent's fma
-        st[rb][f][r] = e;
-        rs += e;
-      }
-    rs = group_sum(rs);
-    l[rb] = l[rb] * alpha + rs;
+      for (int r = 0; r < 4; ++r)
+        st[rb][f][r] = __builtin_amdgcn_exp2f(fmaf(st[rb][f][r], sc2, -msafe));   // scale folded into the exponent's fma
     m[rb] = mnew;
     // lazy rescale: once the running maximum has settled (most tiles of a causal row block) alpha == 1 in every lane of the
     // wave and the 64 output accumulators need no multiply -- wave-uniform test, skips 32 packed multiplies per row block
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) ot[rb][i] *= alpha;
+      l[rb] *= alpha;
     }
     pf[rb][0] = pack_frag(st[rb][0], st[rb][1]);
     pf[rb][1] = pack_frag(st[rb][2], st[rb][3]);
+    // row sums on the matrix pipe (30 % busy) instead of the VALU (the bottleneck: 58 % busy): an all-ones A fragment makes every
+    // row of the 16 x 16 result the column sum of P^T, so each lane ends up with sum_k p[k][its query] -- 2 MFMAs replace 16 adds
+    // and a cross-row reduction per tile. The sum is over the bf16-rounded probabilities, the same values P V is computed from.
+    {
+      union { bf16x8_t v; uint32_t w[4]; } ones;
+      ones.w[0] = ones.w[1] = ones.w[2] = ones.w[3] = 0x3f803f80u;
+      l[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pf[rb][0], l[rb], 0, 0, 0);
+      l[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, pf[rb][1], l[rb], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int fd = 0; fd < 8; ++fd)
@@ -304,15 +308,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
   }
 
   bf16x8_t qf[RB][4];
-  f32x4_t ot[RB][8];
-  float m[RB], l[RB];
+  f32x4_t ot[RB][8], l[RB];
+  float m[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     load_row_frags(qb_ + (long long)(myq[rb] < p.S ? myq[rb] : p.S - 1) * p.ld, lane, qf[rb]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) ot[rb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     m[rb] = -INFINITY;
-    l[rb] = 0.f;
+    l[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
   const float sc2 = p.scale * LOG2E;
 
@@ -354,7 +358,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
     if (myq[rb] < p.S) {
       bf16_t* orow = p.o + ((long long)b * p.S + myq[rb]) * p.ld_o + h * D;
       const bool pad = myq[rb] >= seqlen;
-      const float inv = (pad || l[rb] == 0.f) ? 0.f : 1.f / l[rb];
+      const float lsum = l[rb][0];                  // all four entries hold the row sum
+      const float inv = (pad || lsum == 0.f) ? 0.f : 1.f / lsum;
 #pragma unroll
       for (int fd = 0; fd < 8; ++fd) {
         u32x2_t w;
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
         w[1] = pack2bf(ot[rb][fd][2] * inv, ot[rb][fd][3] * inv);
         *(u32x2_t*)(orow + fd * 16 + g * 4) = w;
       }
-      if (g == 0) lse_p[myq[rb]] = pad ? INFINITY : (m[rb] * LN2 + logf(l[rb]));
+      if (g == 0) lse_p[myq[rb]] = pad ? INFINITY : (m[rb] * LN2 + logf(lsum));
     }
 }
 
