@@ -89,6 +89,9 @@ def cpu_baseline(seconds_budget=28.0):
             t0 = time.time()
             O.decoder_layer(x, p, cos, sin, nh, 1e-5).sum().backward()
             times.append(time.time() - t0)
+            best_so_far = min((v[0] for v in sweep.values()), default=None)
+            if best_so_far is not None and times[-1] > 3 * best_so_far:
+                break                                  # hopeless thread count (oversubscribed host): one iteration is evidence enough
             if time.time() - t_start > 0.55 * seconds_budget and len(times) >= 2:
                 break
         sweep[nthreads] = (statistics.median(times[1:]) if len(times) > 1 else times[0], len(times))
