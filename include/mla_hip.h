@@ -53,6 +53,12 @@ int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const
 int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const float* rope_cos,
                       const float* rope_sin, int S, int rope_cols, mla_stream_t stream);
 
+/* fused down-projection dgrad + SwiGLU backward (autograd of LlamaMLP.forward modeling_llama.py:240): d(act) = dy[M, K] wT[I, K]^T is
+ * consumed in the GEMM epilogue -- gate|up (gu [M, 2I]) is read there and d(gate|up) is written in both layouts, dgu [M, 2I] and
+ * dguT [2I, ldt]; bit-identical to mla_gemm_bf16 followed by mla_swiglu_bwd_t. M, I >= 256, K % 64 == 0, M % 8 == 0. */
+int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const void* gu, void* dgu, void* dguT, int M, int I, int K, int lda,
+                             int ldb, long long ldt, mla_stream_t stream);
+
 /* ---- RMSNorm: LlamaRMSNorm.forward modeling_llama.py:76-90; timm RmsNorm in FinalLayer (models/diffusion/models.py:177) */
 int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int H, float eps, mla_stream_t stream);
 int mla_rmsnorm_bwd_blocks(int rows);

@@ -86,6 +86,15 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
   return w;
 }
 
+// SwiGLU backward of one element (autograd of LlamaMLP.forward, modeling_llama.py:240): d = d(act), act = silu(g) * u.
+// ONE definition for the stand-alone kernel (transpose.hip) and the fused GEMM epilogue (gemm256.hip): identical results, bit for bit.
+__device__ __forceinline__ void swiglu_bwd_elem(float d, float g, float u, float& dg, float& du) {
+  const float sg = 1.f / (1.f + __expf(-g));
+  const float sl = g * sg;
+  dg = d * u * (sg + sl * (1.f - sg));
+  du = d * sl;
+}
+
 // async global -> LDS copy of 16 B per lane: LDS destination = wave-uniform base + lane*16.
 #ifndef MLA_GLDS_AUX
 #define MLA_GLDS_AUX 0   // cache-policy bits of the LDS-DMA loads. Measured on gemm256 (4 shapes, A/B in one box): 1 (sc0) +-0.5 %,

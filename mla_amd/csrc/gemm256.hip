@@ -306,6 +306,80 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
       }
       __syncthreads();
+      if (p.sw_gu) {
+        // ---- fused SwiGLU backward (mla_gemm_dact_swiglu_bwd): the staged tile is d(act)[256 tokens][256 channels], rounded to bf16
+        // exactly like the stand-alone GEMM would have stored it. Four strips of 64 tokens: (a) every thread takes four 8-channel
+        // pieces, reads gate / up from HBM (whole 512-B row runs), applies swiglu_bwd_elem, stores d(gate) / d(up) row-major;
+        // (b) the same values go back into LDS TRANSPOSED -- into the strip's own, now consumed rows of the image and into 32 KiB
+        // beyond the operand ring -- as [channel][token] lines of 128 B whose token slot is XORed with 2 x piece index (bank-
+        // conflict-free 2-byte writes); (c) the lines are read back as 16-B pieces of 8 tokens (undoing the XOR: piece index and a
+        // dword permutation) and stored to d(gate|up)^T. d(act) costs no HBM traffic at all (was: 1 write + 1 read per element).
+        const int I = p.sw_I;
+        char* scrB = smem + 2 * BUF;
+        const size_t ld2 = (size_t)2 * I;
+        for (int s4 = 0; s4 < 4; ++s4) {
+          char* scrA = smem + s4 * 64 * 512;
+          u32x4_t pg[4], pu[4];
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int idx = tid + 512 * k4;
+            const int rl = idx >> 5, ch = idx & 31;
+            const int row = s4 * 64 + rl;
+            const int m = m0 + row, n = n0 + ch * 8;
+            pg[k4] = u32x4_t{0u, 0u, 0u, 0u};
+            pu[k4] = pg[k4];
+            if (m < p.M && n < p.N) {
+              float dv[8], gv[8], uv[8], dg[8], du[8];
+              unpack8(*(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)), dv);
+              unpack8(*(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + n), gv);
+              unpack8(*(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + I + n), uv);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) swiglu_bwd_elem(dv[j], gv[j], uv[j], dg[j], du[j]);
+              pg[k4] = pack8(dg);
+              pu[k4] = pack8(du);
+              *(u32x4_t*)(p.sw_dgu + (size_t)m * ld2 + n) = pg[k4];
+              *(u32x4_t*)(p.sw_dgu + (size_t)m * ld2 + I + n) = pu[k4];
+            }
+          }
+          __syncthreads();           // the strip's rows of the d(act) image have been consumed by everyone
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int idx = tid + 512 * k4;
+            const int rl = idx >> 5, ch = idx & 31;
+            const int slot2 = (rl ^ (2 * ch)) * 2;                      // byte offset of the token slot inside a 128-B channel line
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c0 = (ch * 8 + 2 * j) * 128 + slot2;
+              *(unsigned short*)(scrA + c0) = (unsigned short)(pg[k4][j] & 0xffffu);
+              *(unsigned short*)(scrA + c0 + 128) = (unsigned short)(pg[k4][j] >> 16);
+              *(unsigned short*)(scrB + c0) = (unsigned short)(pu[k4][j] & 0xffffu);
+              *(unsigned short*)(scrB + c0 + 128) = (unsigned short)(pu[k4][j] >> 16);
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int idx = tid + 512 * k4;
+            const int col = idx >> 3, rc = idx & 7;
+            const int chc = col >> 3;                                   // the piece index the writer XORed with
+            const int off = col * 128 + ((rc ^ (chc >> 2)) << 4);
+            const int b = chc & 3;
+            const int m = m0 + s4 * 64 + rc * 8, n = n0 + col;
+            if (m < p.M && n < p.N) {
+#pragma unroll
+              for (int which = 0; which < 2; ++which) {
+                u32x4_t w = *(const u32x4_t*)((which ? scrB : scrA) + off);
+                if (b & 1) w = u32x4_t{w[1], w[0], w[3], w[2]};
+                if (b & 2) w = u32x4_t{w[2], w[3], w[0], w[1]};
+                *(u32x4_t*)(p.sw_dguT + (size_t)(which * I + n) * p.sw_ldt + m) = w;
+              }
+            }
+          }
+          // no barrier here: the next strip's compute phase touches only ITS rows of the image and ends with a barrier before
+          // anything is written to scrB / its scrA again
+        }
+        return;
+      }
       const int ch = lane & 31;
       const int n = n0 + ch * 8;
       if (p.rope_cos && n0 < p.rope_cols) {
@@ -838,6 +912,13 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
     const int tail = num_m * num_n - p.sk_full;
     hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(p.sk_full + tail * p.sk_split), dim3(512), 2 * BUF, stream, p);
     hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
+  } else if (p.sw_gu) {
+    static bool attr_sw = false;      // the fused SwiGLU-backward epilogue stages a second transposed strip in 32 KiB beyond the ring
+    if (!attr_sw) {
+      hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 32768);
+      attr_sw = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF + 32768, stream, p);
   } else {
     hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
   }
@@ -868,6 +949,24 @@ extern "C" int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, i
   p.alpha = 1.f;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_S = S; p.rope_cols = rope_cols;
   return mla_gemm256_dispatch(&p, 0, 0, 0, stream);     // no split-K tail (its fix-up pass has no rotary epilogue)
+}
+
+// Fused d(act) GEMM + SwiGLU backward: d(act) = dy[M, K] wT[I, K]^T stays on the chip; outputs d(gate|up) [M, 2I] and its transpose
+// [2I, ldt]. Replaces hip.gemm + mla_swiglu_bwd_t in the MLP backward (autograd of modeling_llama.py:240); bit-identical to them.
+extern "C" int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const void* gu, void* dgu, void* dguT, int M, int I, int K,
+                                        int lda, int ldb, long long ldt, hipStream_t stream) {
+  MLA_CHECK_ARG(dy && wT && gu && dgu && dguT, "mla_gemm_dact_swiglu_bwd: null pointer");
+  MLA_CHECK_ARG(M >= 256 && I >= 256 && K > 0 && K % 64 == 0 && I % 8 == 0 && M % 8 == 0,
+                "mla_gemm_dact_swiglu_bwd: needs M, I >= 256, K %% 64 == 0, I %% 8 == 0, M %% 8 == 0");
+  MLA_CHECK_ARG(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 && ldt >= M && ldt % 8 == 0,
+                "mla_gemm_dact_swiglu_bwd: leading dimensions must be multiples of 8 (ldt >= M)");
+  MLA_CHECK_ARG(((((uintptr_t)dy) | ((uintptr_t)wT) | ((uintptr_t)gu) | ((uintptr_t)dgu) | ((uintptr_t)dguT)) & 15) == 0,
+                "mla_gemm_dact_swiglu_bwd: 16-B alignment required");
+  GemmArgs p{};
+  p.A = (const bf16_t*)dy; p.B = (const bf16_t*)wT; p.C = dgu /* never written: the epilogue returns before the plain stores */;
+  p.M = M; p.N = I; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = 2 * I; p.alpha = 1.f;
+  p.sw_gu = (const bf16_t*)gu; p.sw_dgu = (bf16_t*)dgu; p.sw_dguT = (bf16_t*)dguT; p.sw_I = I; p.sw_ldt = ldt;
+  return mla_gemm256_dispatch(&p, 0, 0, 0, stream);     // no split-K tail (its fix-up pass has no SwiGLU epilogue)
 }
 
 // called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>

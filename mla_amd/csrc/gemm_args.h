@@ -26,4 +26,12 @@ struct GemmArgs {
   const float* rope_cos;
   const float* rope_sin;
   int rope_S, rope_cols;
+  // gemm256 bf16 fast epilogue only: the product C is d(act) of a SwiGLU MLP and never leaves the chip -- the epilogue reads gate|up
+  // (sw_gu [M, 2 sw_I]), applies the SwiGLU backward and writes d(gate|up) in both layouts: sw_dgu [M, 2 sw_I] and sw_dguT
+  // [2 sw_I, sw_ldt] (mla_gemm_dact_swiglu_bwd). N == sw_I.
+  const bf16_t* sw_gu;
+  bf16_t* sw_dgu;
+  bf16_t* sw_dguT;
+  int sw_I;
+  long long sw_ldt;
 };

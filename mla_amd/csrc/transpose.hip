@@ -99,12 +99,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const bf16_t* __restr
       float gv[8], uv[8], dv[8], dg[8], du[8];
       unpack8(g, gv); unpack8(u, uv); unpack8(d, dv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float sg = 1.f / (1.f + __expf(-gv[j]));
-        const float sl = gv[j] * sg;
-        dg[j] = dv[j] * uv[j] * (sg + sl * (1.f - sg));
-        du[j] = dv[j] * sl;
-      }
+      for (int j = 0; j < 8; ++j) swiglu_bwd_elem(dv[j], gv[j], uv[j], dg[j], du[j]);
       const u32x4_t pg = pack8(dg), pu = pack8(du);
       *(u32x4_t*)(dgu + r * 2 * I + c) = pg;
       *(u32x4_t*)(dgu + r * 2 * I + I + c) = pu;

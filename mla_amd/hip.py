@@ -35,6 +35,8 @@ _SIGNATURES = {
                          c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p],
     "mla_gemm_qkv_rope": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                           c_void_p],
+    "mla_gemm_dact_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
+                                 c_void_p],
     "mla_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "mla_rmsnorm_bwd_blocks": [c_int],
     "mla_timm_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
@@ -227,6 +229,30 @@ def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols):
         ev1.record()
         prof.append((ev0, ev1, 2.0 * T * N * K, (0, 0, T, N, K)))
     return True
+
+
+def gemm_dact_swiglu_bwd(dy2d, wT, gu2d):
+    """(dgu [T, 2I], dguT [2I, T]) = SwiGLU backward of d(act) = dy2d @ wT^T without ever writing d(act); None when the shape is outside
+    the fused kernel's contract (the caller then runs gemm + swiglu_bwd_t)."""
+    T, K = dy2d.shape
+    I = wT.shape[0]
+    ok = (T >= 256 and I >= 256 and K % 64 == 0 and I % 8 == 0 and T % 8 == 0 and gu2d.shape == (T, 2 * I) and gu2d.is_contiguous() and
+          dy2d.stride(0) % 8 == 0 and wT.stride(0) % 8 == 0 and all(t.data_ptr() % 16 == 0 for t in (dy2d, wT, gu2d)))
+    if not ok:
+        return None
+    _req(dy2d, torch.bfloat16, "gemm_dact_swiglu_bwd dy")
+    _req(wT, torch.bfloat16, "gemm_dact_swiglu_bwd wT")
+    dgu = torch.empty_like(gu2d)
+    dguT = torch.empty((2 * I, T), dtype=torch.bfloat16, device=gu2d.device)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("mla_gemm_dact_swiglu_bwd", _p(dy2d), _p(wT), _p(gu2d), _p(dgu), _p(dguT), T, I, K, dy2d.stride(0), wT.stride(0), T)
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * T * I * K, (0, 0, T, I, K)))
+    return dgu, dguT
 
 
 # --------------------------------------------------------------------------------------------- norms

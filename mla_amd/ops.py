@@ -454,6 +454,7 @@ def info_nce(a, b, M, temperature):
 
 # ------------------------------------------------------------------------------------------------- decoder layer
 _ROPE_EPILOGUE = os.environ.get("MLA_ROPE_EPILOGUE", "1") != "0"   # A/B switch (tools): 0 = separate RoPE pass after the QKV GEMM
+_SWIGLU_BWD_EPILOGUE = os.environ.get("MLA_SWIGLU_BWD_EPILOGUE", "1") != "0"   # A/B switch: 0 = d(act) GEMM + separate SwiGLU backward
 _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (tools): 0 = recompute act^T in the backward
 
 
@@ -575,19 +576,24 @@ class DecoderLayerFn(torch.autograd.Function):
             return hip.transpose(wc if wc is not None else torch.cat(list(ws), 0))
 
         # ---- MLP: down projection
-        dact = hip.gemm(d2, wT((wd,)))                                   # [T, I]
+        want_w = need[6] or need[7]
+        wdT = wT((wd,))
+        fused = hip.gemm_dact_swiglu_bwd(d2, wdT, gu) if (want_w and _SWIGLU_BWD_EPILOGUE) else None   # d(act) never leaves the chip
+        dact = hip.gemm(d2, wdT) if fused is None else None              # [T, I]
+        del wdT
         if need[8]:
             actT = actT_saved if actT_saved is not None else (hip.swiglu_fwd_t(gu) if act_ is None else hip.transpose(act_))
             grads[8] = deliver_wgrad_nt((wd,), hip.transpose(d2), actT, need[8:9])[0]
             del actT
         act_ = actT_saved = None
-        want_w = need[6] or need[7]
-        fuse_t = want_w and dact.shape[0] % 8 == 0       # dgu and dgu^T from one pass (saves re-reading the 2I-wide gradient)
-        if fuse_t:
+        fuse_t = want_w and gu.shape[0] % 8 == 0         # dgu and dgu^T from one pass (saves re-reading the 2I-wide gradient)
+        if fused is not None:
+            dgu, dguT = fused
+        elif fuse_t:
             dgu, dguT = hip.swiglu_bwd_t(dact, gu)
         else:
             dgu, _ = hip.swiglu_bwd(dact, gu)
-        del dact
+        del dact, fused
         # ---- MLP: gate | up projection
         dxn2 = hip.gemm(dgu, wT((wg, wu)))                               # [T, H], K = 2I
         if want_w:

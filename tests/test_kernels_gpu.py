@@ -286,6 +286,28 @@ def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, T, S, nh):
     assert fro_rel(got, qr) < 6e-3
 
 
+@pytest.mark.parametrize("T,I,K", [(512, 512, 256), (1096, 768, 128), (264, 256, 64)])
+def test_dact_gemm_with_swiglu_bwd_epilogue_is_bit_identical(dev, T, I, K):
+    """mla_gemm_dact_swiglu_bwd == mla_gemm_bf16 (d(act)) + mla_swiglu_bwd_t, bit for bit, for d(gate|up) in both layouts (tile edges:
+    T % 256 != 0 with T % 8 == 0; several column tiles), and against fp32 autograd of silu(g) * u."""
+    from mla_amd import hip
+    dy = bfr(T, K, seed=51).to(dev)
+    wT = bfr(I, K, seed=52, scale=0.2).to(dev)
+    gu = bfr(T, 2 * I, seed=53).to(dev)
+    dact = hip.gemm(dy, wT)
+    ref_dgu, ref_dguT = hip.swiglu_bwd_t(dact, gu)
+    out = hip.gemm_dact_swiglu_bwd(dy, wT, gu)
+    assert out is not None
+    dgu, dguT = out
+    assert torch.equal(dgu, ref_dgu), float((dgu.float() - ref_dgu.float()).abs().max())
+    assert torch.equal(dguT, ref_dguT), float((dguT.float() - ref_dguT.float()).abs().max())
+    assert torch.equal(dguT, dgu.t().contiguous())
+    g = gu[:, :I].float().cpu().requires_grad_(True)
+    u = gu[:, I:].float().cpu().requires_grad_(True)
+    (F.silu(g) * u).backward((dy.float().cpu() @ wT.float().cpu().t()).to(BF).float())
+    assert fro_rel(dgu[:, :I], g.grad) < 5e-3 and fro_rel(dgu[:, I:], u.grad) < 5e-3
+
+
 def test_attention_bwd_fused_rope_is_bit_identical(dev):
     """mla_attn_bwd with the RoPE tables == mla_attn_bwd followed by mla_rope_inplace(backward=True) on dq | dk, bit for bit
     (full and ragged sequences; apply_rotary_pos_emb backward, modeling_llama.py:184-208)."""
