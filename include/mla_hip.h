@@ -53,6 +53,11 @@ int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const
 int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const float* rope_cos,
                       const float* rope_sin, int S, int rope_cols, mla_stream_t stream);
 
+/* fused gate|up projection + SwiGLU (LlamaMLP.forward modeling_llama.py:240): gu[M, 2I] = x[M, K] wgu[2I, K]^T (wgu = gate rows then up
+ * rows), act[M, I] = silu(gate) * up and, if actT != NULL, actT[I, ldt] = act^T, all from one GEMM launch; bit-identical to
+ * mla_gemm_bf16 followed by mla_swiglu_fwd_dual. M >= 256, I % 128 == 0, K % 64 == 0. */
+int mla_gemm_gateup_swiglu(const void* x, const void* wgu, void* gu, void* act, void* actT, int M, int I, int K, int lda, int ldb,
+                           long long ldt, mla_stream_t stream);
 /* fused down-projection dgrad + SwiGLU backward (autograd of LlamaMLP.forward modeling_llama.py:240): d(act) = dy[M, K] wT[I, K]^T is
  * consumed in the GEMM epilogue -- gate|up (gu [M, 2I]) is read there and d(gate|up) is written in both layouts, dgu [M, 2I] and
  * dguT [2I, ldt]; bit-identical to mla_gemm_bf16 followed by mla_swiglu_bwd_t. M, I >= 256, K % 64 == 0, M % 8 == 0. */

@@ -86,6 +86,13 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
   return w;
 }
 
+// SwiGLU forward of one element: silu(g) * u on bf16-rounded inputs, fp32 arithmetic, rounded once by the caller
+// (LlamaMLP.forward, modeling_llama.py:240). One definition for the stand-alone kernels and the fused GEMM epilogue.
+__device__ __forceinline__ float swiglu_fwd_elem(float g, float u) {
+  const float sg = 1.f / (1.f + __expf(-g));
+  return (g * sg) * u;
+}
+
 // SwiGLU backward of one element (autograd of LlamaMLP.forward, modeling_llama.py:240): d = d(act), act = silu(g) * u.
 // ONE definition for the stand-alone kernel (transpose.hip) and the fused GEMM epilogue (gemm256.hip): identical results, bit for bit.
 __device__ __forceinline__ void swiglu_bwd_elem(float d, float g, float u, float& dg, float& du) {

@@ -115,6 +115,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
     pA0[it] = stage_src<AMODE, true>(p.A, p.lda, m0, p.M, 0, wave * 2 + it, lane);
     pA1[it] = stage_src<AMODE, true>(p.A, p.lda, m0, p.M, 1, wave * 2 + it, lane);
+    if (p.sf_I) {   // fused gate|up + SwiGLU: left half-tile = 128 gate rows, right half-tile = the 128 matching up rows of the packed weight
+      pB0[it] = stage_src<BMODE, false>(p.B, p.ldb, pid_n * 128, p.sf_I, 0, wave * 2 + it, lane);
+      pB1[it] = stage_src<BMODE, false>(p.B, p.ldb, p.sf_I + pid_n * 128 - 128, 2 * p.sf_I, 1, wave * 2 + it, lane);
+      continue;
+    }
     pB0[it] = stage_src<BMODE, false>(p.B, p.ldb, n0, p.N, 0, wave * 2 + it, lane);
     pB1[it] = stage_src<BMODE, false>(p.B, p.ldb, n0, p.N, 1, wave * 2 + it, lane);
   }
@@ -306,6 +311,69 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
       }
       __syncthreads();
+      if (p.sf_I) {
+        // ---- fused SwiGLU forward (mla_gemm_gateup_swiglu): image columns 0..127 = gate, 128..255 = up of channels [128 pid_n, +128).
+        // Per strip of 64 tokens: gate|up rows leave as two 256-B runs per row; act = swiglu_fwd_elem(g, u) is stored row-major and --
+        // when the caller keeps it for the backward -- goes back into the strip's own (consumed) image rows as [channel][token] lines
+        // (token slot XORed with 2 x piece index) and leaves as 16-B pieces of 8 tokens, like the backward epilogue below.
+        const int I = p.sf_I, cbase = pid_n * 128;
+        const size_t ld2 = (size_t)2 * I;
+        for (int s4 = 0; s4 < 4; ++s4) {
+          char* scrA = smem + s4 * 64 * 512;
+          u32x4_t pa[2];
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int idx = tid + 512 * k4;
+            const int rl = idx >> 5, ch = idx & 31;
+            const int row = s4 * 64 + rl, m = m0 + row;
+            if (m < p.M)
+              *(u32x4_t*)((bf16_t*)p.C + (size_t)m * ld2 + (ch < 16 ? cbase + ch * 8 : I + cbase + (ch - 16) * 8)) =
+                  *(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4));
+          }
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const int idx = tid + 512 * k2;
+            const int rl = idx >> 4, c = idx & 15;
+            const int row = s4 * 64 + rl, m = m0 + row;
+            float gv[8], uv[8], o[8];
+            unpack8(*(const u32x4_t*)(smem + row * 512 + ((c ^ (row & 31)) << 4)), gv);
+            unpack8(*(const u32x4_t*)(smem + row * 512 + (((16 + c) ^ (row & 31)) << 4)), uv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = swiglu_fwd_elem(gv[j], uv[j]);
+            pa[k2] = pack8(o);
+            if (m < p.M) *(u32x4_t*)(p.sf_act + (size_t)m * I + cbase + c * 8) = pa[k2];
+          }
+          if (p.sf_actT == nullptr) continue;          // uniform: the caller does not keep the transposed product
+          __syncthreads();
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const int idx = tid + 512 * k2;
+            const int rl = idx >> 4, c = idx & 15;
+            const int slot2 = (rl ^ (2 * c)) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c0 = (c * 8 + 2 * j) * 128 + slot2;
+              *(unsigned short*)(scrA + c0) = (unsigned short)(pa[k2][j] & 0xffffu);
+              *(unsigned short*)(scrA + c0 + 128) = (unsigned short)(pa[k2][j] >> 16);
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) {
+            const int idx = tid + 512 * k2;
+            const int col = idx >> 3, rc = idx & 7;          // 128 channel lines x 8 pieces of 8 tokens
+            const int chc = col >> 3, b = chc & 3;
+            const int m = m0 + s4 * 64 + rc * 8;
+            if (m < p.M) {
+              u32x4_t w = *(const u32x4_t*)(scrA + col * 128 + ((rc ^ (chc >> 2)) << 4));
+              if (b & 1) w = u32x4_t{w[1], w[0], w[3], w[2]};
+              if (b & 2) w = u32x4_t{w[2], w[3], w[0], w[1]};
+              *(u32x4_t*)(p.sf_actT + (size_t)(cbase + col) * p.sf_ldt + m) = w;
+            }
+          }
+        }
+        return;
+      }
       if (p.sw_gu) {
         // ---- fused SwiGLU backward (mla_gemm_dact_swiglu_bwd): the staged tile is d(act)[256 tokens][256 channels], rounded to bf16
         // exactly like the stand-alone GEMM would have stored it. Four strips of 64 tokens: (a) every thread takes four 8-channel
@@ -949,6 +1017,23 @@ extern "C" int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, i
   p.alpha = 1.f;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_S = S; p.rope_cols = rope_cols;
   return mla_gemm256_dispatch(&p, 0, 0, 0, stream);     // no split-K tail (its fix-up pass has no rotary epilogue)
+}
+
+// Fused gate|up projection + SwiGLU: gu[M, 2I] = x[M, K] wgu[2I, K]^T (stored, the backward needs it), act = silu(gate) * up [M, I] and
+// (optional) its transpose [I, ldt]. Replaces hip.gemm + mla_swiglu_fwd_dual (LlamaMLP.forward modeling_llama.py:240); bit-identical.
+extern "C" int mla_gemm_gateup_swiglu(const void* x, const void* wgu, void* gu, void* act, void* actT, int M, int I, int K, int lda,
+                                      int ldb, long long ldt, hipStream_t stream) {
+  MLA_CHECK_ARG(x && wgu && gu && act, "mla_gemm_gateup_swiglu: null pointer");
+  MLA_CHECK_ARG(M >= 256 && I >= 128 && I % 128 == 0 && K > 0 && K % 64 == 0, "mla_gemm_gateup_swiglu: needs M >= 256, I %% 128 == 0, K %% 64 == 0");
+  MLA_CHECK_ARG(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0, "mla_gemm_gateup_swiglu: leading dimensions must be multiples of 8");
+  MLA_CHECK_ARG(actT == nullptr || (M % 8 == 0 && ldt >= M && ldt % 8 == 0), "mla_gemm_gateup_swiglu: transposed output needs M %% 8 == 0, ldt >= M, ldt %% 8 == 0");
+  MLA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wgu) | ((uintptr_t)gu) | ((uintptr_t)act) | ((uintptr_t)actT)) & 15) == 0,
+                "mla_gemm_gateup_swiglu: 16-B alignment required");
+  GemmArgs p{};
+  p.A = (const bf16_t*)x; p.B = (const bf16_t*)wgu; p.C = gu; p.M = M; p.N = 2 * I; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = 2 * I;
+  p.alpha = 1.f;
+  p.sf_I = I; p.sf_act = (bf16_t*)act; p.sf_actT = (bf16_t*)actT; p.sf_ldt = ldt;
+  return mla_gemm256_dispatch(&p, 0, 0, 0, stream);     // no split-K tail (its fix-up pass has no SwiGLU epilogue)
 }
 
 // Fused d(act) GEMM + SwiGLU backward: d(act) = dy[M, K] wT[I, K]^T stays on the chip; outputs d(gate|up) [M, 2I] and its transpose

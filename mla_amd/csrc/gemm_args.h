@@ -29,6 +29,14 @@ struct GemmArgs {
   // gemm256 bf16 fast epilogue only: the product C is d(act) of a SwiGLU MLP and never leaves the chip -- the epilogue reads gate|up
   // (sw_gu [M, 2 sw_I]), applies the SwiGLU backward and writes d(gate|up) in both layouts: sw_dgu [M, 2 sw_I] and sw_dguT
   // [2 sw_I, sw_ldt] (mla_gemm_dact_swiglu_bwd). N == sw_I.
+  // gemm256 bf16 fast epilogue only: fused gate|up projection + SwiGLU (mla_gemm_gateup_swiglu). N = 2 sf_I; workgroup column j
+  // computes gate channels [128 j, 128 j + 128) AND up channels [sf_I + 128 j, ...) (its B half-tiles come from the two halves of
+  // the packed weight), so every lane holds g and u of the same channel: C = gate|up [M, 2 sf_I] is stored as usual, and
+  // act = silu(g) u goes to sf_act [M, sf_I] and (optional) sf_actT [sf_I, sf_ldt].
+  int sf_I;
+  bf16_t* sf_act;
+  bf16_t* sf_actT;
+  long long sf_ldt;
   const bf16_t* sw_gu;
   bf16_t* sw_dgu;
   bf16_t* sw_dguT;

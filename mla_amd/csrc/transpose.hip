@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_dual_kernel(const bf16_t* __re
       unpack8(*(const u32x4_t*)(gu + r * 2 * I + c), g);
       unpack8(*(const u32x4_t*)(gu + r * 2 * I + I + c), u);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float sg = 1.f / (1.f + __expf(-g[j])); o[j] = (g[j] * sg) * u[j]; }   // = swiglu_fwd_kernel
+      for (int j = 0; j < 8; ++j) o[j] = swiglu_fwd_elem(g[j], u[j]);
       const u32x4_t pk = pack8(o);
       *(u32x4_t*)(act + r * I + c) = pk;
 #pragma unroll

@@ -35,6 +35,8 @@ _SIGNATURES = {
                          c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p],
     "mla_gemm_qkv_rope": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                           c_void_p],
+    "mla_gemm_gateup_swiglu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
+                               c_void_p],
     "mla_gemm_dact_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
                                  c_void_p],
     "mla_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
@@ -229,6 +231,31 @@ def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols):
         ev1.record()
         prof.append((ev0, ev1, 2.0 * T * N * K, (0, 0, T, N, K)))
     return True
+
+
+def gemm_gateup_swiglu(x2d, wgu, want_t):
+    """(gu [T, 2I], act [T, I], actT [I, T] or None) from ONE launch: the SwiGLU product is formed in the gate|up GEMM's epilogue.
+    None when the shape is outside the fused kernel's contract (the caller then runs gemm + swiglu_fwd[_dual])."""
+    T, K = x2d.shape
+    I = wgu.shape[0] // 2
+    ok = (T >= 256 and I % 128 == 0 and K % 64 == 0 and wgu.shape[0] == 2 * I and x2d.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0 and
+          (not want_t or T % 8 == 0) and all(t.data_ptr() % 16 == 0 for t in (x2d, wgu)))
+    if not ok:
+        return None
+    _req(x2d, torch.bfloat16, "gemm_gateup_swiglu x")
+    _req(wgu, torch.bfloat16, "gemm_gateup_swiglu w")
+    gu = torch.empty((T, 2 * I), dtype=torch.bfloat16, device=x2d.device)
+    act = torch.empty((T, I), dtype=torch.bfloat16, device=x2d.device)
+    actT = torch.empty((I, T), dtype=torch.bfloat16, device=x2d.device) if want_t else None
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("mla_gemm_gateup_swiglu", _p(x2d), _p(wgu), _p(gu), _p(act), _p(actT), T, I, K, x2d.stride(0), wgu.stride(0), T)
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * T * 2 * I * K, (0, 0, T, 2 * I, K)))
+    return gu, act, actT
 
 
 def gemm_dact_swiglu_bwd(dy2d, wT, gu2d):

@@ -454,6 +454,7 @@ def info_nce(a, b, M, temperature):
 
 # ------------------------------------------------------------------------------------------------- decoder layer
 _ROPE_EPILOGUE = os.environ.get("MLA_ROPE_EPILOGUE", "1") != "0"   # A/B switch (tools): 0 = separate RoPE pass after the QKV GEMM
+_SWIGLU_FWD_EPILOGUE = os.environ.get("MLA_SWIGLU_FWD_EPILOGUE", "1") != "0"   # A/B switch: 0 = gate|up GEMM + separate SwiGLU pass
 _SWIGLU_BWD_EPILOGUE = os.environ.get("MLA_SWIGLU_BWD_EPILOGUE", "1") != "0"   # A/B switch: 0 = d(act) GEMM + separate SwiGLU backward
 _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (tools): 0 = recompute act^T in the backward
 
@@ -494,18 +495,24 @@ class DecoderLayerFn(torch.autograd.Function):
         xn2, rstd2 = hip.rmsnorm_fwd(h1, ln2, eps)
         I = wg.shape[0]
         wgu = cat_view((wg, wu))
-        if wgu is not None:
-            gu = hip.gemm(xn2, wgu)
+        # fused gate|up projection + SwiGLU: the product (and, with save_t, its transposed copy for the backward's wgrad) is formed in the
+        # GEMM epilogue -- gu is written once and not read again in the forward pass
+        fused = hip.gemm_gateup_swiglu(xn2, wgu, save_t and h2.shape[0] % 8 == 0) if (wgu is not None and _SWIGLU_FWD_EPILOGUE) else None
+        if fused is not None:
+            gu, act_, actT = fused
         else:
-            gu = torch.empty((h2.shape[0], 2 * I), dtype=BF16, device=h2.device)
-            hip.gemm(xn2, wg, out=gu[:, :I])
-            hip.gemm(xn2, wu, out=gu[:, I:])
-        # save_t: the caller keeps the SwiGLU product for the backward in TRANSPOSED layout (the wgrad operand), written by the same
-        # pass that produces the row-major copy for the down projection
-        if save_t and gu.shape[0] % 8 == 0:
-            act_, actT = hip.swiglu_fwd_dual(gu)
-        else:
-            act_, actT = hip.swiglu_fwd(gu), None
+            if wgu is not None:
+                gu = hip.gemm(xn2, wgu)
+            else:
+                gu = torch.empty((h2.shape[0], 2 * I), dtype=BF16, device=h2.device)
+                hip.gemm(xn2, wg, out=gu[:, :I])
+                hip.gemm(xn2, wu, out=gu[:, I:])
+            # save_t: the caller keeps the SwiGLU product for the backward in TRANSPOSED layout (the wgrad operand), written by the
+            # same pass that produces the row-major copy for the down projection
+            if save_t and gu.shape[0] % 8 == 0:
+                act_, actT = hip.swiglu_fwd_dual(gu)
+            else:
+                act_, actT = hip.swiglu_fwd(gu), None
         out = hip.gemm(act_, wd, residual=h1)
         return out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT)
 

@@ -286,6 +286,24 @@ def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, T, S, nh):
     assert fro_rel(got, qr) < 6e-3
 
 
+@pytest.mark.parametrize("T,I,K", [(512, 512, 256), (1096, 640, 128), (264, 128, 64)])
+def test_gateup_gemm_with_swiglu_epilogue_is_bit_identical(dev, T, I, K):
+    """mla_gemm_gateup_swiglu == mla_gemm_bf16 (gate|up) + mla_swiglu_fwd_dual, bit for bit: gu, act and act^T (the workgroup column
+    takes its right half-tile from the up rows of the packed weight; T % 256 != 0, odd numbers of 128-channel column tiles), and
+    without the transposed output."""
+    from mla_amd import hip
+    x = bfr(T, K, seed=61).to(dev)
+    w = bfr(2 * I, K, seed=62, scale=0.2).to(dev)
+    ref_gu = hip.gemm(x, w)
+    ref_act, ref_actT = hip.swiglu_fwd_dual(ref_gu)
+    gu, act, actT = hip.gemm_gateup_swiglu(x, w, True)
+    assert torch.equal(gu, ref_gu) and torch.equal(act, ref_act) and torch.equal(actT, ref_actT)
+    gu2, act2, none = hip.gemm_gateup_swiglu(x, w, False)
+    assert none is None and torch.equal(gu2, ref_gu) and torch.equal(act2, ref_act)
+    ref = O.swiglu_mlp(x.float().cpu(), w[:I].float().cpu(), w[I:].float().cpu(), torch.eye(I))
+    assert fro_rel(act, ref) < 6e-3
+
+
 @pytest.mark.parametrize("T,I,K", [(512, 512, 256), (1096, 768, 128), (264, 256, 64)])
 def test_dact_gemm_with_swiglu_bwd_epilogue_is_bit_identical(dev, T, I, K):
     """mla_gemm_dact_swiglu_bwd == mla_gemm_bf16 (d(act)) + mla_swiglu_bwd_t, bit for bit, for d(gate|up) in both layouts (tile edges:
