@@ -57,7 +57,10 @@ __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* g, int ld, int 
   }
 }
 
-template <int AMODE, int BMODE>
+// EPI: 0 = plain epilogue (bias / residual / fp32 / fused RoPE by arguments), 1 = fused gate|up + SwiGLU forward, 2 = fused d(act) +
+// SwiGLU backward. Separate instantiations: the fused forms are different kernels (GEMM + an HBM-bound elementwise pass in the
+// epilogue) and show up under their own names in rocprofv3, so the plain kernel's statistics are not mixed with theirs.
+template <int AMODE, int BMODE, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const bool LGKM_BEFORE = false;
   const int GROUP_M = 4;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
     pA0[it] = stage_src<AMODE, true>(p.A, p.lda, m0, p.M, 0, wave * 2 + it, lane);
     pA1[it] = stage_src<AMODE, true>(p.A, p.lda, m0, p.M, 1, wave * 2 + it, lane);
-    if (p.sf_I) {   // fused gate|up + SwiGLU: left half-tile = 128 gate rows, right half-tile = the 128 matching up rows of the packed weight
+    if (EPI == 1) {   // fused gate|up + SwiGLU: left half-tile = 128 gate rows, right half-tile = the 128 matching up rows of the packed weight
       pB0[it] = stage_src<BMODE, false>(p.B, p.ldb, pid_n * 128, p.sf_I, 0, wave * 2 + it, lane);
       pB1[it] = stage_src<BMODE, false>(p.B, p.ldb, p.sf_I + pid_n * 128 - 128, 2 * p.sf_I, 1, wave * 2 + it, lane);
       continue;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
       }
       __syncthreads();
-      if (p.sf_I) {
+      if (EPI == 1) {
         // ---- fused SwiGLU forward (mla_gemm_gateup_swiglu): image columns 0..127 = gate, 128..255 = up of channels [128 pid_n, +128).
         // Per strip of 64 tokens: gate|up rows leave as two 256-B runs per row; act = swiglu_fwd_elem(g, u) is stored row-major and --
         // when the caller keeps it for the backward -- goes back into the strip's own (consumed) image rows as [channel][token] lines
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
         return;
       }
-      if (p.sw_gu) {
+      if (EPI == 2) {
         // ---- fused SwiGLU backward (mla_gemm_dact_swiglu_bwd): the staged tile is d(act)[256 tokens][256 channels], rounded to bf16
         // exactly like the stand-alone GEMM would have stored it. Four strips of 64 tokens: (a) every thread takes four 8-channel
         // pieces, reads gate / up from HBM (whole 512-B row runs), applies swiglu_bwd_elem, stores d(gate) / d(up) row-major;
@@ -983,10 +986,17 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
   } else if (p.sw_gu) {
     static bool attr_sw = false;      // the fused SwiGLU-backward epilogue stages a second transposed strip in 32 KiB beyond the ring
     if (!attr_sw) {
-      hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 32768);
+      hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 32768);
       attr_sw = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF + 32768, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_, 2>), dim3(num_m * num_n), dim3(512), 2 * BUF + 32768, stream, p);
+  } else if (p.sf_I) {
+    static bool attr_sf = false;
+    if (!attr_sf) {
+      hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+      attr_sf = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_, 1>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
   } else {
     hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
   }
@@ -1084,6 +1094,7 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   // persistent walk when there is more than one round of tiles and the operands fit 31-bit byte offsets (buffer addressing)
   const size_t bytesA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bytesB = ((size_t)(p.N - 1) * p.ldb + p.K) * 2;
   const int grid = ncu & ~7;
-  const bool use_p = (persist || (p.debug & 0x100)) && (p.debug & 0x80) == 0 && tiles > grid && bytesA < 0x7fffffffULL && bytesB < 0x7fffffffULL;
+  const bool use_p = (persist || (p.debug & 0x100)) && (p.debug & 0x80) == 0 && tiles > grid && bytesA < 0x7fffffffULL && bytesB < 0x7fffffffULL &&
+                     p.sf_I == 0 && p.sw_gu == nullptr && p.rope_cos == nullptr;     // the persistent walk has the plain epilogue only
   return launch256<0, 0>(p, stream, use_p ? grid : 0);
 }

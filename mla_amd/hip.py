@@ -229,7 +229,7 @@ def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols):
          int(S), int(rope_cols))
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * T * N * K, (0, 0, T, N, K)))
+        prof.append((ev0, ev1, 2.0 * T * N * K, (0, 0, T, N, K, "rope_epilogue")))
     return True
 
 
@@ -254,7 +254,7 @@ def gemm_gateup_swiglu(x2d, wgu, want_t):
     call("mla_gemm_gateup_swiglu", _p(x2d), _p(wgu), _p(gu), _p(act), _p(actT), T, I, K, x2d.stride(0), wgu.stride(0), T)
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * T * 2 * I * K, (0, 0, T, 2 * I, K)))
+        prof.append((ev0, ev1, 2.0 * T * 2 * I * K, (0, 0, T, 2 * I, K, "swiglu_fwd_epilogue")))
     return gu, act, actT
 
 
@@ -278,7 +278,7 @@ def gemm_dact_swiglu_bwd(dy2d, wT, gu2d):
     call("mla_gemm_dact_swiglu_bwd", _p(dy2d), _p(wT), _p(gu2d), _p(dgu), _p(dguT), T, I, K, dy2d.stride(0), wT.stride(0), T)
     if prof is not None:
         ev1.record()
-        prof.append((ev0, ev1, 2.0 * T * I * K, (0, 0, T, I, K)))
+        prof.append((ev0, ev1, 2.0 * T * I * K, (0, 0, T, I, K, "swiglu_bwd_epilogue")))
     return dgu, dguT
 
 
