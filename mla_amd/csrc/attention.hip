@@ -371,30 +371,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
     }
 }
 
-// delta[b][h][q] = sum_d O[q][d] * dO[q][d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int S, int H, long long ld_o) {
-  const long long total = (long long)B * S * H * 16;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const bool ok = idx < total;
-    const long long id = ok ? idx : total - 1;
-    const int c = (int)(id & 15);
-    const long long r = id >> 4;
-    const int h = (int)(r % H);
-    const long long tok = r / H;
-    const u32x4_t a = *(const u32x4_t*)(o + tok * ld_o + h * D + c * 8);
-    const u32x4_t d = *(const u32x4_t*)(dout + tok * ld_o + h * D + c * 8);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s += bflo(a[j]) * bflo(d[j]) + bfhi(a[j]) * bfhi(d[j]);
-    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
-    if (ok && c == 0) {
-      const long long bb = tok / S, q = tok % S;
-      delta[(bb * H + h) * S + q] = s;
-    }
-  }
-}
-
 #ifndef MLA_ATTN_BWD_SW
 #define MLA_ATTN_BWD_SW 0
 #endif
@@ -510,7 +486,25 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
     load_row_frags(p.dout + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, dof[rb]);
     padq[rb] = (myq[rb] >= seqlen) || (myq[rb] >= p.S);
     lse2[rb] = padq[rb] ? INFINITY : p.lse[((long long)b * p.H + h) * p.S + qc] * LOG2E;
-    dlt[rb] = p.delta[((long long)b * p.H + h) * p.S + qc];
+    if (p.o) {
+      // delta = rowsum(O * dO) formed here (the four lanes of a row hold all 128 channels of dO already) and published for the
+      // dK / dV kernel that runs behind this one: replaces the stand-alone delta pass over O and dO
+      bf16x8_t of[4];
+      load_row_frags(p.o + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, of);
+      float acc = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        union { bf16x8_t v; uint32_t w[4]; } a, d;
+        a.v = of[ks];
+        d.v = dof[rb][ks];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += bflo(a.w[j]) * bflo(d.w[j]) + bfhi(a.w[j]) * bfhi(d.w[j]);
+      }
+      dlt[rb] = group_sum(acc);
+      if (g == 0 && myq[rb] < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myq[rb]] = dlt[rb];
+    } else {
+      dlt[rb] = p.delta[((long long)b * p.H + h) * p.S + qc];
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) dqt[rb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
@@ -723,9 +717,8 @@ extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const v
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
     attr = true;
   }
-  const long long items = (long long)B * S * H * 16;
-  long long nb = (items + 255) / 256; if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((int)nb), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta, B, S, H, ld_o);
+  // delta = rowsum(O * dO) is computed by the dQ kernel's prologue (p.o set) and read by the dK / dV kernel launched behind it
+  p.o = (bf16_t*)o;
   constexpr int BQ = 16 * DQ_NW * DQ_RB;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DQ_RB, DQ_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * DQ_NW), 4 * TILE_BYTES, stream, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
