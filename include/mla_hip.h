@@ -119,9 +119,12 @@ int mla_swiglu_fwd_dual(const void* gu, void* act, void* actT, long long rows, i
  * (modeling_llama.py:241 LlamaMLP backward; saves re-reading the 2I-wide gradient for a separate transpose) */
 int mla_swiglu_bwd_t(const void* dact, const void* gu, void* dgu, void* dguT, long long rows, int I, long long ldt, mla_stream_t stream);
 
-/* ---- embedding: LlamaModel.embed_tokens modeling_llama.py:975-976 (deterministic, atomics-free backward) */
+/* ---- embedding: LlamaModel.embed_tokens modeling_llama.py:975-976 (deterministic, atomics-free backward).
+ * bwd: grad[ids[t]] += dy[t] in ascending token order. workspace: fp32 [tokens / 64, H] scratch or NULL; with it, every aligned
+ * batch of 64 tokens that carries one id (padding) is summed first by its own workgroup and enters the walk as one row. */
 int mla_embedding_fwd(const long long* ids, const void* table, void* out, long long tokens, int H, int vocab, mla_stream_t stream);
-int mla_embedding_bwd(const long long* ids, const void* dy, float* grad, long long tokens, int H, int vocab, mla_stream_t stream);
+int mla_embedding_bwd(const long long* ids, const void* dy, float* grad, float* workspace, long long tokens, int H, int vocab,
+                      mla_stream_t stream);
 
 /* ---- optimizer: AdamW (training/strategies/fsdp.py:257) over the local fp32 shard + bf16 compute copy; clip (:308-310) */
 int mla_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long long n, float lr, float beta1, float beta2,

@@ -58,7 +58,7 @@ _SIGNATURES = {
     "mla_cast_bf16_to_f32": [c_void_p, c_void_p, c_longlong, c_void_p],
     "mla_add_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
     "mla_embedding_fwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
-    "mla_embedding_bwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+    "mla_embedding_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "mla_adamw_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
                        c_float, c_int, c_void_p, c_void_p],
     "mla_sumsq_f32": [c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
@@ -409,8 +409,12 @@ def embedding_fwd(ids, table):
 
 
 def embedding_bwd(ids, dy2d, grad_f32):
+    """grad_f32[ids[t]] += dy2d[t], deterministic (ascending token order; an aligned batch of 64 equal ids -- padding -- is summed
+    first into the workspace row the library asks for)."""
     vocab, H = grad_f32.shape
-    call("mla_embedding_bwd", _p(ids), _p(dy2d), _p(grad_f32), ids.numel(), H, vocab)
+    tokens = ids.numel()
+    ws = torch.empty((tokens // 64, H), dtype=torch.float32, device=grad_f32.device) if tokens >= 64 else None
+    call("mla_embedding_bwd", _p(ids), _p(dy2d), _p(grad_f32), _p(ws), tokens, H, vocab)
 
 
 def adamw_step(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=None):

@@ -460,6 +460,18 @@ def test_adamw_embedding_misc(dev):
     hip.embedding_bwd(ids.to(dev), dy.to(dev), grad)
     ref = torch.zeros(vocab, H).index_add_(0, ids, dy.float())
     assert fro_rel(grad, ref) < 1e-6
+    # padded batch: runs of one id (aligned batches of 64 go through the pre-reduction), ragged H, repeatable bit for bit
+    for Hh in (1024, 136):
+        ids = torch.randint(0, vocab, (4, 300), generator=g)
+        ids[:, 120:] = vocab - 1
+        ids[2, :] = 7
+        ids = ids.reshape(-1)
+        dy = bfr(ids.numel(), Hh, seed=5)
+        g1, g2 = torch.zeros(vocab, Hh, device=dev), torch.zeros(vocab, Hh, device=dev)
+        hip.embedding_bwd(ids.to(dev), dy.to(dev), g1)
+        hip.embedding_bwd(ids.to(dev), dy.to(dev), g2)
+        assert torch.equal(g1, g2)
+        assert fro_rel(g1, torch.zeros(vocab, Hh).index_add_(0, ids, dy.float())) < 1e-6
     # casts / add / colsum / layernorm / q_sample
     x32 = torch.randn(1003, generator=g)
     assert torch.equal(hip.cast_f32_to_bf16(x32.to(dev)).cpu(), x32.to(BF))
