@@ -147,6 +147,13 @@ int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
 int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
                  void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
                  float scale, const float* rope_cos, const float* rope_sin, mla_stream_t stream);
+/* mla_attn_bwd + token-contiguous copies dqT / dkT / dvT / oT [H * head_dim, ldt] (column = b * S + s; columns >= B * S untouched)
+ * of dq / dk / dv / o: the k-contiguous operands of the q|k|v and o projection wgrad GEMMs (autograd of modeling_llama.py:371-380),
+ * written from the registers that hold the rows instead of by four transpose passes. All four or none; S % 4 == 0, ldt % 4 == 0. */
+int mla_attn_bwd_t(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
+                   void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
+                   float scale, const float* rope_cos, const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT,
+                   long long ldt, mla_stream_t stream);
 
 /* ---- losses: CrossEntropyLoss modeling_llama.py:1258-1269; InfoNCE models/mla/fuser/contrastive.py:208-215 */
 int mla_ce_fwd(const void* logits, int logits_fp32, long long ld, const long long* labels, float* loss, float* lse, int rows,

@@ -142,7 +142,44 @@ struct AttnArgs {
   float scale;
   const float* rope_cos; const float* rope_sin;        // backward only: [S, 64] fp32 tables; non-null = dq / dk leave the kernels with
                                                        // the RoPE backward already applied (replaces a separate in-place pass)
+  bf16_t* dqT; bf16_t* dkT; bf16_t* dvT; bf16_t* oT;   // backward only, all or none: [H*D, ldT] token-contiguous copies of dq / dk / dv
+  long long ldT;                                       // / o (the wgrad GEMM operands), written from the registers that hold the rows
 };
+
+// 4 x 4 transpose of bf16 values among the four lanes of a quad (lanes 4a .. 4a+3 hold four consecutive tokens).
+// in : w0 = channels (c, c+1), w1 = channels (c+2, c+3) of THIS lane's token
+// out: channel c + (lane & 3) of tokens 4a .. 4a+3, in token order -- 8 contiguous bytes of a [channel][token] matrix
+// Stage A swaps the off-diagonal 2 x 2 blocks between lanes p and p ^ 2, stage B the 16-bit halves between lanes p and p ^ 1
+// (DPP quad permutes + v_perm_b32: 8 VALU instructions, no LDS).
+__device__ __forceinline__ u32x2_t quad_transpose_bf16(uint32_t w0, uint32_t w1, int lane) {
+  const bool lo2 = (lane & 2) == 0;
+  const uint32_t x = lo2 ? w1 : w0;
+  const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  if (lo2) w1 = y; else w0 = y;
+  const uint32_t sel = (lane & 1) ? 0x03020706u : 0x05040100u;
+  const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+  const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0xB1, 0xf, 0xf, false);
+  u32x2_t r;
+  r[0] = __builtin_amdgcn_perm(p0, w0, sel);
+  r[1] = __builtin_amdgcn_perm(p1, w1, sel);
+  return r;
+}
+// Direct transposed store of a row held as load_row_frags() delivers it: f[ks] = channels ks*32 + g*8 .. +7 (two groups of four);
+// the quad's four tokens of one channel go to dstT[channel * ldT + tok4] (tok4 = first token of the quad). Padding blocks only.
+__device__ __forceinline__ void store_frags_t(bf16_t* __restrict__ dstT, long long ldT, long long tok4, const bf16x8_t (&f)[4], int lane,
+                                              bool valid) {
+  const int g = lane >> 4, pq = lane & 3;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    union { bf16x8_t v; uint32_t w[4]; } u;
+    u.v = f[ks];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const u32x2_t t = quad_transpose_bf16(u.w[2 * half], u.w[2 * half + 1], lane);
+      if (valid) *(u32x2_t*)(dstT + (long long)(ks * 32 + g * 8 + half * 4 + pq) * ldT + tok4) = t;
+    }
+  }
+}
 
 // RoPE backward of one gradient row held as 8 x f32x4 (d = fd*16 + g*4 + r): pairs (d, d + 64) sit in the SAME lane (fd, fd + 4).
 // Same arithmetic as rope_kernel(sign = -1) on the bf16-rounded values, so fused and unfused results are bit-identical:
@@ -472,6 +509,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
         bf16_t* dqrow = p.dq + ((long long)b * p.S + myq[rb]) * p.ld + h * D;
 #pragma unroll
         for (int fd = 0; fd < 8; ++fd) *(u32x2_t*)(dqrow + fd * 16 + g * 4) = u32x2_t{0u, 0u};
+        if (p.dqT) {   // (S % 4 == 0: a quad of tokens is inside the sequence or outside as a whole)
+          const long long tok4 = (long long)b * p.S + (myq[rb] & ~3);
+#pragma unroll
+          for (int fd = 0; fd < 8; ++fd)
+            *(u32x2_t*)(p.dqT + ((long long)h * D + fd * 16 + g * 4 + (lane & 3)) * p.ldT + tok4) = u32x2_t{0u, 0u};
+          bf16x8_t of[4];   // o^T of these rows: whatever the forward wrote (zeros for padded rows)
+          load_row_frags(p.o + ((long long)b * p.S + myq[rb]) * p.ld_o + h * D, lane, of);
+          store_frags_t(p.oT + (long long)h * D * p.ldT, p.ldT, tok4, of, lane, true);
+        }
       }
     return;
   }
@@ -534,9 +580,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
       dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
     }
   }
+  // dq^T / o^T [128 channels][BQ = 128 queries]: quad-transposed 8-B pieces go through LDS (the K / V ring is free now) and leave as
+  // 256-B runs per channel row (see the dK / dV kernel). Image: row pitch 256 B, 8-B chunk index XOR-swizzled by (channel & 7) << 2.
+  const bool tr = p.dqT != nullptr && BQ == 128;
+  if (tr) __syncthreads();
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-    if (myq[rb] < p.S) {
+  for (int rb = 0; rb < RB; ++rb) {
+    const bool valid = myq[rb] < p.S;
+    u32x2_t w[8];
+    if (valid) {
       bf16_t* dqrow = p.dq + ((long long)b * p.S + myq[rb]) * p.ld + h * D;
       const float sc = padq[rb] ? 0.f : p.scale;
 #pragma unroll
@@ -544,12 +596,49 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
       if (p.rope_cos) rope_bwd_row(dqt[rb], p.rope_cos, p.rope_sin, myq[rb], g);
 #pragma unroll
       for (int fd = 0; fd < 8; ++fd) {
-        u32x2_t w;
-        w[0] = pack2bf(dqt[rb][fd][0], dqt[rb][fd][1]);
-        w[1] = pack2bf(dqt[rb][fd][2], dqt[rb][fd][3]);
-        *(u32x2_t*)(dqrow + fd * 16 + g * 4) = w;
+        w[fd][0] = pack2bf(dqt[rb][fd][0], dqt[rb][fd][1]);
+        w[fd][1] = pack2bf(dqt[rb][fd][2], dqt[rb][fd][3]);
+        *(u32x2_t*)(dqrow + fd * 16 + g * 4) = w[fd];
       }
     }
+    if (tr) {
+      const int pq = lane & 3;
+      const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
+      bf16x8_t of[4];
+      load_row_frags(p.o + ((long long)b * p.S + (valid ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
+#pragma unroll
+      for (int fd = 0; fd < 8; ++fd) {
+        const int c = fd * 16 + g * 4 + pq;
+        *(u32x2_t*)(smem + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) =
+            quad_transpose_bf16(valid ? w[fd][0] : 0u, valid ? w[fd][1] : 0u, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        union { bf16x8_t v; uint32_t u[4]; } f;
+        f.v = of[ks];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int c = ks * 32 + g * 8 + half * 4 + pq;
+          *(u32x2_t*)(smem + 32768 + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
+        }
+      }
+    }
+  }
+  if (tr) {
+    __syncthreads();
+    constexpr int RPP = 64 * NW / 32;                     // channel rows per pass (32 lanes x 8 B per row)
+    const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3
+    if (q0 + j * 4 < p.S) {
+      const long long tok = (long long)b * p.S + q0 + j * 4;
+#pragma unroll
+      for (int ps = 0; ps < 128 / RPP; ++ps) {
+        const int c = ps * RPP + (threadIdx.x >> 5);
+        const int off = c * 256 + ((j ^ ((c & 7) << 2)) * 8);
+        *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + off);
+        *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 32768 + off);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -648,6 +737,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(qt_, fd, 1, lane), ds1, dkt[fd], 0, 0, 0);
     }
   }
+  u32x2_t wk[8], wv[8];
   if (mykey < p.S) {
     bf16_t* dkrow = p.dk + ((long long)b * p.S + mykey) * p.ld + h * D;
     bf16_t* dvrow = p.dv + ((long long)b * p.S + mykey) * p.ld + h * D;
@@ -656,13 +746,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     if (p.rope_cos) rope_bwd_row(dkt, p.rope_cos, p.rope_sin, mykey, g);
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
-      u32x2_t w;
-      w[0] = pack2bf(dkt[fd][0], dkt[fd][1]);
-      w[1] = pack2bf(dkt[fd][2], dkt[fd][3]);
-      *(u32x2_t*)(dkrow + fd * 16 + g * 4) = w;
-      w[0] = pack2bf(dvt[fd][0], dvt[fd][1]);
-      w[1] = pack2bf(dvt[fd][2], dvt[fd][3]);
-      *(u32x2_t*)(dvrow + fd * 16 + g * 4) = w;
+      wk[fd][0] = pack2bf(dkt[fd][0], dkt[fd][1]);
+      wk[fd][1] = pack2bf(dkt[fd][2], dkt[fd][3]);
+      *(u32x2_t*)(dkrow + fd * 16 + g * 4) = wk[fd];
+      wv[fd][0] = pack2bf(dvt[fd][0], dvt[fd][1]);
+      wv[fd][1] = pack2bf(dvt[fd][2], dvt[fd][3]);
+      *(u32x2_t*)(dvrow + fd * 16 + g * 4) = wv[fd];
+    }
+  }
+  if (p.dkT) {
+    // dk^T / dv^T [128 channels][64 keys]: quad-transposed 8-B pieces go through LDS (the Q / dO ring is free now) and leave as
+    // 128-B runs per channel row -- 4 rows per store instruction instead of 32-B pieces of 16 rows (same lesson as the GEMM
+    // epilogue: a workgroup keeps its CU until its last store is acknowledged, and partial-line scatter is what makes that long).
+    // Image: row pitch 128 B, 8-B chunk index XOR-swizzled by ((channel >> 1) & 3) << 2 (conflict-free writes and reads).
+    __syncthreads();
+    const int pq = lane & 3;
+    const bool kvalid = mykey < p.S;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      const int c = fd * 16 + g * 4 + pq;
+      const int chunk = (wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2);
+      u32x2_t tk = quad_transpose_bf16(kvalid ? wk[fd][0] : 0u, kvalid ? wk[fd][1] : 0u, lane);
+      u32x2_t tv = quad_transpose_bf16(kvalid ? wv[fd][0] : 0u, kvalid ? wv[fd][1] : 0u, lane);
+      *(u32x2_t*)(smem + c * 128 + chunk * 8) = tk;
+      *(u32x2_t*)(smem + 16384 + c * 128 + chunk * 8) = tv;
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 15;                       // 8-B chunk = keys kb*64 + 4 j .. + 3
+    const long long tok = (long long)b * p.S + kb * 64 + j * 4;
+    if (kb * 64 + j * 4 < p.S) {
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int c = ps * 16 + (threadIdx.x >> 4);
+        const int off = c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8);
+        *(u32x2_t*)(p.dkT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + off);
+        *(u32x2_t*)(p.dvT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 16384 + off);
+      }
     }
   }
   (void)nkb;
@@ -695,10 +814,15 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 // delta: workspace [B,H,S] fp32 (caller-allocated)
-extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                            const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
-                            int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
-                            const float* rope_sin, hipStream_t stream) {
+static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                         const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
+                         int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
+                         const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, hipStream_t stream) {
+  const int nT = (dqT != nullptr) + (dkT != nullptr) + (dvT != nullptr) + (oT != nullptr);
+  MLA_CHECK_ARG(nT == 0 || nT == 4, "mla_attn_bwd_t: dqT / dkT / dvT / oT must all be given or all be null");
+  MLA_CHECK_ARG(nT == 0 || (S % 4 == 0 && ldt % 4 == 0 && ldt >= (long long)B * S && ((uintptr_t)dqT & 7) == 0 &&
+                            ((uintptr_t)dkT & 7) == 0 && ((uintptr_t)dvT & 7) == 0 && ((uintptr_t)oT & 7) == 0),
+                "mla_attn_bwd_t: transposed outputs need S %% 4 == 0, ldt %% 4 == 0, ldt >= B * S and 8-B aligned bases");
   MLA_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "mla_attn_bwd: rope_cos / rope_sin must both be given or both be null");
   MLA_CHECK_ARG(!rope_cos || (AL16(rope_cos) && AL16(rope_sin)), "mla_attn_bwd: rope tables must be 16-B aligned");
   MLA_CHECK_ARG(q && k && v && o && dout && lse && dq && dk && dv && delta, "mla_attn_bwd: null pointer");
@@ -710,6 +834,7 @@ extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const v
   p.dout = (const bf16_t*)dout; p.delta = delta; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
   p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin;
+  p.dqT = (bf16_t*)dqT; p.dkT = (bf16_t*)dkT; p.dvT = (bf16_t*)dvT; p.oT = (bf16_t*)oT; p.ldT = ldt;
   if (check_common(p, "mla_attn_bwd")) return -1;
   static bool attr = false;
   if (!attr) {
@@ -720,7 +845,25 @@ extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const v
   // delta = rowsum(O * dO) is computed by the dQ kernel's prologue (p.o set) and read by the dK / dV kernel launched behind it
   p.o = (bf16_t*)o;
   constexpr int BQ = 16 * DQ_NW * DQ_RB;
+  static_assert(BQ == 128, "the transposed-output epilogue of the dQ kernel stages a 128-query image");
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DQ_RB, DQ_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * DQ_NW), 4 * TILE_BYTES, stream, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
   MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                            const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
+                            int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
+                            const float* rope_sin, hipStream_t stream) {
+  return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
+                       nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+// + token-contiguous copies dqT / dkT / dvT / oT [H * head_dim, ldt] of dq / dk / dv / o (columns b * S + s; columns >= B * S are
+// not touched): the k-contiguous operands of the q|k|v and o projection wgrad GEMMs, written from the registers that hold the rows
+// instead of by four transpose passes over HBM.
+extern "C" int mla_attn_bwd_t(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                              const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
+                              int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
+                              const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, hipStream_t stream) {
+  return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
+                       dqT, dkT, dvT, oT, ldt, stream);
 }

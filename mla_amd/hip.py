@@ -68,6 +68,9 @@ _SIGNATURES = {
                      c_longlong, c_float, c_void_p],
     "mla_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p, c_void_p],
+    "mla_attn_bwd_t": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
     "mla_ce_fwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p],
     "mla_ce_bwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong, c_int, c_int,
                    c_longlong, c_void_p],
@@ -452,13 +455,25 @@ def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale, rope_cos=None, rope_sin=None):
-    """rope_cos / rope_sin ([S, D/2] fp32): dq / dk come out with the RoPE backward already applied (no separate pass)."""
+def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale, rope_cos=None, rope_sin=None, transposed=None):
+    """rope_cos / rope_sin ([S, D/2] fp32): dq / dk come out with the RoPE backward already applied (no separate pass).
+    transposed = (dqkvT [3*H*D, ldt], oT [H*D, ldt]) bf16: also filled with the token-contiguous copies of dq|dk|dv and o (columns
+    b*S + s; columns >= B*S are left alone) -- the wgrad operands, without transpose passes. Needs S % 4 == 0, ldt % 4 == 0."""
     delta = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
     if rope_cos is not None:
         _req(rope_cos, torch.float32, "rope cos")
         _req(rope_sin, torch.float32, "rope sin")
         assert rope_cos.shape == (S, D // 2) and rope_sin.shape == (S, D // 2) and rope_cos.is_contiguous() and rope_sin.is_contiguous()
+    if transposed is not None:
+        dqkvT, oT = transposed
+        _req(dqkvT, torch.bfloat16, "dqkvT")
+        _req(oT, torch.bfloat16, "oT")
+        ldt = dqkvT.stride(0)
+        assert dqkvT.shape[0] == 3 * H * D and oT.shape[0] == H * D and oT.stride(0) == ldt and dqkvT.stride(1) == 1 and oT.stride(1) == 1
+        call("mla_attn_bwd_t", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
+             H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(dqkvT[:H * D]), _p(dqkvT[H * D:2 * H * D]),
+             _p(dqkvT[2 * H * D:]), _p(oT), ldt)
+        return
     call("mla_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
          H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin))
 

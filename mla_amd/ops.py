@@ -456,6 +456,7 @@ def info_nce(a, b, M, temperature):
 _ROPE_EPILOGUE = os.environ.get("MLA_ROPE_EPILOGUE", "1") != "0"   # A/B switch (tools): 0 = separate RoPE pass after the QKV GEMM
 _SWIGLU_FWD_EPILOGUE = os.environ.get("MLA_SWIGLU_FWD_EPILOGUE", "1") != "0"   # A/B switch: 0 = gate|up GEMM + separate SwiGLU pass
 _SWIGLU_BWD_EPILOGUE = os.environ.get("MLA_SWIGLU_BWD_EPILOGUE", "1") != "0"   # A/B switch: 0 = d(act) GEMM + separate SwiGLU backward
+_ATTN_BWD_T = os.environ.get("MLA_ATTN_BWD_T", "1") != "0"           # dqkv^T / o^T written by the attention-backward kernels
 _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (tools): 0 = recompute act^T in the backward
 
 
@@ -624,26 +625,35 @@ class DecoderLayerFn(torch.autograd.Function):
 
         # ---- attention output projection
         do = hip.gemm(dh1, wT((wo,)))
-        if need[4]:
-            grads[4] = deliver_wgrad_nt((wo,), hip.transpose(dh1), hip.transpose(o), need[4:5])[0]
         dqkv = torch.empty_like(qkv)
         if T != Tr:
             dqkv[Tr:].zero_()
         # the RoPE backward of dq / dk is applied in the attention-backward epilogues (no separate in-place pass over dqkv)
         fuse_rope = cos.shape[0] == S and cos.is_contiguous() and sin.is_contiguous() and cos.dtype == torch.float32
+        want_qkv_w = need[1] or need[2] or need[3]
+        # dqkv^T and o^T (wgrad operands) leave the attention-backward kernels with the rows: no transpose passes over them
+        tr = None
+        if _ATTN_BWD_T and fuse_rope and S % 4 == 0 and want_qkv_w and need[4]:
+            tr = (torch.empty((3 * H, T), dtype=BF16, device=qkv.device), torch.empty((H, T), dtype=BF16, device=qkv.device))
+            if T != Tr:
+                tr[0][:, Tr:].zero_()
+                tr[1][:, Tr:].zero_()
         hip.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, seqlens, dqkv[:, :H], dqkv[:, H:2 * H],
                      dqkv[:, 2 * H:], B, S, nheads, D, 3 * H, 1.0 / math.sqrt(D), rope_cos=cos if fuse_rope else None,
-                     rope_sin=sin if fuse_rope else None)
+                     rope_sin=sin if fuse_rope else None, transposed=tr)
         del do
         if not fuse_rope:
             hip.rope_inplace(dqkv, cos, sin, S, nheads, D, 0, H, backward=True)
+        if need[4]:
+            grads[4] = deliver_wgrad_nt((wo,), hip.transpose(dh1), tr[1] if tr is not None else hip.transpose(o), need[4:5])[0]
         # ---- q | k | v projection
         dxn1 = hip.gemm(dqkv, wT((wq, wk, wv)))                          # [T, H], K = 3H
-        if need[1] or need[2] or need[3]:
+        if want_qkv_w:
             xn1T = hip.rmsnorm_apply_t(h2, ln1, rstd1) if xn1 is None else hip.transpose(xn1)
-            grads[1], grads[2], grads[3] = deliver_wgrad_nt((wq, wk, wv), hip.transpose(dqkv), xn1T, need[1:4])
+            grads[1], grads[2], grads[3] = deliver_wgrad_nt((wq, wk, wv), tr[0] if tr is not None else hip.transpose(dqkv), xn1T,
+                                                            need[1:4])
             del xn1T
-        del dqkv
+        del dqkv, tr
 
         def ln1_run(dw_out, acc):
             holder["dh"] = hip.rmsnorm_bwd(dxn1, h2, ln1, rstd1, dres=dh1, dw_out=dw_out, dw_accumulate=acc)

@@ -347,6 +347,33 @@ def test_attention_bwd_fused_rope_is_bit_identical(dev):
         assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
 
 
+@pytest.mark.parametrize("S,lens", [(200, None), (548, [548, 36, 300]), (64, [64, 0, 5]), (132, [1, 132, 129])])
+def test_attention_bwd_transposed_outputs_are_bit_identical(dev, S, lens):
+    """mla_attn_bwd_t: dq^T | dk^T | dv^T and o^T written by the kernels == transposes of what mla_attn_bwd writes (and of o), with the
+    caller's row padding columns left alone (the wgrad operands of the q|k|v / o projections, autograd of modeling_llama.py:371-380)."""
+    from mla_amd import hip
+    B, H, D = 3 if lens else 2, 3, 128
+    T, Tp = B * S, (B * S + 7) // 8 * 8 + 8
+    qkv = bfr(T, 3 * H * D, seed=23, scale=0.7).to(dev)
+    do = bfr(T, H * D, seed=24).to(dev)
+    cos, sin = O.rope_tables(S, D)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, sl, 1 / math.sqrt(D))
+    a, b = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    hip.attn_bwd(q, k, v, o, do, lse, sl, a[:, :H * D], a[:, H * D:2 * H * D], a[:, 2 * H * D:], B, S, H, D, 3 * H * D, 1 / math.sqrt(D),
+                 rope_cos=cos, rope_sin=sin)
+    marker = 7.0
+    dT = torch.full((3 * H * D, Tp), marker, dtype=BF, device=dev)
+    oT = torch.full((H * D, Tp), marker, dtype=BF, device=dev)
+    hip.attn_bwd(q, k, v, o, do, lse, sl, b[:, :H * D], b[:, H * D:2 * H * D], b[:, 2 * H * D:], B, S, H, D, 3 * H * D, 1 / math.sqrt(D),
+                 rope_cos=cos, rope_sin=sin, transposed=(dT, oT))
+    assert torch.equal(a, b)
+    assert torch.equal(dT[:, :T], a.t()) and torch.equal(oT[:, :T], o.t())
+    assert bool((dT[:, T:] == marker).all()) and bool((oT[:, T:] == marker).all())
+
+
 def test_attention_full_size_config4_properties(dev):
     """BASELINE configs[4] attention at FULL size (S = 2048, 32 heads x 128; 2 sequences, one ragged) through size-independent
     properties, no CPU reference needed:
