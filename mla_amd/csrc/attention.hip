@@ -390,22 +390,39 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
       fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
     }
   }
+  // ---- epilogue: O leaves through LDS (the K / V ring is free now) as whole 256-B rows, 16 B per lane, 4 rows per store
+  // instruction -- straight from the MFMA layout it is 32-B pieces of 16 rows per instruction (see the dK / dV kernel).
+  // Image [128 q][128 ch] (32 KiB), 8-B chunk index XOR-swizzled by (q & 15) << 1.
+  static_assert(BQ == 128, "the epilogue stages a 128-query image");
+  __syncthreads();
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-    if (myq[rb] < p.S) {
-      bf16_t* orow = p.o + ((long long)b * p.S + myq[rb]) * p.ld_o + h * D;
-      const bool pad = myq[rb] >= seqlen;
-      const float lsum = l[rb][0];                  // all four entries hold the row sum
-      const float inv = (pad || lsum == 0.f) ? 0.f : 1.f / lsum;
+  for (int rb = 0; rb < RB; ++rb) {
+    const bool valid = myq[rb] < p.S;
+    const bool pad = myq[rb] >= seqlen;
+    const float lsum = l[rb][0];                  // all four entries hold the row sum
+    const float inv = (pad || lsum == 0.f) ? 0.f : 1.f / lsum;
+    const int row = row_group<RB>(wave, rb) * 16 + (lane & 15);
 #pragma unroll
-      for (int fd = 0; fd < 8; ++fd) {
-        u32x2_t w;
-        w[0] = pack2bf(ot[rb][fd][0] * inv, ot[rb][fd][1] * inv);
-        w[1] = pack2bf(ot[rb][fd][2] * inv, ot[rb][fd][3] * inv);
-        *(u32x2_t*)(orow + fd * 16 + g * 4) = w;
-      }
-      if (g == 0) lse_p[myq[rb]] = pad ? INFINITY : (m[rb] * LN2 + logf(lsum));
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2_t w;
+      w[0] = pack2bf(ot[rb][fd][0] * inv, ot[rb][fd][1] * inv);
+      w[1] = pack2bf(ot[rb][fd][2] * inv, ot[rb][fd][3] * inv);
+      *(u32x2_t*)(smem + row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8)) = w;
     }
+    if (valid && g == 0) lse_p[myq[rb]] = pad ? INFINITY : (m[rb] * LN2 + logf(lsum));
+  }
+  __syncthreads();
+  {
+    constexpr int NT = 64 * NW;
+    const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
+#pragma unroll
+    for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
+      const int r = ps * (NT / 16) + (threadIdx.x >> 4);
+      if (q0 + r < p.S)
+        *(u32x4_t*)(p.o + ((long long)b * p.S + q0 + r) * p.ld_o + h * D + j * 8) =
+            *(const u32x4_t*)(smem + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
+    }
+  }
 }
 
 #ifndef MLA_ATTN_BWD_SW
@@ -580,38 +597,61 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
       dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
     }
   }
-  // dq^T / o^T [128 channels][BQ = 128 queries]: quad-transposed 8-B pieces go through LDS (the K / V ring is free now) and leave as
-  // 256-B runs per channel row (see the dK / dV kernel). Image: row pitch 256 B, 8-B chunk index XOR-swizzled by (channel & 7) << 2.
-  const bool tr = p.dqT != nullptr && BQ == 128;
-  if (tr) __syncthreads();
+  // ---- epilogue: everything leaves through LDS (the K / V ring is free now) as whole row runs, see the dK / dV kernel. Images
+  // (32 KiB each, BQ = 128 queries): dq [128 q][128 ch], 8-B chunk index XOR-swizzled by (q & 15) << 1; dq^T and, in a second
+  // round, o^T [128 ch][128 q], chunk index swizzled by (ch & 7) << 2. O is re-read here (L2) for its transposed copy.
+  static_assert(BQ == 128, "the epilogue stages 128-query images");
+  const bool tr = p.dqT != nullptr;
+  const int pq = lane & 3;
+  __syncthreads();
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const bool valid = myq[rb] < p.S;
-    u32x2_t w[8];
-    if (valid) {
-      bf16_t* dqrow = p.dq + ((long long)b * p.S + myq[rb]) * p.ld + h * D;
-      const float sc = padq[rb] ? 0.f : p.scale;
+    const float sc = padq[rb] ? 0.f : p.scale;
 #pragma unroll
-      for (int fd = 0; fd < 8; ++fd) dqt[rb][fd] *= sc;
-      if (p.rope_cos) rope_bwd_row(dqt[rb], p.rope_cos, p.rope_sin, myq[rb], g);
+    for (int fd = 0; fd < 8; ++fd) dqt[rb][fd] *= sc;
+    if (p.rope_cos) rope_bwd_row(dqt[rb], p.rope_cos, p.rope_sin, valid ? myq[rb] : 0, g);
+    const int grp = row_group<RB>(wave, rb);
+    const int row = grp * 16 + (lane & 15);
 #pragma unroll
-      for (int fd = 0; fd < 8; ++fd) {
-        w[fd][0] = pack2bf(dqt[rb][fd][0], dqt[rb][fd][1]);
-        w[fd][1] = pack2bf(dqt[rb][fd][2], dqt[rb][fd][3]);
-        *(u32x2_t*)(dqrow + fd * 16 + g * 4) = w[fd];
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2_t w;
+      w[0] = valid ? pack2bf(dqt[rb][fd][0], dqt[rb][fd][1]) : 0u;
+      w[1] = valid ? pack2bf(dqt[rb][fd][2], dqt[rb][fd][3]) : 0u;
+      *(u32x2_t*)(smem + row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8)) = w;
+      if (tr) {
+        const int c = fd * 16 + g * 4 + pq;
+        *(u32x2_t*)(smem + 32768 + c * 256 + (((grp * 4 + ((lane & 15) >> 2)) ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(w[0], w[1], lane);
       }
     }
-    if (tr) {
-      const int pq = lane & 3;
+  }
+  __syncthreads();
+  constexpr int NT = 64 * NW;
+  {
+    const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
+#pragma unroll
+    for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
+      const int r = ps * (NT / 16) + (threadIdx.x >> 4);
+      if (q0 + r < p.S)
+        *(u32x4_t*)(p.dq + ((long long)b * p.S + q0 + r) * p.ld + h * D + j * 8) =
+            *(const u32x4_t*)(smem + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
+    }
+  }
+  if (tr) {
+    const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3
+    const bool jv = q0 + j * 4 < p.S;
+    const long long tok = (long long)b * p.S + q0 + j * 4;
+#pragma unroll
+    for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
+      const int c = ps * (NT / 32) + (threadIdx.x >> 5);
+      if (jv) *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 32768 + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
       const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
       bf16x8_t of[4];
-      load_row_frags(p.o + ((long long)b * p.S + (valid ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
-#pragma unroll
-      for (int fd = 0; fd < 8; ++fd) {
-        const int c = fd * 16 + g * 4 + pq;
-        *(u32x2_t*)(smem + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) =
-            quad_transpose_bf16(valid ? w[fd][0] : 0u, valid ? w[fd][1] : 0u, lane);
-      }
+      load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         union { bf16x8_t v; uint32_t u[4]; } f;
@@ -619,24 +659,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int c = ks * 32 + g * 8 + half * 4 + pq;
-          *(u32x2_t*)(smem + 32768 + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
+          *(u32x2_t*)(smem + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
         }
       }
     }
-  }
-  if (tr) {
     __syncthreads();
-    constexpr int RPP = 64 * NW / 32;                     // channel rows per pass (32 lanes x 8 B per row)
-    const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3
-    if (q0 + j * 4 < p.S) {
-      const long long tok = (long long)b * p.S + q0 + j * 4;
 #pragma unroll
-      for (int ps = 0; ps < 128 / RPP; ++ps) {
-        const int c = ps * RPP + (threadIdx.x >> 5);
-        const int off = c * 256 + ((j ^ ((c & 7) << 2)) * 8);
-        *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + off);
-        *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 32768 + off);
-      }
+    for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
+      const int c = ps * (NT / 32) + (threadIdx.x >> 5);
+      if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
     }
   }
 }
@@ -737,41 +768,59 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(qt_, fd, 1, lane), ds1, dkt[fd], 0, 0, 0);
     }
   }
+  // ---- epilogue. Everything leaves through LDS (the Q / dO ring is free now) as whole row runs: dk / dv rows as 256 B (16 B per
+  // lane, 4 rows per store instruction), dk^T / dv^T as 128-B runs per channel row. Stored straight from the MFMA layout it is
+  // 8 B per lane = 32-B pieces of 16 different rows per instruction, and a workgroup keeps its CU until its last partial-line store
+  // is acknowledged (the GEMM-epilogue lesson; measured here: +85 us per launch for the transposed copies stored directly, +45
+  // staged). Images (16 KiB each): dk, dv [64 keys][128 ch] with the 8-B chunk index XOR-swizzled by (key & 15) << 1;
+  // dk^T, dv^T [128 ch][64 keys] with the chunk index swizzled by ((ch >> 1) & 3) << 2 -- conflict-free writes and reads.
+  const bool kvalid = mykey < p.S;
   u32x2_t wk[8], wv[8];
-  if (mykey < p.S) {
-    bf16_t* dkrow = p.dk + ((long long)b * p.S + mykey) * p.ld + h * D;
-    bf16_t* dvrow = p.dv + ((long long)b * p.S + mykey) * p.ld + h * D;
 #pragma unroll
-    for (int fd = 0; fd < 8; ++fd) dkt[fd] *= p.scale;
-    if (p.rope_cos) rope_bwd_row(dkt, p.rope_cos, p.rope_sin, mykey, g);
+  for (int fd = 0; fd < 8; ++fd) dkt[fd] *= p.scale;
+  if (p.rope_cos) rope_bwd_row(dkt, p.rope_cos, p.rope_sin, kvalid ? mykey : 0, g);
+#pragma unroll
+  for (int fd = 0; fd < 8; ++fd) {
+    wk[fd][0] = kvalid ? pack2bf(dkt[fd][0], dkt[fd][1]) : 0u;
+    wk[fd][1] = kvalid ? pack2bf(dkt[fd][2], dkt[fd][3]) : 0u;
+    wv[fd][0] = kvalid ? pack2bf(dvt[fd][0], dvt[fd][1]) : 0u;
+    wv[fd][1] = kvalid ? pack2bf(dvt[fd][2], dvt[fd][3]) : 0u;
+  }
+  __syncthreads();
+  {
+    const int row = wave * 16 + (lane & 15);
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
-      wk[fd][0] = pack2bf(dkt[fd][0], dkt[fd][1]);
-      wk[fd][1] = pack2bf(dkt[fd][2], dkt[fd][3]);
-      *(u32x2_t*)(dkrow + fd * 16 + g * 4) = wk[fd];
-      wv[fd][0] = pack2bf(dvt[fd][0], dvt[fd][1]);
-      wv[fd][1] = pack2bf(dvt[fd][2], dvt[fd][3]);
-      *(u32x2_t*)(dvrow + fd * 16 + g * 4) = wv[fd];
+      const int off = row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8);
+      *(u32x2_t*)(smem + off) = wk[fd];
+      *(u32x2_t*)(smem + 16384 + off) = wv[fd];
     }
   }
   if (p.dkT) {
-    // dk^T / dv^T [128 channels][64 keys]: quad-transposed 8-B pieces go through LDS (the Q / dO ring is free now) and leave as
-    // 128-B runs per channel row -- 4 rows per store instruction instead of 32-B pieces of 16 rows (same lesson as the GEMM
-    // epilogue: a workgroup keeps its CU until its last store is acknowledged, and partial-line scatter is what makes that long).
-    // Image: row pitch 128 B, 8-B chunk index XOR-swizzled by ((channel >> 1) & 3) << 2 (conflict-free writes and reads).
-    __syncthreads();
     const int pq = lane & 3;
-    const bool kvalid = mykey < p.S;
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
       const int c = fd * 16 + g * 4 + pq;
-      const int chunk = (wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2);
-      u32x2_t tk = quad_transpose_bf16(kvalid ? wk[fd][0] : 0u, kvalid ? wk[fd][1] : 0u, lane);
-      u32x2_t tv = quad_transpose_bf16(kvalid ? wv[fd][0] : 0u, kvalid ? wv[fd][1] : 0u, lane);
-      *(u32x2_t*)(smem + c * 128 + chunk * 8) = tk;
-      *(u32x2_t*)(smem + 16384 + c * 128 + chunk * 8) = tv;
+      const int off = c * 128 + (((wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8);
+      *(u32x2_t*)(smem + 32768 + off) = quad_transpose_bf16(wk[fd][0], wk[fd][1], lane);
+      *(u32x2_t*)(smem + 49152 + off) = quad_transpose_bf16(wv[fd][0], wv[fd][1], lane);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  {
+    const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int r = ps * 16 + (threadIdx.x >> 4);
+      if (kb * 64 + r < p.S) {
+        const int off = r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8);
+        const long long dst = ((long long)b * p.S + kb * 64 + r) * p.ld + h * D + j * 8;
+        *(u32x4_t*)(p.dk + dst) = *(const u32x4_t*)(smem + off);
+        *(u32x4_t*)(p.dv + dst) = *(const u32x4_t*)(smem + 16384 + off);
+      }
+    }
+  }
+  if (p.dkT) {
     const int j = threadIdx.x & 15;                       // 8-B chunk = keys kb*64 + 4 j .. + 3
     const long long tok = (long long)b * p.S + kb * 64 + j * 4;
     if (kb * 64 + j * 4 < p.S) {
@@ -779,8 +828,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       for (int ps = 0; ps < 8; ++ps) {
         const int c = ps * 16 + (threadIdx.x >> 4);
         const int off = c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8);
-        *(u32x2_t*)(p.dkT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + off);
-        *(u32x2_t*)(p.dvT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 16384 + off);
+        *(u32x2_t*)(p.dkT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 32768 + off);
+        *(u32x2_t*)(p.dvT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 49152 + off);
       }
     }
   }
