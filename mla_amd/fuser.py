@@ -78,11 +78,17 @@ def get_projection_func(camera_name: str):
     return project
 
 
+_CONSTS_ON_DEVICE: dict = {}
+
+
 def project_points(xyz: torch.Tensor, camera_name: str, image_size_resize=(672, 672), total_stride: int = 42):
     """contrastive.py:5-45: pinhole projection of point centres to the patch grid. xyz [..., 3] fp32 on the GPU.
     Returns (patch_idx [..., 2] int64 (row, col), valid bool [...])."""
-    Rw, tw, Ks = projection_constants(camera_name, image_size_resize)
-    consts = torch.cat([Rw.reshape(-1), tw.reshape(-1), Ks.reshape(-1)]).to(xyz.device)
+    key = (camera_name, tuple(image_size_resize), xyz.device)
+    consts = _CONSTS_ON_DEVICE.get(key)
+    if consts is None:     # uploaded once: a pageable host-to-device copy per step is a host synchronisation in the front end
+        Rw, tw, Ks = projection_constants(camera_name, image_size_resize)
+        consts = _CONSTS_ON_DEVICE[key] = torch.cat([Rw.reshape(-1), tw.reshape(-1), Ks.reshape(-1)]).to(xyz.device)
     flat = xyz.reshape(-1, 3).float().contiguous()
     n = flat.shape[0]
     idx = torch.empty((n, 2), dtype=torch.int64, device=xyz.device)

@@ -39,7 +39,9 @@ def build_splice_plan(input_ids, attention_mask, labels, n_fused: int, ins: int,
     B, L = input_ids.shape
     dev = input_ids.device
     ar_l = torch.arange(L, device=dev)
-    pos = torch.where(input_ids == tag_0, ar_l[None], -1).max(dim=1).values
+    # (a row without the tag gives -1; clamped so that the plan stays inside the pool -- the caller raises the reference's IndexError
+    # for such a row at its next host synchronisation point, after these launches are queued)
+    pos = torch.where(input_ids == tag_0, ar_l[None], -1).max(dim=1).values.clamp_min(0)
     k = (pos + n_fused)[:, None]
     S = L + n_fused + ins
     s = torch.arange(S, device=dev)[None]
@@ -327,15 +329,6 @@ class PrismaticVLM(nn.Module):
 
         parts, patch_indices, valid_mask, pos_pc_tac, lin_img_tac, _ = self.get_fused_tokens(images, point_cloud, tactile, gripper_xyz,
                                                                                         camera_name)
-        if self.training and self.use_contrastive and valid_mask is not None:
-            # the contrastive loss compacts the valid correspondences (a host-synchronising index, like the reference's mask index,
-            # contrastive.py:196-203). The mask only depends on the point centres, so the index is taken HERE, while the GPU has
-            # barely started the step, instead of after the decoder forward where the same sync drains a full launch queue
-            valid_mask._mla_valid_index = torch.nonzero(valid_mask.reshape(-1), as_tuple=False).squeeze(-1)
-        self.vision_tower_2d.assert_masks_ok()      # pixel-mask verdict of the vision tokenizer (free behind the sync above)
-        if not bool(tag_present):
-            raise IndexError(f"input_ids row without the splice tag {tag_0}: the reference indexes the last occurrence "
-                             "(models/vlm/prismatic.py:983) and fails the same way")
         n_fused = sum(p.shape[1] for p in parts)
         N_pc = N_img = 256
         pc_idx = (1, 1 + N_pc)
@@ -357,6 +350,18 @@ class PrismaticVLM(nn.Module):
         P = S
         pool = torch.cat([text_emb] + parts + [proprio_e, t_e, x_e], dim=1).reshape(B * P, H)
         fused_embeddings = ops.gather_rows(pool, flat).view(B, S, H)
+
+        if self.training and self.use_contrastive and valid_mask is not None:
+            # the contrastive loss compacts the valid correspondences (a host-synchronising index, like the reference's mask index,
+            # contrastive.py:196-203). The mask only depends on the point centres, so the index is taken HERE, once every front-end
+            # launch (tokenizers, embedders, splice) is queued and right before the decoder's launches: taken after the decoder
+            # forward the same sync drains a full launch queue. (Before or after the embedders / splice makes no measurable
+            # difference: 629.8 / 630.7 / 631.8 vs 630.6 / 628.1 / 629.2 ms in three same-box pairs.)
+            valid_mask._mla_valid_index = torch.nonzero(valid_mask.reshape(-1), as_tuple=False).squeeze(-1)
+        self.vision_tower_2d.assert_masks_ok()      # pixel-mask verdict of the vision tokenizer (free behind the sync above)
+        if not bool(tag_present):
+            raise IndexError(f"input_ids row without the splice tag {tag_0}: the reference indexes the last occurrence "
+                             "(models/vlm/prismatic.py:983) and fails the same way")
 
         output: CausalLMOutputWithPast = self.llm_backbone(
             input_ids=None, attention_mask=fused_attention_mask, position_ids=None, past_key_values=None,
