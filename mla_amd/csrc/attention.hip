@@ -13,6 +13,24 @@
 // K/V (or Q/dO) tiles of 64 rows are staged with global_load_lds_dwordx4 into a double-buffered, source-swizzled
 // LDS image. One block = 4 waves x 16 rows.
 #include "common.h"
+// staging copies are issued untracked (see glds16_untracked): every loop orders them itself with `s_waitcnt vmcnt(0)` + barrier
+#ifndef MLA_ATTN_GLDS_ASM
+#define MLA_ATTN_GLDS_ASM 1
+#endif
+// s_waitcnt vmcnt(0) as a builtin (gfx9 encoding: vmcnt = 0, expcnt = 7, lgkmcnt = 15), so that the compiler's own wait-count
+// bookkeeping sees it: issued as inline assembly it is invisible, the compiler then keeps its waits for the prologue's row loads at
+// their first use INSIDE the loop, and with the untracked copies in flight those waits drain the prefetch in every iteration.
+#define ATTN_WAIT_VM0()                    \
+  do {                                     \
+    __builtin_amdgcn_s_waitcnt(0x0F70);    \
+    asm volatile("" ::: "memory");         \
+  } while (0)
+#if MLA_ATTN_GLDS_ASM
+#define ATTN_GLDS glds16_untracked
+#else
+#define ATTN_GLDS glds16
+#endif
+
 #include <math.h>
 
 namespace {
@@ -43,7 +61,7 @@ __device__ __forceinline__ void stage_rows64(const bf16_t* __restrict__ base, lo
     const int c = swz<SW>(row, cp);
     int gr = row0 + row;
     gr = gr < row_lim ? gr : row_lim - 1;
-    glds16(base + (long long)gr * ld + c * 8, tile + instr * 1024);
+    ATTN_GLDS(base + (long long)gr * ld + c * 8, tile + instr * 1024);
   }
 }
 
@@ -61,7 +79,7 @@ __device__ __forceinline__ void stage_offs(long long ld, int wave, int lane, uns
 template <int NW = 4>
 __device__ __forceinline__ void stage_fast(const bf16_t* __restrict__ tile_base, const unsigned* off, char* tile, int wave) {
 #pragma unroll
-  for (int it = 0; it < 16 / NW; ++it) glds16(tile_base + off[it], tile + (wave * (16 / NW) + it) * 1024);
+  for (int it = 0; it < 16 / NW; ++it) ATTN_GLDS(tile_base + off[it], tile + (wave * (16 / NW) + it) * 1024);
 }
 
 // A/B fragment of 16 tile rows (rb) x 32 d (ks): lane (i = lane&15 -> row, g = lane>>4 -> d group of 8)
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
   stage_rows64<0, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
   stage_rows64<1, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_WAIT_VM0();
     __syncthreads();
     const char* kt_ = smem + (kt & 1) * 2 * TILE_BYTES;
     const char* vt_ = kt_ + TILE_BYTES;
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
   stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   for (int kt = 0; kt < nkt; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_WAIT_VM0();
     __syncthreads();
     const char* kt_ = smem + (kt & 1) * 2 * TILE_BYTES;
     const char* vt_ = kt_ + TILE_BYTES;
@@ -719,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       else val = (qi < qend) ? dl_p[qi] : 0.f;
       stats[bufi * 128 + threadIdx.x] = val;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_WAIT_VM0();
     __syncthreads();
     const char* qt_ = smem + bufi * 2 * TILE_BYTES;
     const char* dot_ = qt_ + TILE_BYTES;

@@ -111,6 +111,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const MLA_GLOBAL_AS void*)gsrc, (MLA_LDS_AS void*)lds_wave_base, 16, 0, MLA_GLDS_AUX);
 }
 
+// The same copy issued from inline assembly, i.e. invisible to the compiler's wait-count insertion. With the builtin the compiler
+// cannot tell which LDS bytes an LDS-DMA load writes, so it puts `s_waitcnt vmcnt(0)` in front of the first LDS read it cannot
+// disambiguate (every ds_read_b64_tr_b16, which carries no memory operand): in the attention loops that drained the next tile's
+// prefetch in the middle of the current tile. Callers order the copy against its readers themselves (vmcnt wait + barrier).
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, void* lds_wave_base) {
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(MLA_LDS_AS void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");   // (m0 is not used by compiled code on gfx950)
+}
+
 // LDS transpose read: 4 x b16 per lane (see DESIGN.md "tr16 semantics", verified by mla_selftest_tr16)
 __device__ __forceinline__ short4_t lds_tr16_b64(const void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((MLA_LDS_AS short4_t*)lds_addr);
