@@ -40,7 +40,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // MODE 1: global is [K][cols] (ld), tile = k0..k0+63 x cols i0..i0+127.  Out-of-range rows/cols/k are clamped to
 // valid addresses: clamped row/col data only reaches masked outputs, clamped k data is never multiplied (the
 // K tail is a multiple of 32 and the second k-step is skipped).
-template <int MODE>
+// UNTRACKED: the copy is issued from inline assembly (glds16_untracked): kernels that read fragments with ds_read_b64_tr_b16 must
+// not let the compiler see the LDS-DMA copies, or it drains the prefetch in front of every such read (common.h).
+template <int MODE, bool UNTRACKED>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int i0, int ilim, int k0, int K,
                                            char* tile, int wave, int lane) {
 #pragma unroll
@@ -65,7 +67,8 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld,
       gi = (gi + 8 <= ilim) ? gi : 0;
       src = g + (size_t)gk * ld + gi;
     }
-    glds16(src, tile + instr * 1024);
+    if (UNTRACKED) glds16_untracked(src, tile + instr * 1024);
+    else glds16(src, tile + instr * 1024);
   }
 }
 
@@ -123,17 +126,18 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nt = (p.K + BK - 1) / BK;
-  stage_tile<AMODE>(p.A, p.lda, m0, p.M, 0, p.K, smem, wave, lane);
-  stage_tile<BMODE>(p.B, p.ldb, n0, p.N, 0, p.K, smem + TILE_BYTES, wave, lane);
+  stage_tile<AMODE, (AMODE != 0 || BMODE != 0)>(p.A, p.lda, m0, p.M, 0, p.K, smem, wave, lane);
+  stage_tile<BMODE, (AMODE != 0 || BMODE != 0)>(p.B, p.ldb, n0, p.N, 0, p.K, smem + TILE_BYTES, wave, lane);
 
   for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) as a builtin, so that the compiler's wait-count bookkeeping sees it
+    asm volatile("" ::: "memory");
     __syncthreads();
     char* cur = smem + (t & 1) * 2 * TILE_BYTES;
     if (t + 1 < nt) {
       char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-      stage_tile<AMODE>(p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, nxt, wave, lane);
-      stage_tile<BMODE>(p.B, p.ldb, n0, p.N, (t + 1) * BK, p.K, nxt + TILE_BYTES, wave, lane);
+      stage_tile<AMODE, (AMODE != 0 || BMODE != 0)>(p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, nxt, wave, lane);
+      stage_tile<BMODE, (AMODE != 0 || BMODE != 0)>(p.B, p.ldb, n0, p.N, (t + 1) * BK, p.K, nxt + TILE_BYTES, wave, lane);
     }
     const int ksteps = (p.K - t * BK) >= BK ? 2 : 1;
     for (int ks = 0; ks < ksteps; ++ks) {
@@ -301,16 +305,16 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const void* R, 
   if (!out_fp32 && (((uintptr_t)C & 7) != 0)) mfma_ok = false;
   if (R && (((uintptr_t)R & 7) != 0)) mfma_ok = false;
   if (bias && (((uintptr_t)bias & 7) != 0)) mfma_ok = false;
-  // the 256x256 kernel is used for k-contiguous operands only: its reduction-major (ds_read_b64_tr_b16) path is slower than
-  // the 128x128 kernel's (issue-limited at 2 waves/SIMD); force_generic == 3 forces it for tests / experiments
+  // the 256x256 kernel takes every operand layout (round 2: its reduction-major path stages untracked and runs at 1.1-1.3 PFLOP/s,
+  // gemm128's at 0.87-0.96; round 1 measured 0.47-0.70 because the compiler drained the ring in front of every ds_read_b64_tr_b16);
+  // force_generic == 2 keeps it off, == 3 forces it without the split-K tail (tests / experiments)
   // force_generic == 4: the assembly-scheduled 256x256x32 kernel (gemm_asm.hip); K % 128 == 0, N % 4 == 0
   if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 4)
     return mla_gemm_asm_dispatch(&p, stream);
   // force_generic == 5: the 4-wave (128 x 128 per wave) assembly kernel, same eligibility
   if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 5)
     return mla_gemm_asm4_dispatch(&p, stream);
-  if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 &&
-      a_mode == 0 && b_mode == 0 && (force_generic == 0 || force_generic == 3))
+  if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 && (force_generic == 0 || force_generic == 3))
     return mla_gemm256_dispatch(&p, a_mode, b_mode, force_generic == 0 ? workspace_bytes : 0, stream);
   if (mfma_ok) {
     if (a_mode == 0 && b_mode == 0) return launch128<0, 0>(p, stream);

@@ -60,6 +60,9 @@ __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* g, int ld, int 
 // EPI: 0 = plain epilogue (bias / residual / fp32 / fused RoPE by arguments), 1 = fused gate|up + SwiGLU forward, 2 = fused d(act) +
 // SwiGLU backward. Separate instantiations: the fused forms are different kernels (GEMM + an HBM-bound elementwise pass in the
 // epilogue) and show up under their own names in rocprofv3, so the plain kernel's statistics are not mixed with theirs.
+#ifndef MLA_GEMM256_UNTRACKED
+#define MLA_GEMM256_UNTRACKED 0   // 1: k-contiguous instantiations stage untracked too (A/B)
+#endif
 template <int AMODE, int BMODE, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const bool LGKM_BEFORE = false;
@@ -134,14 +137,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
   }
   int tA0 = 0, tA1 = 0, tB0 = 0, tB1 = 0;  // next K-tile index (relative to kt0) each slot stages (wave-uniform)
+  // Reduction-major operands are read with ds_read_b64_tr_b16, which carries no memory operand: with compiler-tracked LDS-DMA copies
+  // the compiler puts `s_waitcnt vmcnt(0)` in front of those reads and the ring never overlaps (this, not instruction issue, is what
+  // made these instantiations slow in round 1). They stage untracked; the counted waits below order the ring as for mode 0.
+  constexpr bool UNTRACKED = (AMODE != 0 || BMODE != 0) || MLA_GEMM256_UNTRACKED;
 
 #define STAGE(PTR, TCNT, STEP, SLOTOFF)                                                           \
   do {                                                                                            \
     const size_t back__ = (TCNT < nt) ? 0 : (size_t)TCNT * (STEP); /* dummy re-load of K-tile 0 past the end */ \
     char* dst__ = smem + (TCNT & 1) * BUF + (SLOTOFF) + wave * 2048;                              \
     if (!NO_STAGE || TCNT < 2) { /* ablation: the first two K-tiles are real, so LDS holds real operands */ \
-      glds16(PTR[0] - back__, dst__);                                                             \
-      glds16(PTR[1] - back__, dst__ + 1024);                                                      \
+      if (UNTRACKED) {                                                                            \
+        glds16_untracked(PTR[0] - back__, dst__);                                                 \
+        glds16_untracked(PTR[1] - back__, dst__ + 1024);                                          \
+      } else {                                                                                    \
+        glds16(PTR[0] - back__, dst__);                                                           \
+        glds16(PTR[1] - back__, dst__ + 1024);                                                    \
+      }                                                                                           \
     }                                                                                             \
     PTR[0] += (STEP); PTR[1] += (STEP); ++TCNT;                                                   \
   } while (0)
@@ -965,6 +977,27 @@ inline int choose_split(int tiles, int ncu, int nt, size_t ws_bytes, int* full_o
 
 template <int AM, int BM_>
 int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
+  if constexpr (AM != 0 || BM_ != 0) {   // reduction-major operands: the plain one-tile-per-workgroup launch only
+    static bool attr_rm = false;
+    if (!attr_rm) {
+      hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+      attr_rm = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (p.sk_split > 1) {
+      const int tail = tiles - p.sk_full;
+      hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(p.sk_full + tail * p.sk_split), dim3(512), 2 * BUF, stream, p);
+      hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
+    } else {
+      hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(tiles), dim3(512), 2 * BUF, stream, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      mla_set_error("gemm256 launch failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    return 0;
+  } else {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
@@ -1006,6 +1039,7 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
     return (int)e;
   }
   return 0;
+  }
 }
 
 }  // namespace
@@ -1067,11 +1101,11 @@ extern "C" int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const vo
 // called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>
 // instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream) {
-  if (a_mode != 0 || b_mode != 0) {
-    mla_set_error("gemm256: k-contiguous operands only");
+  GemmArgs p = *(const GemmArgs*)args;
+  if ((a_mode != 0 || b_mode != 0) && (p.sf_I || p.sw_gu || p.rope_cos)) {
+    mla_set_error("gemm256: the fused epilogues take k-contiguous operands only");
     return -1;
   }
-  GemmArgs p = *(const GemmArgs*)args;
   p.sk_split = 1;
   p.sk_full = 0;
   static int ncu = 0, persist = -1;
@@ -1096,5 +1130,9 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   const int grid = ncu & ~7;
   const bool use_p = (persist || (p.debug & 0x100)) && (p.debug & 0x80) == 0 && tiles > grid && bytesA < 0x7fffffffULL && bytesB < 0x7fffffffULL &&
                      p.sf_I == 0 && p.sw_gu == nullptr && p.rope_cos == nullptr;     // the persistent walk has the plain epilogue only
+  // reduction-major operands ([K, rows] storage, fragments gathered with ds_read_b64_tr_b16): plain epilogue, split-K tail allowed
+  if (a_mode == 0 && b_mode == 1) return launch256<0, 1>(p, stream, 0);
+  if (a_mode == 1 && b_mode == 0) return launch256<1, 0>(p, stream, 0);
+  if (a_mode == 1 && b_mode == 1) return launch256<1, 1>(p, stream, 0);
   return launch256<0, 0>(p, stream, use_p ? grid : 0);
 }
