@@ -66,3 +66,14 @@ for name, M, N, K, am, bm in (("qkv wgrad TN", 3 * H, H, T, 1, 1), ("down dgrad 
     t2 = timeit(lambda: hip.gemm(a, b, out=out, a_mode=am, b_mode=bm, force_generic=2))
     fl = 2.0 * M * N * K
     print(f"  {name:14s} gemm256 {t3:7.3f} ms ({fl / t3 / 1e9:6.0f} TF/s) | gemm128 {t2:7.3f} ms ({fl / t2 / 1e9:6.0f} TF/s)", flush=True)
+
+print("wgrad with ONE reduction-major operand (the other one k-contiguous, as the producers' fused transposed outputs provide it)")
+for name, nout, kin in (("qkv", 3 * H, H), ("o", H, H), ("gate|up", 2 * I, H), ("down", H, I)):
+    dy, x = rnd(T, nout), rnd(T, kin)
+    dyt, xt = hip.transpose(dy), hip.transpose(x)
+    o0 = torch.empty(nout, kin, dtype=torch.float32, device=dev)
+    t00 = timeit(lambda: hip.gemm(dyt, xt, out=o0))
+    t10 = timeit(lambda: hip.gemm(dy, xt, out=o0, a_mode=1))
+    t01 = timeit(lambda: hip.gemm(dyt, x, out=o0, b_mode=1))
+    print(f"  {name:8s} NT {t00:7.3f} ms | A as stored (a_mode 1) {t10:7.3f} ms ({(t10 - t00) * 1e3:+7.1f} us) | "
+          f"B as stored (b_mode 1) {t01:7.3f} ms ({(t01 - t00) * 1e3:+7.1f} us)", flush=True)
