@@ -199,7 +199,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()   # torch's current stream == the stream the kernel is launched on (see _stream())
-    if SPLITK and (force_generic & 15) == 0 and a_mode == 0 and b_mode == 0 and M >= 256 and N >= 256:
+    if SPLITK and (force_generic & 15) == 0 and M >= 256 and N >= 256:
         ws = workspace(SPLITK_WS_BYTES, a.device)      # per (device, stream) scratch owned by torch
         call("mla_gemm_bf16_ws", _p(a), _p(b), _p(out), _p(residual), _p(bias), M, N, K, lda, ldb, ldc, ldr or 0, a_mode, b_mode,
              out_fp32, 1 if accumulate else 0, float(alpha), int(force_generic), _p(ws), SPLITK_WS_BYTES)
