@@ -499,6 +499,20 @@ def test_adamw_embedding_misc(dev):
         hip.embedding_bwd(ids.to(dev), dy.to(dev), g2)
         assert torch.equal(g1, g2)
         assert fro_rel(g1, torch.zeros(vocab, Hh).index_add_(0, ids, dy.float())) < 1e-6
+    # full size (BASELINE configs[1] / [4] token counts, Llama-2 vocabulary): against torch's own index_add_ on the device, repeatable
+    for Tn in (17536, 65536):
+        gi = torch.Generator().manual_seed(Tn)
+        idb = torch.randint(0, 32000, (Tn // 548 if Tn == 17536 else 32, 548 if Tn == 17536 else 2048), generator=gi)
+        idb[:, -100:] = 32000                                  # <PAD> runs at the sequence ends
+        idb = idb.reshape(-1).to(dev)
+        dyb = bfr(Tn, 4096, seed=11, scale=0.05).to(dev)
+        ga, gb = torch.zeros(32064, 4096, device=dev), torch.zeros(32064, 4096, device=dev)
+        hip.embedding_bwd(idb, dyb, ga)
+        hip.embedding_bwd(idb, dyb, gb)
+        assert torch.equal(ga, gb)
+        refb = torch.zeros(32064, 4096, device=dev).index_add_(0, idb, dyb.float())
+        assert fro_rel(ga, refb) < 1e-6
+        del ga, gb, refb, dyb
     # casts / add / colsum / layernorm / q_sample
     x32 = torch.randn(1003, generator=g)
     assert torch.equal(hip.cast_f32_to_bf16(x32.to(dev)).cpu(), x32.to(BF))
