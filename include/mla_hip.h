@@ -46,6 +46,13 @@ int mla_gemm_bf16(const void* A, const void* B, void* C, const void* R, const vo
 int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N, int K, int lda, int ldb,
                      int ldc, int ldr, int a_mode, int b_mode, int out_fp32, int accumulate, float alpha, int force_generic,
                      float* workspace, size_t workspace_bytes, mla_stream_t stream);
+/* mla_gemm_bf16_ws with fp32 output (no bias / residual) that ALSO leaves sum(C^2) of the final values -- after `accumulate` -- as
+ * *sq_slots partial sums in sq_out (capacity in floats >= tiles + 16320, tiles = ceil(M/256) * ceil(N/256)): the contribution of a
+ * weight gradient to the clipping norm (training/strategies/fsdp.py:308-310) without a second pass over the fp32 gradient buffer.
+ * Fixed partial order, deterministic. Shapes of the 256x256 kernel only (M, N >= 256, K % 64 == 0, N % 8 == 0): error otherwise. */
+int mla_gemm_bf16_ws_sq(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
+                        float alpha, float* workspace, size_t workspace_bytes, float* sq_out, int sq_capacity, int* sq_slots,
+                        mla_stream_t stream);
 
 /* fused q|k|v projection + rotary embedding (LlamaAttention.forward modeling_llama.py:351-361 + apply_rotary_pos_emb :184-208):
  * C[M, N] = A[M, K] B[N, K]^T in bf16 with columns [0, rope_cols) rotated per head of 128 (position = row % S, tables [S, 64]
@@ -131,6 +138,8 @@ int mla_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long
                    float eps, float weight_decay, int step, const float* grad_scale, mla_stream_t stream);
 int mla_sumsq_f32(const float* x, long long n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
                   mla_stream_t stream);
+/* out[0] (+)= sum(partial[0 .. n)), fixed order: second stage of the gradient norm over mla_gemm_bf16_ws_sq partials */
+int mla_sum_partials(const float* partial, int n, float* out, int accumulate, mla_stream_t stream);
 int mla_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, mla_stream_t stream);
 
 /* ---- diffusion: GaussianDiffusion.q_sample models/diffusion/gaussian_diffusion.py:214-229 */

@@ -942,6 +942,13 @@ extern "C" int mla_sumsq_f32(const float* x, long long n, float* out, int accumu
   hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, stream, workspace, out, nb, accumulate);
   MLA_LAUNCH_CHECK();
 }
+// out[0] (+)= sum(partial[0 .. n)) in a fixed order (one workgroup): the second stage of the gradient norm when the first stage was
+// produced elsewhere (sum-of-squares partials of the wgrad GEMM epilogues, mla_gemm_bf16_ws_sq)
+extern "C" int mla_sum_partials(const float* partial, int n, float* out, int accumulate, hipStream_t stream) {
+  MLA_CHECK_ARG(partial && out && n >= 0, "mla_sum_partials: bad args");
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, stream, partial, out, n, accumulate);
+  MLA_LAUNCH_CHECK();
+}
 extern "C" int mla_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, hipStream_t stream) {
   MLA_CHECK_ARG(sumsq && coef, "mla_clip_coef: bad args");
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, max_norm, coef, norm_out);

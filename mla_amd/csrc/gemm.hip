@@ -19,7 +19,7 @@
 
 #include "gemm_args.h"
 
-int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream);  // gemm256.hip
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream, int* sq_slots = nullptr);  // gemm256.hip
 int mla_gemm_asm_dispatch(const void* args, hipStream_t stream);
 int mla_gemm_asm4_dispatch(const void* args, hipStream_t stream);                           // gemm_asm.hip
 
@@ -287,7 +287,7 @@ int launch128(const GemmArgs& p, hipStream_t stream, int nbatch = 1) {
 static int gemm_bf16_impl(const void* A, const void* B, void* C, const void* R, const void* bias, int M, int N,
                           int K, int lda, int ldb, int ldc, int ldr, int a_mode, int b_mode, int out_fp32,
                           int accumulate, float alpha, int force_generic, float* workspace, size_t workspace_bytes,
-                          hipStream_t stream) {
+                          hipStream_t stream, float* sq_out = nullptr, int sq_capacity = 0, int* sq_slots = nullptr) {
   MLA_CHECK_ARG(A && B && C, "mla_gemm_bf16: null operand");
   MLA_CHECK_ARG(M > 0 && N > 0 && K > 0, "mla_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
   MLA_CHECK_ARG((a_mode == 0 || a_mode == 1) && (b_mode == 0 || b_mode == 1), "mla_gemm_bf16: bad modes");
@@ -314,6 +314,14 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const void* R, 
   // force_generic == 5: the 4-wave (128 x 128 per wave) assembly kernel, same eligibility
   if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 5)
     return mla_gemm_asm4_dispatch(&p, stream);
+  if (sq_out) {   // sum-of-squares partials exist in the 256x256 kernel only; the caller sizes the buffer for the worst case
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    MLA_CHECK_ARG(mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 && force_generic == 0 && sq_slots != nullptr &&
+                      sq_capacity >= tiles + 64 * 255,
+                  "mla_gemm_bf16_ws_sq: shape outside the 256x256 kernel or sq_capacity < tiles + 16320");
+    p.sq_out = sq_out;
+    return mla_gemm256_dispatch(&p, a_mode, b_mode, workspace_bytes, stream, sq_slots);
+  }
   if (mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 && (force_generic == 0 || force_generic == 3))
     return mla_gemm256_dispatch(&p, a_mode, b_mode, force_generic == 0 ? workspace_bytes : 0, stream);
   if (mfma_ok) {
@@ -345,6 +353,18 @@ extern "C" int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const voi
   MLA_CHECK_ARG(workspace == nullptr || (((uintptr_t)workspace & 15) == 0), "mla_gemm_bf16_ws: workspace must be 16-byte aligned");
   return gemm_bf16_impl(A, B, C, R, bias, M, N, K, lda, ldb, ldc, ldr, a_mode, b_mode, out_fp32, accumulate, alpha, force_generic, workspace,
                         workspace_bytes, stream);
+}
+
+// mla_gemm_bf16_ws with fp32 output that also leaves sum(C^2) of the final values as *sq_slots partial sums in sq_out (capacity in
+// floats >= tiles + 16320): the gradient-norm contribution of a weight gradient without re-reading it (training/strategies/fsdp.py:
+// 308-310 clips by the global norm). Fixed partial order -> deterministic. 256x256-kernel shapes only (error otherwise).
+extern "C" int mla_gemm_bf16_ws_sq(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
+                                   float alpha, float* workspace, size_t workspace_bytes, float* sq_out, int sq_capacity, int* sq_slots,
+                                   hipStream_t stream) {
+  MLA_CHECK_ARG(sq_out && sq_slots, "mla_gemm_bf16_ws_sq: null sq_out / sq_slots");
+  MLA_CHECK_ARG(workspace == nullptr || (((uintptr_t)workspace & 15) == 0), "mla_gemm_bf16_ws_sq: workspace must be 16-byte aligned");
+  return gemm_bf16_impl(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, 0, 0, 1, accumulate, alpha, 0, workspace, workspace_bytes,
+                        stream, sq_out, sq_capacity, sq_slots);
 }
 
 // Batched form (no bias / residual): for z = (outer, inner) in [0, n_outer) x [0, n_inner):

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       }
       return;
     }
+    float sq = 0.f;                                // sum of squares of this lane's FINAL fp32 outputs (p.sq_out)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       if (hf) __syncthreads();                     // the readers of the first half are done
@@ -538,6 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
               float* c = (float*)p.C + (size_t)m * p.ldc + n;
               if (p.accumulate) o += *(const f32x4_t*)c;
               *(f32x4_t*)c = o;
+              sq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
             }
           }
         }
@@ -567,6 +569,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             }
           }
         }
+      }
+    }
+    if (p.sq_out) {          // uniform; fixed reduction order (lanes, then the 8 waves): deterministic
+      sq = wave_sum(sq);
+      __syncthreads();
+      if (lane == 0) ((float*)smem)[wave] = sq;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += ((float*)smem)[w];
+        p.sq_out[pid] = t;
       }
     }
     return;
@@ -924,6 +938,25 @@ __global__ __launch_bounds__(256) void gemm256_fixup_kernel(GemmArgs p) {
   const int e = ((blockIdx.x & 63) * 256 + threadIdx.x) * 4;
   const int ml = e >> 8, nl = e & 255;
   const int m = pid_m * 256 + ml, n = pid_n * 256 + nl;
+  if (p.sq_out) {            // sum(C^2) partial of this block (fp32 vector path only: checked by the dispatcher)
+    __shared__ float sq_s[16];
+    float sq = 0.f;
+    if (m < p.M && n < p.N) {
+      const float* src = p.sk_ws + (size_t)tile * p.sk_split * 65536 + ml * 256 + nl;
+      f32x4_t a = *(const f32x4_t*)src;
+      for (int sl = 1; sl < p.sk_split; ++sl) a += *(const f32x4_t*)(src + (size_t)sl * 65536);
+      f32x4_t o = a * p.alpha;
+      if (p.bias) { const u32x2_t bb = *(const u32x2_t*)(p.bias + n); o[0] += bflo(bb[0]); o[1] += bfhi(bb[0]); o[2] += bflo(bb[1]); o[3] += bfhi(bb[1]); }
+      if (p.R) { const u32x2_t rr = *(const u32x2_t*)(p.R + (size_t)m * p.ldr + n); o[0] += bflo(rr[0]); o[1] += bfhi(rr[0]); o[2] += bflo(rr[1]); o[3] += bfhi(rr[1]); }
+      float* c = (float*)p.C + (size_t)m * p.ldc + n;
+      if (p.accumulate) o += *(const f32x4_t*)c;
+      *(f32x4_t*)c = o;
+      sq = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+    }
+    sq = block_sum(sq, sq_s);
+    if (threadIdx.x == 0) p.sq_out[p.sk_full + blockIdx.x] = sq;
+    return;
+  }
   if (m >= p.M || n >= p.N) return;
   const float* src = p.sk_ws + (size_t)tile * p.sk_split * 65536 + ml * 256 + nl;
   f32x4_t a = *(const f32x4_t*)src;
@@ -1044,7 +1077,7 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
 
 }  // namespace
 
-int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream);
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream, int* sq_slots = nullptr);
 
 // Fused QKV projection + rotary embedding: C[M, N] = A[M, K] B[N, K]^T (bf16), columns [0, rope_cols) rotated per head of 128 with
 // position = row % S. Replaces hip.gemm + mla_rope_inplace on the packed q|k|v buffer (LlamaAttention.forward :351-361).
@@ -1100,7 +1133,7 @@ extern "C" int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const vo
 
 // called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>
 // instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.
-int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream) {
+int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream, int* sq_slots) {
   GemmArgs p = *(const GemmArgs*)args;
   if ((a_mode != 0 || b_mode != 0) && (p.sf_I || p.sw_gu || p.rope_cos)) {
     mla_set_error("gemm256: the fused epilogues take k-contiguous operands only");
@@ -1120,6 +1153,15 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
     persist = (e && e[0] == '1') ? 1 : 0;
   }
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  if (p.sq_out) {   // sum-of-squares partials: fp32 output through the whole-row (fast) epilogue, plain instantiation only
+    const bool ok = p.out_fp32 && a_mode == 0 && b_mode == 0 && !p.sf_I && !p.sw_gu && !p.rope_cos && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
+                    (((uintptr_t)p.C) & 15) == 0 && (p.R == nullptr || ((p.ldr & 7) == 0 && (((uintptr_t)p.R) & 15) == 0)) &&
+                    (p.bias == nullptr || (((uintptr_t)p.bias) & 15) == 0);
+    if (!ok) {
+      mla_set_error("gemm256: sum-of-squares partials need an fp32, 8-column-aligned output of the plain kernel");
+      return -1;
+    }
+  }
   if (p.sk_ws && ws_bytes) {
     int full = 0;
     const int s = choose_split(tiles, ncu, p.K / 64, ws_bytes, &full);
@@ -1129,7 +1171,8 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   const size_t bytesA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bytesB = ((size_t)(p.N - 1) * p.ldb + p.K) * 2;
   const int grid = ncu & ~7;
   const bool use_p = (persist || (p.debug & 0x100)) && (p.debug & 0x80) == 0 && tiles > grid && bytesA < 0x7fffffffULL && bytesB < 0x7fffffffULL &&
-                     p.sf_I == 0 && p.sw_gu == nullptr && p.rope_cos == nullptr;     // the persistent walk has the plain epilogue only
+                     p.sf_I == 0 && p.sw_gu == nullptr && p.rope_cos == nullptr && p.sq_out == nullptr;     // the persistent walk has the plain epilogue only
+  if (sq_slots) *sq_slots = p.sk_split > 1 ? p.sk_full + (tiles - p.sk_full) * 64 : tiles;
   // reduction-major operands ([K, rows] storage, fragments gathered with ds_read_b64_tr_b16): plain epilogue, split-K tail allowed
   if (a_mode == 0 && b_mode == 1) return launch256<0, 1>(p, stream, 0);
   if (a_mode == 1 && b_mode == 0) return launch256<1, 0>(p, stream, 0);

@@ -21,6 +21,10 @@ struct GemmArgs {
   // sk_split K-slices whose fp32 partial tiles go to sk_ws [unit][256][256]; a fix-up kernel sums them and applies the epilogue
   int sk_full, sk_split;
   float* sk_ws;
+  // fp32-output launches (wgrad into the fp32 gradient buffer) can also leave sum(C^2) of the FINAL values (after accumulate) as one
+  // partial per workgroup: slot = tile id for whole tiles, sk_full + 64 * tail_tile + block for the fix-up pass. The gradient norm of
+  // the step is then a sum over these partials instead of a second pass over the 4-B/parameter gradient buffer.
+  float* sq_out;
   // gemm256 bf16 fast epilogue only: rotary embedding applied to output columns [0, rope_cols) on the way out (heads of 128 columns,
   // pairs (d, d + 64), position = output row % rope_S; tables [rope_S, 64] fp32) -- the fused QKV projection (mla_gemm_qkv_rope)
   const float* rope_cos;

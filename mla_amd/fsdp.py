@@ -41,6 +41,9 @@ class HipLocalOps:
     def sumsq(self, x32, out1, accumulate):
         self.hip.sumsq(x32, out1, accumulate)
 
+    def sum_partials(self, partials, n, out1, accumulate):
+        self.hip.sum_partials(partials, n, out1, accumulate)
+
     def clip_coef(self, sumsq1, max_norm, coef1, norm1):
         self.hip.clip_coef(sumsq1, max_norm, coef1, norm1)
 
@@ -102,15 +105,41 @@ class FlatUnit:
             self.exp_avg = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
             self.exp_avg_sq = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
         # ---- re-point the module parameters at the bf16 compute storage; install fp32 main_grad views
+        # gradient-norm partials delivered by the wgrad GEMM epilogues (ops._gemm_into_main_grad): offset -> (numel, partials, count).
+        # Only without collectives: under FSDP the norm is taken over the REDUCED shards, which no local epilogue has seen.
+        self.sq_entries: Dict[int, Tuple[int, torch.Tensor, int]] = {}
+        self._offset_of = {id(p): o for _, p, o in self.params}
         for n, p, o in self.params:
             p.data = self.flat16[o:o + p.numel()].view(p.shape)
             if p.requires_grad:
                 p.main_grad = self.grad32[o:o + p.numel()].view(p.shape)
                 p._mg_touched = False
                 p._mg_dirty = False
+                if not coll and hasattr(ops, "sum_partials"):
+                    p._sq_sink = self._sq_sink
             p.grad = None
         self.gather_event = None
         self.rs_event = None
+
+    def _sq_sink(self, weights, partials, count) -> None:
+        """A wgrad launch wrote main_grad of `weights` (adjacent in the flat buffer) and left sum(dW^2) partials of the final values.
+        A later launch on the same range (gradient accumulation) replaces the entry: its partials are of the accumulated values."""
+        off = self._offset_of[id(weights[0])]
+        end = self._offset_of[id(weights[-1])] + weights[-1].numel()
+        self.sq_entries[off] = (end - off, partials, count)
+
+    def uncovered_ranges(self) -> List[Tuple[int, int]]:
+        """[a, b) pieces of the trainable gradient buffer that no sq_entries range covers (norm weights, biases, embeddings, ...)."""
+        out, pos = [], 0
+        for off in sorted(self.sq_entries):
+            n = self.sq_entries[off][0]
+            assert off >= pos, "overlapping gradient-norm ranges"
+            if off > pos:
+                out.append((pos, off))
+            pos = off + n
+        if pos < self.n_train:
+            out.append((pos, self.n_train))
+        return out
 
     # shard-local [lo, hi) intersections with the decay / no-decay regions (optimizer launches)
     def _shard_ranges(self):
@@ -124,6 +153,7 @@ class FlatUnit:
         return out
 
     def begin_step(self):
+        self.sq_entries = {}
         for _, p, _ in self.params:
             if p.requires_grad:
                 p._mg_touched = False
@@ -133,8 +163,10 @@ class FlatUnit:
     def collect_autograd_grads(self):
         """Gradients delivered by autograd into ``.grad`` (small broadcast parameters: queries, mask token, position tables) move
         into main_grad; called after every backward so that accumulation over micro-batches happens in fp32."""
-        for _, p, _ in self.params:
+        for _, p, o in self.params:
             if p.requires_grad and p.grad is not None:
+                for off in [k for k, e in self.sq_entries.items() if k <= o < k + e[0]]:
+                    del self.sq_entries[off]     # an autograd gradient lands on top of a wgrad epilogue's values: its partials are stale
                 if p._mg_touched:
                     p.main_grad.add_(p.grad.to(torch.float32))
                 else:
@@ -340,7 +372,24 @@ class ShardedModel:
         """Global L2 norm over the reduced gradient shards (+ scalar all-reduce), clip coefficient kept on device."""
         first = True
         for u in self.units:
-            if u.trainable:
+            if not u.trainable:
+                continue
+            if u.sq_entries and not self.coll:
+                # the big matrices' contributions come from their wgrad epilogues; only what no such launch wrote is read here
+                for n, part, count in u.sq_entries.values():
+                    self.ops.sum_partials(part, count, self._sumsq, not first)
+                    first = False
+                small = []
+                for a, b in u.uncovered_ranges():
+                    if b - a > (1 << 20):
+                        self.ops.sumsq(u.gshard[a:b], self._sumsq, not first)
+                        first = False
+                    else:
+                        small.append(u.gshard[a:b])
+                if small:
+                    self.ops.sumsq(torch.cat(small) if len(small) > 1 else small[0], self._sumsq, not first)
+                    first = False
+            else:
                 self.ops.sumsq(u.gshard, self._sumsq, not first)
                 first = False
         if self.coll:

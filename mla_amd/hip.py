@@ -35,6 +35,9 @@ _SIGNATURES = {
                          c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p],
     "mla_gemm_qkv_rope": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                           c_void_p],
+    "mla_gemm_bf16_ws_sq": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t,
+                            c_void_p, c_int, c_void_p, c_void_p],
+    "mla_sum_partials": [c_void_p, c_int, c_void_p, c_int, c_void_p],
     "mla_gemm_gateup_swiglu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
                                c_void_p],
     "mla_gemm_dact_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
@@ -210,6 +213,38 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (a_mode, b_mode, M, N, K)))
     return out
+
+
+def gemm_sq(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, accumulate: bool):
+    """out[M, N] (fp32) (+)= a[M, K] b[N, K]^T like gemm(), and sum(out^2) of the FINAL values as partial sums: returns
+    (partials fp32 tensor, number of valid partials) -- or None when the shape is outside the 256x256 kernel (the caller then runs
+    gemm() and the gradient norm reads the buffer as before). mla_sum_partials adds the partials up in a fixed order."""
+    M, K = a.shape
+    N = b.shape[0]
+    ok = (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and out.dtype == torch.float32 and b.shape[1] == K and
+          a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and M >= 256 and N >= 256 and K % 64 == 0 and N % 8 == 0 and
+          a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and
+          all(t.data_ptr() % 16 == 0 for t in (a, b, out)) and tuple(out.shape) == (M, N))
+    if not ok:
+        return None
+    cap = ((M + 255) // 256) * ((N + 255) // 256) + 64 * 255
+    part = torch.empty(cap, dtype=torch.float32, device=out.device)
+    slots = ctypes.c_int(0)
+    ws = workspace(SPLITK_WS_BYTES, a.device) if SPLITK else None
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("mla_gemm_bf16_ws_sq", _p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), 1 if accumulate else 0, 1.0,
+         _p(ws), SPLITK_WS_BYTES if ws is not None else 0, _p(part), cap, ctypes.byref(slots))
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (0, 0, M, N, K)))
+    return part, int(slots.value)
+
+
+def sum_partials(partials: torch.Tensor, n: int, out1: torch.Tensor, accumulate: bool):
+    call("mla_sum_partials", _p(partials), int(n), _p(out1), 1 if accumulate else 0)
 
 
 def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols):

@@ -90,6 +90,24 @@ def deliver_wgrad(weights: Sequence[torch.Tensor], dy2: torch.Tensor, x2: torch.
     return grads
 
 
+_WGRAD_SQ = os.environ.get("MLA_WGRAD_SQ", "1") != "0"      # A/B switch (tools): gradient-norm partials from the wgrad epilogues
+
+
+def _gemm_into_main_grad(weights, dyT, xT, out, accumulate: bool) -> None:
+    """dW (+)= dyT xT^T into the fp32 gradient buffer. When the owner of the buffer collects the clipping norm itself (one process,
+    no reduce-scatter: FlatUnit.sq_sink) the same launch also leaves sum(dW^2) of the final values as partial sums, so the norm
+    never re-reads these 4 bytes per parameter (training/strategies/fsdp.py:308-310)."""
+    sink = getattr(weights[0], "_sq_sink", None) if _WGRAD_SQ else None
+    owner = getattr(sink, "__self__", None)      # (a bound method is a fresh object per access: compare the owners)
+    if sink is not None and all(getattr(getattr(w, "_sq_sink", None), "__self__", None) is owner and
+                                getattr(w, "_mg_region", None) is None for w in weights):
+        res = hip.gemm_sq(dyT, xT, out, accumulate)
+        if res is not None:
+            sink(weights, res[0], res[1])
+            return
+    hip.gemm(dyT, xT, out=out, accumulate=accumulate)
+
+
 def deliver_wgrad_nt(weights: Sequence[torch.Tensor], dyT: torch.Tensor, xT: torch.Tensor, needs: Sequence[bool]):
     """Same as deliver_wgrad with pre-transposed operands: dW_i = dyT[rows_i] @ xT^T  (dyT [sum N_i, T], xT [K, T], both
     k-contiguous -> the fast NT kernel)."""
@@ -99,7 +117,7 @@ def deliver_wgrad_nt(weights: Sequence[torch.Tensor], dyT: torch.Tensor, xT: tor
         mcat = cat_view(mgs)
         states = {_is_touched(w) for w in weights}
         if mcat is not None and len(states) == 1:
-            hip.gemm(dyT, xT, out=mcat, accumulate=states.pop())
+            _gemm_into_main_grad(weights, dyT, xT, mcat, states.pop())
             for w in weights:
                 _mark_touched(w)
             return grads
@@ -108,7 +126,7 @@ def deliver_wgrad_nt(weights: Sequence[torch.Tensor], dyT: torch.Tensor, xT: tor
         n = w.shape[0]
         if needs[i]:
             if mgs[i] is not None:
-                hip.gemm(dyT[off:off + n], xT, out=mgs[i], accumulate=_touch(w))
+                _gemm_into_main_grad((w,), dyT[off:off + n], xT, mgs[i], _touch(w))
             else:
                 grads[i] = hip.gemm(dyT[off:off + n], xT, out_dtype=torch.float32).to(w.dtype)
         off += n

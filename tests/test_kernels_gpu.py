@@ -374,6 +374,30 @@ def test_attention_bwd_transposed_outputs_are_bit_identical(dev, S, lens):
     assert bool((dT[:, T:] == marker).all()) and bool((oT[:, T:] == marker).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 1088), (768, 512, 256), (4096 + 256 * 3, 4096, 640)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_sum_of_squares_partials(dev, M, N, K, accumulate):
+    """mla_gemm_bf16_ws_sq: same fp32 result as mla_gemm_bf16_ws, bit for bit, plus sum(C^2) of the FINAL values as partial sums
+    (whole tiles and the split-K fix-up blocks) -- the wgrad contribution to the clipping norm, training/strategies/fsdp.py:308-310."""
+    from mla_amd import hip
+    a, b = bfr(M, K, seed=31).to(dev), bfr(N, K, seed=32, scale=0.05).to(dev)
+    base = (torch.randn(M, N, generator=torch.Generator().manual_seed(33)) * 0.1).to(dev)
+    ref, out = base.clone(), base.clone()
+    hip.gemm(a, b, out=ref, accumulate=accumulate)
+    res = hip.gemm_sq(a, b, out, accumulate)
+    assert res is not None
+    part, cnt = res
+    assert torch.equal(out, ref)
+    tot = torch.zeros(1, device=dev)
+    hip.sum_partials(part, cnt, tot, False)
+    want = float((ref.double() ** 2).sum())
+    assert abs(float(tot) - want) < 2e-6 * want, (float(tot), want)
+    tot2 = torch.full((1,), 5.0, device=dev)
+    hip.sum_partials(part, cnt, tot2, True)
+    assert abs(float(tot2) - 5.0 - want) < 2e-6 * want + 1e-3
+    assert hip.gemm_sq(a[:, :K - 32], b[:, :K - 32], out, accumulate) is None      # outside the 256x256 kernel: the caller falls back
+
+
 def test_attention_full_size_config4_properties(dev):
     """BASELINE configs[4] attention at FULL size (S = 2048, 32 heads x 128; 2 sequences, one ragged) through size-independent
     properties, no CPU reference needed:
