@@ -47,9 +47,10 @@ int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const
                      int ldc, int ldr, int a_mode, int b_mode, int out_fp32, int accumulate, float alpha, int force_generic,
                      float* workspace, size_t workspace_bytes, mla_stream_t stream);
 /* mla_gemm_bf16_ws with fp32 output (no bias / residual) that ALSO leaves sum(C^2) of the final values -- after `accumulate` -- as
- * *sq_slots partial sums in sq_out (capacity in floats >= tiles + 16320, tiles = ceil(M/256) * ceil(N/256)): the contribution of a
+ * *sq_slots partial sums in sq_out (capacity in floats >= mla_gemm_sq_slots(M, N, K, workspace_bytes)): the contribution of a
  * weight gradient to the clipping norm (training/strategies/fsdp.py:308-310) without a second pass over the fp32 gradient buffer.
  * Fixed partial order, deterministic. Shapes of the 256x256 kernel only (M, N >= 256, K % 64 == 0, N % 8 == 0): error otherwise. */
+int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes);   /* partials the launch below writes; -1 = shape not supported */
 int mla_gemm_bf16_ws_sq(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
                         float alpha, float* workspace, size_t workspace_bytes, float* sq_out, int sq_capacity, int* sq_slots,
                         mla_stream_t stream);

@@ -20,6 +20,7 @@
 #include "gemm_args.h"
 
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream, int* sq_slots = nullptr);  // gemm256.hip
+extern "C" int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes);                                                          // gemm256.hip
 int mla_gemm_asm_dispatch(const void* args, hipStream_t stream);
 int mla_gemm_asm4_dispatch(const void* args, hipStream_t stream);                           // gemm_asm.hip
 
@@ -316,9 +317,11 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const void* R, 
     return mla_gemm_asm4_dispatch(&p, stream);
   if (sq_out) {   // sum-of-squares partials exist in the 256x256 kernel only; the caller sizes the buffer for the worst case
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    MLA_CHECK_ARG(mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 && force_generic == 0 && sq_slots != nullptr &&
-                      sq_capacity >= tiles + 64 * 255,
-                  "mla_gemm_bf16_ws_sq: shape outside the 256x256 kernel or sq_capacity < tiles + 16320");
+    MLA_CHECK_ARG(mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 && force_generic == 0 && sq_slots != nullptr,
+                  "mla_gemm_bf16_ws_sq: shape outside the 256x256 kernel");
+    const int need = mla_gemm_sq_slots(M, N, K, workspace ? workspace_bytes : 0);
+    MLA_CHECK_ARG(need > 0 && sq_capacity >= need, "mla_gemm_bf16_ws_sq: sq_capacity %d < %d (mla_gemm_sq_slots)", sq_capacity, need);
+    (void)tiles;
     p.sq_out = sq_out;
     return mla_gemm256_dispatch(&p, a_mode, b_mode, workspace_bytes, stream, sq_slots);
   }
@@ -356,7 +359,7 @@ extern "C" int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const voi
 }
 
 // mla_gemm_bf16_ws with fp32 output that also leaves sum(C^2) of the final values as *sq_slots partial sums in sq_out (capacity in
-// floats >= tiles + 16320): the gradient-norm contribution of a weight gradient without re-reading it (training/strategies/fsdp.py:
+// floats >= mla_gemm_sq_slots(M, N, K, workspace_bytes)): the gradient-norm contribution of a weight gradient without re-reading it (training/strategies/fsdp.py:
 // 308-310 clips by the global norm). Fixed partial order -> deterministic. 256x256-kernel shapes only (error otherwise).
 extern "C" int mla_gemm_bf16_ws_sq(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
                                    float alpha, float* workspace, size_t workspace_bytes, float* sq_out, int sq_capacity, int* sq_slots,

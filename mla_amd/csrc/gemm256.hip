@@ -1133,6 +1133,23 @@ extern "C" int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const vo
 
 // called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>
 // instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.
+// number of sum-of-squares partials a k-contiguous fp32-output launch of this shape writes (whole tiles + 64 per split tile): lets the
+// caller reserve exactly that many floats in a shared buffer and sum the whole buffer in one launch afterwards
+extern "C" int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes) {
+  if (M < 256 || N < 256 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return -1;
+  int ncu = 0, dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (ncu <= 0) ncu = 256;
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  if (workspace_bytes) {
+    int full = 0;
+    const int s = choose_split(tiles, ncu, K / 64, workspace_bytes, &full);
+    if (s > 1 && full % 8 == 0) return full + (tiles - full) * 64;
+  }
+  return tiles;
+}
+
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream, int* sq_slots) {
   GemmArgs p = *(const GemmArgs*)args;
   if ((a_mode != 0 || b_mode != 0) && (p.sf_I || p.sw_gu || p.rope_cos)) {

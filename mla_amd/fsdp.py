@@ -51,6 +51,22 @@ class HipLocalOps:
         return torch.cuda.Stream(device=device)
 
 
+class _SqArena:
+    """Bump allocator over one fp32 buffer: every wgrad launch of a step takes the slice its sum-of-squares partials go to; the
+    gradient norm then sums the used prefix in one launch. Reset at the start of every step."""
+
+    def __init__(self, n: int, device):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.used = 0
+
+    def take(self, count: int):
+        if self.used + count > self.buf.numel():
+            return None
+        part = self.buf[self.used:self.used + count]
+        self.used += count
+        return part
+
+
 def _round_up(n, m):
     return ((n + m - 1) // m) * m
 
@@ -107,7 +123,8 @@ class FlatUnit:
         # ---- re-point the module parameters at the bf16 compute storage; install fp32 main_grad views
         # gradient-norm partials delivered by the wgrad GEMM epilogues (ops._gemm_into_main_grad): offset -> (numel, partials, count).
         # Only without collectives: under FSDP the norm is taken over the REDUCED shards, which no local epilogue has seen.
-        self.sq_entries: Dict[int, Tuple[int, torch.Tensor, int]] = {}
+        self.sq_entries: Dict[int, Tuple[int, int, int]] = {}      # offset -> (numel, arena offset, partial count)
+        self.sq_arena = None                                        # set by ShardedModel (one arena for all units)
         self._offset_of = {id(p): o for _, p, o in self.params}
         for n, p, o in self.params:
             p.data = self.flat16[o:o + p.numel()].view(p.shape)
@@ -121,12 +138,24 @@ class FlatUnit:
         self.gather_event = None
         self.rs_event = None
 
-    def _sq_sink(self, weights, partials, count) -> None:
-        """A wgrad launch wrote main_grad of `weights` (adjacent in the flat buffer) and left sum(dW^2) partials of the final values.
-        A later launch on the same range (gradient accumulation) replaces the entry: its partials are of the accumulated values."""
+    def _sq_sink(self, weights, count):
+        """A wgrad launch is about to write main_grad of `weights` (adjacent in the flat buffer) and to leave `count` sum(dW^2)
+        partials of the final values: returns where they go (a slice of the model-wide arena, summed by ONE launch at clipping
+        time) or None when the arena is full. A later launch on the same range (gradient accumulation) supersedes the earlier
+        one: its partials are of the accumulated values, the old slice is zeroed."""
+        arena = self.sq_arena
+        if arena is None:
+            return None
         off = self._offset_of[id(weights[0])]
         end = self._offset_of[id(weights[-1])] + weights[-1].numel()
-        self.sq_entries[off] = (end - off, partials, count)
+        old = self.sq_entries.pop(off, None)
+        if old is not None:
+            arena.buf[old[1]:old[1] + old[2]].zero_()
+        part = arena.take(count)
+        if part is None:
+            return None
+        self.sq_entries[off] = (end - off, part.storage_offset(), count)
+        return part
 
     def uncovered_ranges(self) -> List[Tuple[int, int]]:
         """[a, b) pieces of the trainable gradient buffer that no sq_entries range covers (norm weights, biases, embeddings, ...)."""
@@ -166,7 +195,8 @@ class FlatUnit:
         for _, p, o in self.params:
             if p.requires_grad and p.grad is not None:
                 for off in [k for k, e in self.sq_entries.items() if k <= o < k + e[0]]:
-                    del self.sq_entries[off]     # an autograd gradient lands on top of a wgrad epilogue's values: its partials are stale
+                    e = self.sq_entries.pop(off)  # an autograd gradient lands on top of a wgrad epilogue's values: its partials are stale
+                    self.sq_arena.buf[e[1]:e[1] + e[2]].zero_()
                 if p._mg_touched:
                     p.main_grad.add_(p.grad.to(torch.float32))
                 else:
@@ -247,6 +277,11 @@ class ShardedModel:
         self.step_count = 0
         self.defer_reduce = False     # gradient accumulation: micro-batches before the last one only add into main_grad
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        # arena of the wgrad epilogues' sum-of-squares partials (FlatUnit._sq_sink): ~1.4 K floats per decoder-layer GEMM at 7B
+        self._sq_arena = _SqArena(1 << 20, device) if (not self.coll and hasattr(self.ops, "sum_partials") and
+                                                       self.device.type == "cuda") else None
+        for u in self.units:
+            u.sq_arena = self._sq_arena
         self._coef = torch.ones(1, dtype=torch.float32, device=device)
         self._norm = torch.zeros(1, dtype=torch.float32, device=device)
         self.on_gpu = self.device.type == "cuda"
@@ -337,6 +372,8 @@ class ShardedModel:
 
     # ------------------------------------------------------------------------------------------ step API
     def begin_step(self):
+        if self._sq_arena is not None:
+            self._sq_arena.used = 0
         for u in self.units:
             u.begin_step()
             u.rs_event = None
@@ -371,27 +408,28 @@ class ShardedModel:
     def grad_norm_and_clip(self, max_norm: Optional[float]):
         """Global L2 norm over the reduced gradient shards (+ scalar all-reduce), clip coefficient kept on device."""
         first = True
+        small: List[torch.Tensor] = []
         for u in self.units:
             if not u.trainable:
                 continue
             if u.sq_entries and not self.coll:
-                # the big matrices' contributions come from their wgrad epilogues; only what no such launch wrote is read here
-                for n, part, count in u.sq_entries.values():
-                    self.ops.sum_partials(part, count, self._sumsq, not first)
-                    first = False
-                small = []
+                # the big matrices' contributions come from their wgrad epilogues (arena, below); only what no such launch wrote
+                # is read here: large pieces (embeddings) in place, the small ones (norm weights, biases) of all units together
                 for a, b in u.uncovered_ranges():
                     if b - a > (1 << 20):
                         self.ops.sumsq(u.gshard[a:b], self._sumsq, not first)
                         first = False
                     else:
                         small.append(u.gshard[a:b])
-                if small:
-                    self.ops.sumsq(torch.cat(small) if len(small) > 1 else small[0], self._sumsq, not first)
-                    first = False
             else:
                 self.ops.sumsq(u.gshard, self._sumsq, not first)
                 first = False
+        if small:
+            self.ops.sumsq(torch.cat(small) if len(small) > 1 else small[0], self._sumsq, not first)
+            first = False
+        if self._sq_arena is not None and self._sq_arena.used:
+            self.ops.sum_partials(self._sq_arena.buf, self._sq_arena.used, self._sumsq, not first)    # every wgrad epilogue's partials
+            first = False
         if self.coll:
             dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.pg)
         self.ops.clip_coef(self._sumsq, float(max_norm) if max_norm is not None else 3.0e38, self._coef, self._norm)

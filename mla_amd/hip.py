@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mla_gemm_bf16_ws_sq": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t,
                             c_void_p, c_int, c_void_p, c_void_p],
     "mla_sum_partials": [c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "mla_gemm_sq_slots": [c_int, c_int, c_int, c_size_t],
     "mla_gemm_gateup_swiglu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
                                c_void_p],
     "mla_gemm_dact_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
@@ -215,10 +216,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
     return out
 
 
-def gemm_sq(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, accumulate: bool):
-    """out[M, N] (fp32) (+)= a[M, K] b[N, K]^T like gemm(), and sum(out^2) of the FINAL values as partial sums: returns
-    (partials fp32 tensor, number of valid partials) -- or None when the shape is outside the 256x256 kernel (the caller then runs
-    gemm() and the gradient norm reads the buffer as before). mla_sum_partials adds the partials up in a fixed order."""
+def gemm_sq_slots(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> int:
+    """Number of sum-of-squares partials gemm_sq() writes for these operands, or -1 when the shape is outside its contract."""
     M, K = a.shape
     N = b.shape[0]
     ok = (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and out.dtype == torch.float32 and b.shape[1] == K and
@@ -226,9 +225,23 @@ def gemm_sq(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, accumulate: boo
           a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and
           all(t.data_ptr() % 16 == 0 for t in (a, b, out)) and tuple(out.shape) == (M, N))
     if not ok:
+        return -1
+    return int(lib().mla_gemm_sq_slots(M, N, K, SPLITK_WS_BYTES if SPLITK else 0))
+
+
+def gemm_sq(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, accumulate: bool, part: Optional[torch.Tensor] = None):
+    """out[M, N] (fp32) (+)= a[M, K] b[N, K]^T like gemm(), and sum(out^2) of the FINAL values as partial sums written to `part`
+    (fp32, >= gemm_sq_slots() elements; allocated here when None): returns (part, number of valid partials) -- or None when the shape
+    is outside the 256x256 kernel (the caller then runs gemm() and the gradient norm reads the buffer as before).
+    mla_sum_partials adds the partials up in a fixed order."""
+    need = gemm_sq_slots(a, b, out)
+    if need < 0:
         return None
-    cap = ((M + 255) // 256) * ((N + 255) // 256) + 64 * 255
-    part = torch.empty(cap, dtype=torch.float32, device=out.device)
+    M, K = a.shape
+    N = b.shape[0]
+    if part is None:
+        part = torch.empty(need, dtype=torch.float32, device=out.device)
+    assert part.dtype == torch.float32 and part.is_contiguous() and part.numel() >= need
     slots = ctypes.c_int(0)
     ws = workspace(SPLITK_WS_BYTES, a.device) if SPLITK else None
     prof = GEMM_PROFILE
@@ -236,11 +249,12 @@ def gemm_sq(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, accumulate: boo
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     call("mla_gemm_bf16_ws_sq", _p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), 1 if accumulate else 0, 1.0,
-         _p(ws), SPLITK_WS_BYTES if ws is not None else 0, _p(part), cap, ctypes.byref(slots))
+         _p(ws), SPLITK_WS_BYTES if ws is not None else 0, _p(part), part.numel(), ctypes.byref(slots))
+    assert int(slots.value) == need
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (0, 0, M, N, K)))
-    return part, int(slots.value)
+    return part, need
 
 
 def sum_partials(partials: torch.Tensor, n: int, out1: torch.Tensor, accumulate: bool):

@@ -101,10 +101,12 @@ def _gemm_into_main_grad(weights, dyT, xT, out, accumulate: bool) -> None:
     owner = getattr(sink, "__self__", None)      # (a bound method is a fresh object per access: compare the owners)
     if sink is not None and all(getattr(getattr(w, "_sq_sink", None), "__self__", None) is owner and
                                 getattr(w, "_mg_region", None) is None for w in weights):
-        res = hip.gemm_sq(dyT, xT, out, accumulate)
-        if res is not None:
-            sink(weights, res[0], res[1])
-            return
+        need = hip.gemm_sq_slots(dyT, xT, out)
+        if need > 0:
+            part = sink(weights, need)                       # `need` floats of the owner's partial-sum arena (None: arena full)
+            if part is not None:
+                hip.gemm_sq(dyT, xT, out, accumulate, part)
+                return
     hip.gemm(dyT, xT, out=out, accumulate=accumulate)
 
 

@@ -384,9 +384,11 @@ def test_gemm_sum_of_squares_partials(dev, M, N, K, accumulate):
     base = (torch.randn(M, N, generator=torch.Generator().manual_seed(33)) * 0.1).to(dev)
     ref, out = base.clone(), base.clone()
     hip.gemm(a, b, out=ref, accumulate=accumulate)
-    res = hip.gemm_sq(a, b, out, accumulate)
+    arena = torch.full((hip.gemm_sq_slots(a, b, out) + 7,), 3.0, device=dev)
+    res = hip.gemm_sq(a, b, out, accumulate, arena[:-7])
     assert res is not None
     part, cnt = res
+    assert cnt == arena.numel() - 7 and bool((arena[-7:] == 3.0).all())       # exactly gemm_sq_slots() partials are written
     assert torch.equal(out, ref)
     tot = torch.zeros(1, device=dev)
     hip.sum_partials(part, cnt, tot, False)
