@@ -69,6 +69,11 @@ def _run(rank, world, dev, accumulate=False):
             out = micro(None if world == 1 else rank)
             losses.append(float(out["total_loss"]))
         norms.append(float(strat.sharded._norm))
+        if world == 1:
+            # the clipping norm is assembled from the wgrad epilogues' sum-of-squares partials (superseded per micro-batch inside an
+            # accumulation window) + a pass over what they did not write: it must equal the norm of the fp32 gradient buffers
+            direct = sum(float((u.grad32.double() ** 2).sum()) for u in strat.sharded.units if u.trainable) ** 0.5
+            assert abs(norms[-1] - direct) < 1e-5 * direct, (norms[-1], direct)
     assert strat.step == STEPS
     full = strat.sharded.full_state_dict_fp32()
     keys = ("vlm.llm_backbone.llm.model.layers.3.mlp.down_proj.weight", "vlm.llm_backbone.llm.model.layers.0.self_attn.q_proj.weight",
