@@ -137,6 +137,10 @@ int mla_embedding_bwd(const long long* ids, const void* dy, float* grad, float* 
 /* ---- optimizer: AdamW (training/strategies/fsdp.py:257) over the local fp32 shard + bf16 compute copy; clip (:308-310) */
 int mla_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, const float* grad_scale, mla_stream_t stream);
+/* the same update over a flat range laid out [weight-decayed | not decayed]: elements [0, n_decay) get weight_decay, the rest none --
+ * both AdamW parameter groups of a sharding unit (training/strategies/fsdp.py:231-257) in one launch */
+int mla_adamw_step_groups(float* p, const float* g, float* m, float* v, void* p16, long long n, long long n_decay, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int step, const float* grad_scale, mla_stream_t stream);
 int mla_sumsq_f32(const float* x, long long n, float* out, int accumulate, float* workspace, size_t workspace_bytes,
                   mla_stream_t stream);
 /* out[0] (+)= sum(partial[0 .. n)), fixed order: second stage of the gradient norm over mla_gemm_bf16_ws_sq partials */

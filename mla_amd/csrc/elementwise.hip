@@ -638,18 +638,28 @@ __global__ __launch_bounds__(64 * EMB_MAX_WAVES) void embedding_bwd_kernel(const
 // Optimizer: fused AdamW over the local fp32 shard, also refreshes the bf16 compute copy
 // (reference: torch.optim.AdamW built at training/strategies/fsdp.py:257; clip at :308-310)
 // ---------------------------------------------------------------------------------------------------------
+// One element of the update with every contraction spelled out: written as plain a * b + c the compiler is free to fuse either
+// product, and it chooses differently in differently shaped copies of the loop (measured: the two-group launch differed from the
+// one-group launch in the last bit of 24 % of the moments). decay = 1 - lr * wd or 1.
+__device__ __forceinline__ void adamw_elem(float& p, float g, float& m, float& v, float gs, float decay, float beta1, float beta2,
+                                           float step, float isq, float eps) {
+  const float gg = g * gs;
+  const float mm = fmaf(beta1, m, (1.f - beta1) * gg);
+  const float vv = fmaf(beta2, v, ((1.f - beta2) * gg) * gg);
+  const float den = fmaf(sqrtf(vv), isq, eps);
+  p = fmaf(-step, mm / den, p * decay);
+  m = mm;
+  v = vv;
+}
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ p16, long long n, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                                                    const float* __restrict__ grad_scale) {
+                                                    const float* __restrict__ grad_scale, long long n_decay) {
   const float gs = grad_scale ? *grad_scale : 1.f;
   const float step = lr / bc1, isq = 1.f / sqrtf(bc2);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float gg = g[i] * gs;
-    float pp = p[i] * (1.f - lr * wd);
-    const float mm = beta1 * m[i] + (1.f - beta1) * gg;
-    const float vv = beta2 * v[i] + (1.f - beta2) * gg * gg;
-    pp -= step * mm / (sqrtf(vv) * isq + eps);
+    float pp = p[i], mm = m[i], vv = v[i];
+    adamw_elem(pp, g[i], mm, vv, gs, i < n_decay ? 1.f - lr * wd : 1.f, beta1, beta2, step, isq, eps);
     p[i] = pp; m[i] = mm; v[i] = vv;
     if (p16) p16[i] = f2bf(pp);
   }
@@ -660,19 +670,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 __global__ __launch_bounds__(256) void adamw_vec4_kernel(f32x4_t* __restrict__ p, const f32x4_t* __restrict__ g, f32x4_t* __restrict__ m,
                                                          f32x4_t* __restrict__ v, u32x2_t* __restrict__ p16, long long n4, float lr,
                                                          float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                                                         const float* __restrict__ grad_scale) {
+                                                         const float* __restrict__ grad_scale, long long n4_decay) {
   const float gs = grad_scale ? *grad_scale : 1.f;
-  const float step = lr / bc1, isq = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+  const float step = lr / bc1, isq = 1.f / sqrtf(bc2), decay_on = 1.f - lr * wd;
   MLA_CHUNK_LOOP(i, n4) {
+    const float decay = i < n4_decay ? decay_on : 1.f;     // groups [0, n4_decay) are weight-decayed, the rest (norms, biases) not
     const f32x4_t g4 = __builtin_nontemporal_load(g + i);
     f32x4_t p4 = __builtin_nontemporal_load(p + i), m4 = __builtin_nontemporal_load(m + i), v4 = __builtin_nontemporal_load(v + i);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float gg = g4[r] * gs;
-      float pp = p4[r] * decay;
-      const float mm = beta1 * m4[r] + (1.f - beta1) * gg;
-      const float vv = beta2 * v4[r] + (1.f - beta2) * gg * gg;
-      pp -= step * mm / (sqrtf(vv) * isq + eps);
+      float pp = p4[r], mm = m4[r], vv = v4[r];
+      adamw_elem(pp, g4[r], mm, vv, gs, decay, beta1, beta2, step, isq, eps);
       p4[r] = pp; m4[r] = mm; v4[r] = vv;
     }
     // every stream is touched exactly once per step: non-temporal loads and stores (+3 % stand-alone, tools/bench_adamw.py)
@@ -928,21 +936,35 @@ extern "C" int mla_embedding_bwd(const long long* ids, const void* dy, float* gr
   MLA_LAUNCH_CHECK();
 }
 
-extern "C" int mla_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long long n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, const float* grad_scale,
-                              hipStream_t stream) {
-  MLA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "mla_adamw_step: bad args");
+static int adamw_impl(float* p, const float* g, float* m, float* v, void* p16, long long n, long long n_decay, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int step, const float* grad_scale, hipStream_t stream) {
+  MLA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1 && n_decay >= 0 && n_decay <= n, "mla_adamw_step: bad args");
   if (n == 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  const long long n4 = (AL16(p) && AL16(g) && AL16(m) && AL16(v) && (p16 == nullptr || ((uintptr_t)p16 & 7) == 0)) ? n / 4 : 0;
+  // (the decay boundary must not cut a 16-B group: otherwise everything goes through the scalar kernel)
+  const long long n4 = (AL16(p) && AL16(g) && AL16(m) && AL16(v) && (p16 == nullptr || ((uintptr_t)p16 & 7) == 0) && (n_decay & 3) == 0) ? n / 4 : 0;
   if (n4)
     hipLaunchKernelGGL(adamw_vec4_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, stream, (f32x4_t*)p, (const f32x4_t*)g, (f32x4_t*)m,
-                       (f32x4_t*)v, (u32x2_t*)p16, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                       (f32x4_t*)v, (u32x2_t*)p16, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, n_decay / 4);
   const long long done = n4 * 4;
   if (done < n)
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n - done, 8192)), dim3(256), 0, stream, p + done, g + done, m + done, v + done,
-                       p16 ? (bf16_t*)p16 + done : (bf16_t*)nullptr, n - done, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                       p16 ? (bf16_t*)p16 + done : (bf16_t*)nullptr, n - done, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
+                       n_decay > done ? n_decay - done : 0);
   MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_adamw_step(float* p, const float* g, float* m, float* v, void* p16, long long n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, const float* grad_scale,
+                              hipStream_t stream) {
+  return adamw_impl(p, g, m, v, p16, n, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
+}
+// One launch for a flat parameter range laid out [weight-decayed | not decayed] (FlatUnit: matrices first, then norm weights and
+// biases): elements [0, n_decay) get `weight_decay`, the rest none -- the reference's two AdamW parameter groups
+// (training/strategies/fsdp.py:231-257) without a second launch per unit.
+extern "C" int mla_adamw_step_groups(float* p, const float* g, float* m, float* v, void* p16, long long n, long long n_decay, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_scale,
+                                     hipStream_t stream) {
+  return adamw_impl(p, g, m, v, p16, n, n_decay, lr, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
 }
 
 // out[0] (+)= sum(x^2); workspace >= 2048 floats

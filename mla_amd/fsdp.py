@@ -38,6 +38,9 @@ class HipLocalOps:
     def adamw(self, p32, g32, m, v, p16, lr, betas, eps, wd, step, grad_scale):
         self.hip.adamw_step(p32, g32, m, v, p16, lr, betas[0], betas[1], eps, wd, step, grad_scale)
 
+    def adamw_groups(self, p32, g32, m, v, p16, n_decay, lr, betas, eps, wd, step, grad_scale):
+        self.hip.adamw_step_groups(p32, g32, m, v, p16, n_decay, lr, betas[0], betas[1], eps, wd, step, grad_scale)
+
     def sumsq(self, x32, out1, accumulate):
         self.hip.sumsq(x32, out1, accumulate)
 
@@ -441,10 +444,21 @@ class ShardedModel:
         for u in self.units:
             if not u.trainable:
                 continue
-            for ls, le, g0, decayed in u._shard_ranges():
-                self.ops.adamw(u.master_train[ls:le], u.gshard[ls:le], u.exp_avg[ls:le], u.exp_avg_sq[ls:le],
-                               u.flat16[g0:g0 + (le - ls)], lr, betas, eps, weight_decay if decayed else 0.0, self.step_count,
-                               self._coef)
+            ranges = u._shard_ranges()
+            if hasattr(self.ops, "adamw_groups") and ranges and ranges[0][0] == 0 and \
+                    all(ranges[i][1] == ranges[i + 1][0] and ranges[i][2] + (ranges[i][1] - ranges[i][0]) == ranges[i + 1][2]
+                        for i in range(len(ranges) - 1)):
+                # the local shard is [decayed | not decayed] back to back: both parameter groups in one launch
+                n_local = ranges[-1][1]
+                n_dec = sum(le - ls for ls, le, _, dec in ranges if dec)
+                g0 = ranges[0][2]
+                self.ops.adamw_groups(u.master_train[:n_local], u.gshard[:n_local], u.exp_avg[:n_local], u.exp_avg_sq[:n_local],
+                                      u.flat16[g0:g0 + n_local], n_dec, lr, betas, eps, weight_decay, self.step_count, self._coef)
+            else:
+                for ls, le, g0, decayed in ranges:
+                    self.ops.adamw(u.master_train[ls:le], u.gshard[ls:le], u.exp_avg[ls:le], u.exp_avg_sq[ls:le],
+                                   u.flat16[g0:g0 + (le - ls)], lr, betas, eps, weight_decay if decayed else 0.0, self.step_count,
+                                   self._coef)
             if self.coll:
                 if self.on_gpu:
                     ev = torch.cuda.Event()

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "mla_add_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
     "mla_embedding_fwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "mla_embedding_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+    "mla_adamw_step_groups": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_float, c_float, c_float, c_float,
+                              c_float, c_int, c_void_p, c_void_p],
     "mla_adamw_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float,
                        c_float, c_int, c_void_p, c_void_p],
     "mla_sumsq_f32": [c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
@@ -471,6 +473,12 @@ def embedding_bwd(ids, dy2d, grad_f32):
 
 def adamw_step(p32, g32, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=None):
     call("mla_adamw_step", _p(p32), _p(g32), _p(m), _p(v), _p(p16), p32.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), float(wd), int(step), _p(grad_scale))
+
+
+def adamw_step_groups(p32, g32, m, v, p16, n_decay, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    """adamw_step over a flat range laid out [decayed | not decayed]: weight decay on the first n_decay elements only."""
+    call("mla_adamw_step_groups", _p(p32), _p(g32), _p(m), _p(v), _p(p16), p32.numel(), int(n_decay), float(lr), float(beta1), float(beta2),
          float(eps), float(wd), int(step), _p(grad_scale))
 
 

@@ -495,6 +495,20 @@ def test_adamw_embedding_misc(dev):
         hip.adamw_step(pd, (gr * step).to(dev), md, vd, p16, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
     assert fro_rel(pd, ref_p) < 1e-5
     assert torch.equal(p16.cpu(), pd.cpu().to(BF))
+    # both parameter groups of a flat range ([decayed | not decayed], training/strategies/fsdp.py:231-257) in one launch ==
+    # two launches, bit for bit (vector path and, for a boundary that cuts a 16-B group, the scalar path)
+    for nd in (60000, 60002, 0, n):
+        st = [t.clone() for t in (p.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev))]
+        a16, b16 = torch.zeros(n, dtype=BF, device=dev), torch.zeros(n, dtype=BF, device=dev)
+        one = [t.clone() for t in st]
+        gd = gr.to(dev)
+        for step in range(1, 3):
+            hip.adamw_step_groups(one[0], gd, one[1], one[2], a16, nd, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+            if nd:
+                hip.adamw_step(st[0][:nd], gd[:nd], st[1][:nd], st[2][:nd], b16[:nd], 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+            if nd < n:
+                hip.adamw_step(st[0][nd:], gd[nd:], st[1][nd:], st[2][nd:], b16[nd:], 1e-2, 0.9, 0.999, 1e-8, 0.0, step)
+        assert all(torch.equal(x, y) for x, y in zip(one, st)) and torch.equal(a16, b16), nd
     s = torch.zeros(1, device=dev)
     hip.sumsq(pd, s, False)
     assert abs(float(s) - float((pd.cpu().double() ** 2).sum())) / float((pd.cpu().double() ** 2).sum()) < 1e-5
