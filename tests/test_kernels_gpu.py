@@ -55,7 +55,8 @@ def test_gemm256_modes(dev, am, bm, M, N, K):
     B = b.float() if bm == 0 else b.float().t()
     ref = A @ B.t()
     ad, bd = a.to(dev), b.to(dev)
-    FG = 3 if (am, bm) == (0, 0) else 0      # the 256x256 kernel takes k-contiguous operands only
+    FG = 3 if (am, bm) == (0, 0) else 0      # 3: k-contiguous operands without the split-K tail; reduction-major ones take the
+                                             # default dispatch = the same 256x256 kernel, untracked staging, split-K tail (round 2)
     out32 = hip.gemm(ad, bd, a_mode=am, b_mode=bm, out_dtype=torch.float32, force_generic=FG)
     assert fro_rel(out32, ref) < 2e-4 and max_rel(out32, ref) < 1e-3
     for _ in range(3):  # race screen: repeated launches must be bit-identical
@@ -624,6 +625,22 @@ def test_gemm256_splitk_tail(dev, M, N, K):
     hip.gemm(a, b, out=acc, accumulate=True)
     assert fro_rel(acc, (plain32 + 1.0).cpu()) < 1e-6
     assert torch.equal(hip.gemm(a, b), hip.gemm(a, b))          # deterministic
+
+
+@pytest.mark.parametrize("am,bm", [(0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(4352, 4096, 1024), (17536, 4096, 640)])
+def test_gemm256_reduction_major_with_splitk_tail(dev, am, bm, M, N, K):
+    """Reduction-major operands ([K, rows] storage, ds_read_b64_tr_b16 fragments) through the 256x256 kernel with a split-K tail
+    (272 / 1104 tiles on 256 CUs): same result as the k-contiguous kernel on the transposed copies, bit for bit -- same K-slices,
+    same fix-up order -- and repeatable."""
+    from mla_amd import hip
+    a, b = bfr(M, K, seed=7).to(dev), bfr(N, K, seed=8, scale=0.1).to(dev)
+    want = hip.gemm(a, b, out_dtype=torch.float32)
+    aa = a if am == 0 else hip.transpose(a)
+    bb = b if bm == 0 else hip.transpose(b)
+    got = hip.gemm(aa, bb, a_mode=am, b_mode=bm, out_dtype=torch.float32)
+    assert torch.equal(got, want)
+    assert torch.equal(hip.gemm(aa, bb, a_mode=am, b_mode=bm, out_dtype=torch.float32), got)
 
 
 @pytest.mark.parametrize("M,N,K", [(17536, 4096, 1024), (17536, 12288, 256), (2200, 7424, 2048), (4100, 33000, 128), (70000, 520, 64),
