@@ -724,21 +724,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   unsigned qoff[4], dooff[4];
   stage_offs<ASW>(p.ld, wave, lane, qoff);
   stage_offs<ASW>(p.ld_o, wave, lane, dooff);
+  // per-row statistics of a query tile (threads 0..63: lse * log2 e, 64..127: delta), fetched one tile ahead: loaded at the top of
+  // the iteration that needs them they sat in front of the wait + barrier with their whole global latency exposed
+  auto load_stat = [&](int qt) -> float {
+    const int qi = qt * 64 + (threadIdx.x & 63);
+    if (threadIdx.x < 64) return (qi < qend) ? lse_p[qi] * LOG2E : INFINITY;
+    return (qi < qend) ? dl_p[qi] : 0.f;
+  };
+  float nstat = 0.f;
   if (qt0 < nqt_end) {
     stage_rows64<ASW>(qb_, p.ld, qt0 * 64, p.S, smem, wave, lane);
     stage_rows64<ASW>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
+    if (threadIdx.x < 128) nstat = load_stat(qt0);
   }
   for (int qt = qt0; qt < nqt_end; ++qt) {
     const int bufi = (qt - qt0) & 1;
-    if (threadIdx.x < 128) {
-      const int qi = qt * 64 + (threadIdx.x & 63);
-      float val;
-      if (threadIdx.x < 64) val = (qi < qend) ? lse_p[qi] * LOG2E : INFINITY;
-      else val = (qi < qend) ? dl_p[qi] : 0.f;
-      stats[bufi * 128 + threadIdx.x] = val;
-    }
+    if (threadIdx.x < 128) stats[bufi * 128 + threadIdx.x] = nstat;
     ATTN_WAIT_VM0();
     __syncthreads();
+    if (qt + 1 < nqt_end && threadIdx.x < 128) nstat = load_stat(qt + 1);
     const char* qt_ = smem + bufi * 2 * TILE_BYTES;
     const char* dot_ = qt_ + TILE_BYTES;
     if (qt + 1 < nqt_end) {
