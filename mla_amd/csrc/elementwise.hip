@@ -787,7 +787,12 @@ extern "C" int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
 }
 
 // workspace: nblocks*H floats (nblocks = mla_rmsnorm_bwd_blocks(rows)); dw may be null (frozen weight)
-extern "C" int mla_rmsnorm_bwd_blocks(int rows) { return rows < 1024 ? rows : 1024; }
+extern "C" int mla_rmsnorm_bwd_blocks(int rows) {
+  // 512 = two 4-wave workgroups per CU. More (1024: round-2 first half) only adds concurrent row streams and dw partials:
+  // 107 vs 130 us stand-alone at 17 536 x 4096, -2.1 ms/step in three same-box pairs (256: 152 us, 768: 116, 2048: 128)
+  static const int cap = getenv("MLA_RMSNORM_BWD_BLOCKS") ? atoi(getenv("MLA_RMSNORM_BWD_BLOCKS")) : 512;
+  return rows < cap ? rows : cap;
+}
 extern "C" int mla_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
                                float* dw, int dw_accumulate, int rows, int H, float* workspace, size_t workspace_bytes,
                                hipStream_t stream) {
@@ -936,6 +941,10 @@ extern "C" int mla_embedding_bwd(const long long* ids, const void* dy, float* gr
   MLA_LAUNCH_CHECK();
 }
 
+static int adamw_grid_cap() {
+  static const int cap = getenv("MLA_ADAMW_BLOCKS") ? atoi(getenv("MLA_ADAMW_BLOCKS")) : 8192;
+  return cap;
+}
 static int adamw_impl(float* p, const float* g, float* m, float* v, void* p16, long long n, long long n_decay, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int step, const float* grad_scale, hipStream_t stream) {
   MLA_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1 && n_decay >= 0 && n_decay <= n, "mla_adamw_step: bad args");
@@ -944,7 +953,7 @@ static int adamw_impl(float* p, const float* g, float* m, float* v, void* p16, l
   // (the decay boundary must not cut a 16-B group: otherwise everything goes through the scalar kernel)
   const long long n4 = (AL16(p) && AL16(g) && AL16(m) && AL16(v) && (p16 == nullptr || ((uintptr_t)p16 & 7) == 0) && (n_decay & 3) == 0) ? n / 4 : 0;
   if (n4)
-    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(grid_for(n4, 8192)), dim3(256), 0, stream, (f32x4_t*)p, (const f32x4_t*)g, (f32x4_t*)m,
+    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(grid_for(n4, adamw_grid_cap())), dim3(256), 0, stream, (f32x4_t*)p, (const f32x4_t*)g, (f32x4_t*)m,
                        (f32x4_t*)v, (u32x2_t*)p16, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, n_decay / 4);
   const long long done = n4 * 4;
   if (done < n)
