@@ -60,13 +60,16 @@ __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* g, int ld, int 
 // EPI: 0 = plain epilogue (bias / residual / fp32 / fused RoPE by arguments), 1 = fused gate|up + SwiGLU forward, 2 = fused d(act) +
 // SwiGLU backward. Separate instantiations: the fused forms are different kernels (GEMM + an HBM-bound elementwise pass in the
 // epilogue) and show up under their own names in rocprofv3, so the plain kernel's statistics are not mixed with theirs.
+#ifndef MLA_GROUP_M
+#define MLA_GROUP_M 4   // tile rows per group of the M-grouped walk inside an XCD's range (round-2 sweep on the twelve 7B shapes: 2 is within +-1 %, 8 loses 0-2 %, 16 loses 1-5 %)
+#endif
 #ifndef MLA_GEMM256_UNTRACKED
 #define MLA_GEMM256_UNTRACKED 0   // 1: k-contiguous instantiations stage untracked too (A/B)
 #endif
 template <int AMODE, int BMODE, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const bool LGKM_BEFORE = false;
-  const int GROUP_M = 4;
+  const int GROUP_M = MLA_GROUP_M;
 #ifdef MLA_GEMM256_ABLATION   // timing experiments only (tools/exp_dbg.py); the runtime flags cost branches in the hot loop
   const bool NO_READ = (p.debug & 4) != 0, NO_STAGE = (p.debug & 8) != 0, NO_BAR2 = (p.debug & 16) != 0, NO_BAR1 = (p.debug & 32) != 0;
   const int dbg = p.debug;
@@ -655,7 +658,7 @@ struct Unit {
 };
 
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
-  const int GROUP_M = 4;
+  const int GROUP_M = MLA_GROUP_M;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
 // Fix-up of the split-K tail: one thread per 4 consecutive outputs of a tail tile; sums the sk_split fp32 partials (fixed order:
 // deterministic) and applies the same epilogue as the main kernel.
 __global__ __launch_bounds__(256) void gemm256_fixup_kernel(GemmArgs p) {
-  const int GROUP_M = 4;
+  const int GROUP_M = MLA_GROUP_M;
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
   const int tile = blockIdx.x >> 6;                       // 64 blocks of 256 threads x 4 outputs per tile
   const int pid = p.sk_full + tile;
