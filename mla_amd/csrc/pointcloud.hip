@@ -319,17 +319,32 @@ __global__ __launch_bounds__(256) void colstats_partial_vec_kernel(const bf16_t*
     partial[((size_t)blockIdx.x * 2 + 1) * C + ch] = tq;
   }
 }
+// 16 columns per workgroup, 16 lanes per column striding over the P partial rows (four partial rows in flight per lane), then a
+// fixed-order tree over the 16 lanes: round 1 summed every column in ONE thread (57 us at P = 256 -- a third of the statistics pass)
 __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __restrict__ partial, float* __restrict__ mean,
                                                              float* __restrict__ var, int P, int C, long long rows) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= C) return;
+  __shared__ double sa[16][17], sq[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
   double a = 0.0, q = 0.0;
-  for (int p = 0; p < P; ++p) { a += (double)partial[((size_t)p * 2) * C + ch]; q += (double)partial[((size_t)p * 2 + 1) * C + ch]; }
-  const double m = a / (double)rows;
-  double v = q / (double)rows - m * m;
-  if (v < 0.0) v = 0.0;
-  mean[ch] = (float)m;
-  var[ch] = (float)v;  // biased (what BatchNorm normalises with)
+  if (ch < C)
+    for (int p = pl; p < P; p += 16) {
+      a += (double)partial[((size_t)p * 2) * C + ch];
+      q += (double)partial[((size_t)p * 2 + 1) * C + ch];
+    }
+  sa[pl][cl] = a;
+  sq[pl][cl] = q;
+  __syncthreads();
+  if (pl == 0 && ch < C) {
+    double ta = 0.0, tq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ta += sa[i][cl]; tq += sq[i][cl]; }
+    const double m = ta / (double)rows;
+    double v = tq / (double)rows - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[ch] = (float)m;
+    var[ch] = (float)v;  // biased (what BatchNorm normalises with)
+  }
 }
 // y = (x - mean) * rsqrt(var + eps) * w + b (+ residual) (relu)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
@@ -425,7 +440,12 @@ extern "C" int mla_lga_prep(const float* xyz, const void* feats, const long long
   MLA_LAUNCH_CHECK();
 }
 
-extern "C" int mla_colstats_blocks(long long rows) { long long r = rows / 2048; return (int)(r < 1 ? 1 : (r > 256 ? 256 : r)); }
+extern "C" int mla_colstats_blocks(long long rows) {
+  // 1024: the partial pass is latency-bound with one workgroup per CU (176 us at 256 workgroups, 123 at 512, 115 at 1024)
+  static const long long cap = getenv("MLA_COLSTATS_BLOCKS") ? atoll(getenv("MLA_COLSTATS_BLOCKS")) : 1024;
+  long long r = rows / 2048;
+  return (int)(r < 1 ? 1 : (r > cap ? cap : r));
+}
 // workspace: mla_colstats_blocks(rows) * 2 * C floats
 extern "C" int mla_colstats_bf16(const void* x, float* mean, float* var, long long rows, int C, int ld, float* workspace,
                                  size_t workspace_bytes, hipStream_t stream) {
@@ -440,7 +460,7 @@ extern "C" int mla_colstats_bf16(const void* x, float* mean, float* var, long lo
   } else {
     hipLaunchKernelGGL(colstats_partial_kernel, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const bf16_t*)x, workspace, rows, C, ld);
   }
-  hipLaunchKernelGGL(colstats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, workspace, mean, var, P, C, rows);
+  hipLaunchKernelGGL(colstats_final_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, workspace, mean, var, P, C, rows);
   MLA_LAUNCH_CHECK();
 }
 
