@@ -20,7 +20,24 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
   const int r = blockIdx.x;
   const T* row = logits + (long long)r * ld;
   float m = -INFINITY, s = 0.f;
-  for (int j = threadIdx.x; j < ncols; j += 256) {
+  int j0 = 0;
+  if (sizeof(T) == 4 && ((((uintptr_t)row) & 15) == 0)) {
+    // fp32 logits, 16-B loads: the running maximum moves once per four columns (branch-free), 5 exponentials per 4 values. The
+    // scalar walk below read 4 B per lane and ran at 3.0 TB/s on the [17 536, 32 064] lm_head logits.
+    const f32x4_t* row4 = (const f32x4_t*)row;
+    const int n4 = ncols >> 2;
+    for (int j = threadIdx.x; j < n4; j += 256) {
+      const f32x4_t x = row4[j];
+      const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+      const float mn = fmaxf(m, mx);
+      if (mn != -INFINITY) {
+        s = s * __expf(m - mn) + ((__expf(x[0] - mn) + __expf(x[1] - mn)) + (__expf(x[2] - mn) + __expf(x[3] - mn)));
+        m = mn;
+      }
+    }
+    j0 = n4 << 2;
+  }
+  for (int j = j0 + threadIdx.x; j < ncols; j += 256) {
     const float x = ldf<T>(row + j);
     if (x > m) { s = s * __expf(m - x) + 1.f; m = x; }
     else s += __expf(x - m);
@@ -44,6 +61,26 @@ __global__ __launch_bounds__(256) void infonce_bwd_kernel(const float* __restric
                                                           const float* __restrict__ clse, const float* __restrict__ gscale,
                                                           bf16_t* __restrict__ dL, int M, int Mp) {
   const float gs = gscale[0] / (2.f * (float)M);
+  if ((Mp & 3) == 0 && ((((uintptr_t)L) | ((uintptr_t)clse)) & 15) == 0 && (((uintptr_t)dL) & 7) == 0) {   // 4 columns per lane: 16-B / 8-B accesses
+    const int q = Mp >> 2;
+    const long long total4 = (long long)Mp * q;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
+      const int i = (int)(idx / q), j = (int)(idx % q) * 4;
+      u32x2_t o = {0u, 0u};
+      if (i < M && j < M) {
+        const f32x4_t x = *(const f32x4_t*)(L + (long long)i * Mp + j);
+        const float ri = rlse[i];
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = (j + k < M) ? gs * (__expf(x[k] - ri) + __expf(x[k] - clse[j + k]) - (i == j + k ? 2.f : 0.f)) : 0.f;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+      }
+      *(u32x2_t*)(dL + (long long)i * Mp + j) = o;
+    }
+    return;
+  }
   const long long total = (long long)Mp * Mp;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int i = (int)(idx / Mp), j = (int)(idx % Mp);
