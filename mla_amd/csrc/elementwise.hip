@@ -287,6 +287,36 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   if (rl == 0 && n < N) partial[(size_t)blockIdx.y * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// same, 8 columns (16 B) per lane: 8 lanes cover the block's 64 columns, 32 row lanes stride over the row slice
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const bf16_t* __restrict__ dy, float* __restrict__ partial,
+                                                                 int rows, int N, int ld) {
+  __shared__ float red[32][65];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int n = blockIdx.x * 64 + cl * 8;
+  const int rs = gridDim.y;
+  const int per = (rows + rs - 1) / rs;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  if (n < N)
+    for (int r = r0 + rl; r < r1; r += 32) {
+      float v[8];
+      unpack8(*(const u32x4_t*)(dy + (size_t)r * ld + n), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cl * 8 + j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x];
+    partial[(size_t)blockIdx.y * N + blockIdx.x * 64 + threadIdx.x] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm forward (frozen vision tokenizer: models/mla/image/vision_tokenizer.py:21-24)
 // ---------------------------------------------------------------------------------------------------------
@@ -843,7 +873,10 @@ extern "C" int mla_colsum_bf16(const void* dy, float* out, int accumulate, int r
   MLA_CHECK_ARG(dy && out && workspace, "mla_colsum_bf16: null pointer");
   const int rs = mla_colsum_blocks(rows);
   MLA_CHECK_ARG(workspace_bytes >= (size_t)rs * N * sizeof(float), "mla_colsum_bf16: workspace too small");
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, (const bf16_t*)dy, workspace, rows, N, ld);
+  if ((N & 7) == 0 && (ld & 7) == 0 && AL16(dy))
+    hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, (const bf16_t*)dy, workspace, rows, N, ld);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, (const bf16_t*)dy, workspace, rows, N, ld);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + RP_COLS - 1) / RP_COLS), dim3(256), 0, stream, workspace, out, rs, N, accumulate);
   MLA_LAUNCH_CHECK();
 }
