@@ -28,7 +28,7 @@ typedef struct ihipStream_t* mla_stream_t; /* == hipStream_t */
 
 /* ---- library ---- */
 const char* mla_last_error(void);
-int mla_query(int what); /* 0: ABI version, 1: compiled gfx arch (950), 2: wavefront size (64) */
+int mla_query(int what); /* 0: ABI version, 1: compiled gfx arch (950), 2: wavefront size (64), 3: 1 if the opt-in experiment kernels are compiled in */
 /* hardware-assumption self test (ds_read_b64_tr_b16 lane map, global_load_lds destination order) */
 int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_1k, mla_stream_t stream);
 

@@ -13,12 +13,18 @@ void mla_set_error(const char* fmt, ...) {
 
 extern "C" const char* mla_last_error(void) { return g_err; }
 
-// what: 0 = ABI version, 1 = compiled gfx arch number (950), 2 = wavefront size the kernels assume
+// what: 0 = ABI version, 1 = compiled gfx arch number (950), 2 = wavefront size the kernels assume, 3 = 1 when the opt-in experiment
+// kernels (assembly GEMM main loops, persistent GEMM walk) were compiled in (build.sh MLA_EXPERIMENTAL=1), else 0
 extern "C" int mla_query(int what) {
   switch (what) {
     case 0: return 1;
     case 1: return 950;
     case 2: return 64;
+#ifdef MLA_EXPERIMENTAL_KERNELS
+    case 3: return 1;
+#else
+    case 3: return 0;
+#endif
     default: return -1;
   }
 }

@@ -4,20 +4,26 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+# MLA_EXPERIMENTAL=1 adds the opt-in experiment kernels (gemm_asm.hip: assembly main loops, gemm256p: persistent walk); the product
+# library is built without them. Objects of the two flavours live in separate directories.
+EXP="${MLA_EXPERIMENTAL:-0}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC ${MLA_EXTRA_FLAGS:-} -Wno-unused-value -Wno-unused-result"
-mkdir -p "$HERE/build"
+BUILD="$HERE/build"
+if [ "$EXP" = 1 ]; then FLAGS="$FLAGS -DMLA_EXPERIMENTAL_KERNELS"; BUILD="$HERE/build_exp"; fi
+mkdir -p "$BUILD"
 pids=()
-SRCS="api gemm gemm256 gemm_asm transpose elementwise attention loss pointcloud vision gen"
+SRCS="api gemm gemm256 transpose elementwise attention loss pointcloud vision gen"
+[ "$EXP" = 1 ] && SRCS="$SRCS gemm_asm"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$HERE/build/$f.o" ] || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_asm_8w_clobbers.inc" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_asm_4w_clobbers.inc" -nt "$HERE/build/$f.o" ]; }; }; then
-    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
+  if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/common.h" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$BUILD/$f.o" ] || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_8w_clobbers.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_clobbers.inc" -nt "$BUILD/$f.o" ]; }; }; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
 # explicit object list: a stale build/<removed source>.o must not be linked
 OBJS=()
-for f in $SRCS; do [ -f "$HERE/$f.hip" ] && OBJS+=("$HERE/build/$f.o"); done
+for f in $SRCS; do [ -f "$HERE/$f.hip" ] && OBJS+=("$BUILD/$f.o"); done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmla_hip.so" "${OBJS[@]}"
 echo "built $OUT/libmla_hip.so"

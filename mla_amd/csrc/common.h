@@ -115,9 +115,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // cannot tell which LDS bytes an LDS-DMA load writes, so it puts `s_waitcnt vmcnt(0)` in front of the first LDS read it cannot
 // disambiguate (every ds_read_b64_tr_b16, which carries no memory operand): in the attention loops that drained the next tile's
 // prefetch in the middle of the current tile. Callers order the copy against its readers themselves (vmcnt wait + barrier).
+//
+// M0 CONTRACT: the statement overwrites m0 and cannot say so -- hipcc treats m0 as reserved ("m0" in the clobber list only draws
+// `-Winline-asm: clobber list contains reserved registers`, and the note says the clobber may be ignored). Compiled code uses m0
+// for exactly one thing on gfx950 in this library: the LDS base of the glds16() BUILTIN, which it may keep live across statements.
+// Therefore A KERNEL USES EITHER glds16 OR glds16_untracked, NEVER BOTH: every call site selects the variant by a template
+// parameter / macro that is fixed per kernel (attention.hip ATTN_GLDS, gemm.hip UNTRACKED, gemm256.hip UNTRACKED), and m0 is
+// written in the SAME statement that reads it, so nothing depends on its value before or after.
 __device__ __forceinline__ void glds16_untracked(const void* gsrc, void* lds_wave_base) {
   const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(MLA_LDS_AS void*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");   // (m0 is not used by compiled code on gfx950)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory");
 }
 
 // LDS transpose read: 4 x b16 per lane (see DESIGN.md "tr16 semantics", verified by mla_selftest_tr16)

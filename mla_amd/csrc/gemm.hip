@@ -21,8 +21,10 @@
 
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream, int* sq_slots = nullptr);  // gemm256.hip
 extern "C" int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes);                                                          // gemm256.hip
+#ifdef MLA_EXPERIMENTAL_KERNELS   // opt-in experiment kernels (build.sh: MLA_EXPERIMENTAL=1); the product library carries only kernels on the path
 int mla_gemm_asm_dispatch(const void* args, hipStream_t stream);
 int mla_gemm_asm4_dispatch(const void* args, hipStream_t stream);                           // gemm_asm.hip
+#endif
 
 namespace {
 
@@ -309,12 +311,16 @@ static int gemm_bf16_impl(const void* A, const void* B, void* C, const void* R, 
   // the 256x256 kernel takes every operand layout (round 2: its reduction-major path stages untracked and runs at 1.1-1.3 PFLOP/s,
   // gemm128's at 0.87-0.96; round 1 measured 0.47-0.70 because the compiler drained the ring in front of every ds_read_b64_tr_b16);
   // force_generic == 2 keeps it off, == 3 forces it without the split-K tail (tests / experiments)
+#ifdef MLA_EXPERIMENTAL_KERNELS
   // force_generic == 4: the assembly-scheduled 256x256x32 kernel (gemm_asm.hip); K % 128 == 0, N % 4 == 0
   if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 4)
     return mla_gemm_asm_dispatch(&p, stream);
   // force_generic == 5: the 4-wave (128 x 128 per wave) assembly kernel, same eligibility
   if (mfma_ok && M >= 256 && N >= 256 && (K % 128) == 0 && (N % 4) == 0 && a_mode == 0 && b_mode == 0 && force_generic == 5)
     return mla_gemm_asm4_dispatch(&p, stream);
+#else
+  MLA_CHECK_ARG(force_generic != 4 && force_generic != 5, "mla_gemm_bf16: the assembly experiment kernels are not in this build (MLA_EXPERIMENTAL=1)");
+#endif
   if (sq_out) {   // sum-of-squares partials exist in the 256x256 kernel only; the caller sizes the buffer for the worst case
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
     MLA_CHECK_ARG(mfma_ok && M >= 256 && N >= 256 && (K % 64) == 0 && force_generic == 0 && sq_slots != nullptr,

@@ -642,6 +642,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef MMA
 }
 
+#ifdef MLA_EXPERIMENTAL_KERNELS   // opt-in experiment (build.sh: MLA_EXPERIMENTAL=1), never faster than the one-tile launch
 // ------------------------------------------------------------------------------------------------ persistent variant (NT)
 // One workgroup per CU walks a static list of work units (whole tiles, then at most a few split-K tail slices) with the K-tile
 // ring running CONTINUOUSLY across units: while the last K-tiles of unit u are multiplied, the staging cursors are already
@@ -926,6 +927,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmArgs p) {
 #undef ST_B1
 }
 
+#endif  // MLA_EXPERIMENTAL_KERNELS
+
 // Fix-up of the split-K tail: one thread per 4 consecutive outputs of a tail tile; sums the sk_split fp32 partials (fixed order:
 // deterministic) and applies the same epilogue as the main kernel.
 __global__ __launch_bounds__(256) void gemm256_fixup_kernel(GemmArgs p) {
@@ -1040,6 +1043,7 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
     attr_set = true;
   }
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
+#ifdef MLA_EXPERIMENTAL_KERNELS
   if (AM == 0 && BM_ == 0 && persistent_grid > 0) {
     static bool attr_p = false;
     if (!attr_p) {
@@ -1048,7 +1052,9 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
     }
     hipLaunchKernelGGL(gemm256p_kernel, dim3(persistent_grid), dim3(512), 2 * BUF, stream, p);
     if (p.sk_split > 1) hipLaunchKernelGGL(gemm256_fixup_kernel, dim3((num_m * num_n - p.sk_full) * 64), dim3(256), 0, stream, p);
-  } else if (p.sk_split > 1) {
+  } else
+#endif
+  if (p.sk_split > 1) {
     const int tail = num_m * num_n - p.sk_full;
     hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(p.sk_full + tail * p.sk_split), dim3(512), 2 * BUF, stream, p);
     hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
@@ -1190,6 +1196,10 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   // persistent walk when there is more than one round of tiles and the operands fit 31-bit byte offsets (buffer addressing)
   const size_t bytesA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bytesB = ((size_t)(p.N - 1) * p.ldb + p.K) * 2;
   const int grid = ncu & ~7;
+#ifndef MLA_EXPERIMENTAL_KERNELS
+  if (p.debug & 0x100) { mla_set_error("gemm256: the persistent experiment kernel is not in this build (MLA_EXPERIMENTAL=1)"); return -1; }
+  persist = 0;
+#endif
   const bool use_p = (persist || (p.debug & 0x100)) && (p.debug & 0x80) == 0 && tiles > grid && bytesA < 0x7fffffffULL && bytesB < 0x7fffffffULL &&
                      p.sf_I == 0 && p.sw_gu == nullptr && p.rope_cos == nullptr && p.sq_out == nullptr;     // the persistent walk has the plain epilogue only
   if (sq_slots) *sq_slots = p.sk_split > 1 ? p.sk_full + (tiles - p.sk_full) * 64 : tiles;

@@ -137,23 +137,37 @@ class FlatUnit:
                 p._mg_dirty = False
                 if not coll and hasattr(ops, "sum_partials"):
                     p._sq_sink = self._sq_sink
+                    p._sq_invalidate = self._sq_invalidate_param
             p.grad = None
         self.gather_event = None
         self.rs_event = None
 
+    def sq_invalidate(self, off: int, end: int) -> None:
+        """main_grad[off:end) is about to be written by something that leaves no sum(dW^2) partials (a plain GEMM, an
+        accumulate on an odd shape, an embedding / vector gradient): every recorded range that INTERSECTS it is stale -- dropped
+        and its arena slice zeroed, so the norm pass reads those elements from the buffer again (uncovered_ranges)."""
+        if not self.sq_entries:
+            return
+        for k in [k for k, e in self.sq_entries.items() if k < end and off < k + e[0]]:
+            e = self.sq_entries.pop(k)
+            self.sq_arena.buf[e[1]:e[1] + e[2]].zero_()
+
+    def _sq_invalidate_param(self, p) -> None:
+        off = self._offset_of.get(id(p))
+        if off is not None:
+            self.sq_invalidate(off, off + p.numel())
+
     def _sq_sink(self, weights, count):
         """A wgrad launch is about to write main_grad of `weights` (adjacent in the flat buffer) and to leave `count` sum(dW^2)
         partials of the final values: returns where they go (a slice of the model-wide arena, summed by ONE launch at clipping
-        time) or None when the arena is full. A later launch on the same range (gradient accumulation) supersedes the earlier
-        one: its partials are of the accumulated values, the old slice is zeroed."""
+        time) or None when the arena is full. A later launch that touches any part of the range (gradient accumulation, or a
+        per-weight launch after a q|k|v-wide one) supersedes the earlier entries: their slices are zeroed."""
         arena = self.sq_arena
         if arena is None:
             return None
         off = self._offset_of[id(weights[0])]
         end = self._offset_of[id(weights[-1])] + weights[-1].numel()
-        old = self.sq_entries.pop(off, None)
-        if old is not None:
-            arena.buf[old[1]:old[1] + old[2]].zero_()
+        self.sq_invalidate(off, end)
         part = arena.take(count)
         if part is None:
             return None
@@ -197,9 +211,7 @@ class FlatUnit:
         into main_grad; called after every backward so that accumulation over micro-batches happens in fp32."""
         for _, p, o in self.params:
             if p.requires_grad and p.grad is not None:
-                for off in [k for k, e in self.sq_entries.items() if k <= o < k + e[0]]:
-                    e = self.sq_entries.pop(off)  # an autograd gradient lands on top of a wgrad epilogue's values: its partials are stale
-                    self.sq_arena.buf[e[1]:e[1] + e[2]].zero_()
+                self.sq_invalidate(o, o + p.numel())   # an autograd gradient lands on top of a wgrad epilogue's values
                 if p._mg_touched:
                     p.main_grad.add_(p.grad.to(torch.float32))
                 else:

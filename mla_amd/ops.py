@@ -64,6 +64,28 @@ def _touch(param) -> bool:
     return acc
 
 
+def _sq_stale(*weights) -> None:
+    """main_grad of these parameters (or of the parents of param_views) is about to be written by a launch that leaves no
+    sum(dW^2) partials: the owner drops every recorded gradient-norm range that intersects them (FlatUnit.sq_invalidate), so the
+    clipping norm re-reads those elements instead of trusting partials of an earlier micro-batch."""
+    for w in weights:
+        region = getattr(w, "_mg_region", None)
+        p = region[0] if region is not None else w
+        inv = getattr(p, "_sq_invalidate", None)
+        if inv is not None:
+            inv(p)
+
+
+def reset_main_grad_state(params) -> None:
+    """Start a new accumulation window for parameters that carry ``main_grad`` but are NOT owned by a FlatUnit (ad-hoc / unit-test
+    use; FlatUnit.begin_step does this for its own): the next backward overwrites main_grad instead of adding to it."""
+    for p in params:
+        if hasattr(p, "_mg_touched"):
+            p._mg_touched = False
+        if hasattr(p, "_mg_regions"):
+            p._mg_regions = {}
+
+
 def deliver_wgrad(weights: Sequence[torch.Tensor], dy2: torch.Tensor, x2: torch.Tensor, needs: Sequence[bool]):
     """dW_i = dy[:, slice_i]^T @ x for every weight; into main_grad when present, else returned as tensors."""
     grads: List[Optional[torch.Tensor]] = [None] * len(weights)
@@ -73,6 +95,7 @@ def deliver_wgrad(weights: Sequence[torch.Tensor], dy2: torch.Tensor, x2: torch.
         states = {_is_touched(w) for w in weights}
         if mcat is not None and len(states) == 1:
             acc = states.pop()
+            _sq_stale(*weights)
             hip.gemm(dy2, x2, out=mcat, a_mode=1, b_mode=1, accumulate=acc)
             for w in weights:
                 _mark_touched(w)
@@ -83,6 +106,7 @@ def deliver_wgrad(weights: Sequence[torch.Tensor], dy2: torch.Tensor, x2: torch.
         if needs[i]:
             dys = dy2[:, off:off + n]
             if mgs[i] is not None:
+                _sq_stale(w)
                 hip.gemm(dys, x2, out=mgs[i], a_mode=1, b_mode=1, M=n, accumulate=_touch(w))
             else:
                 grads[i] = hip.gemm(dys, x2, a_mode=1, b_mode=1, M=n, out_dtype=torch.float32).to(w.dtype)
@@ -107,6 +131,9 @@ def _gemm_into_main_grad(weights, dyT, xT, out, accumulate: bool) -> None:
             if part is not None:
                 hip.gemm_sq(dyT, xT, out, accumulate, part)
                 return
+    # no partials from this launch (odd shape, arena full, param_view region, foreign owner): whatever an earlier micro-batch of this
+    # window recorded for the range is stale once this launch has added to / overwritten it
+    _sq_stale(*weights)
     hip.gemm(dyT, xT, out=out, accumulate=accumulate)
 
 
@@ -139,6 +166,7 @@ def deliver_vec_grad(param: torch.Tensor, compute):
     """compute(out_f32, accumulate) fills a 1-D fp32 gradient. Routes to main_grad or returns a tensor."""
     mg = getattr(param, "main_grad", None)
     if mg is not None:
+        _sq_stale(param)
         compute(mg, _touch(param))
         return None
     g = torch.empty(param.shape, dtype=torch.float32, device=param.device)
@@ -334,6 +362,7 @@ def _deliver_small(param, g32):
     mg = getattr(param, "main_grad", None)
     if mg is None:
         return g32.to(param.dtype).view(param.shape)
+    _sq_stale(param)
     if _touch(param):
         mg.add_(g32.view(mg.shape))
     else:
@@ -405,6 +434,7 @@ class EmbeddingFn(torch.autograd.Function):
         dy2 = _as2d(dy)
         mg = getattr(w, "main_grad", None)
         if mg is not None:
+            _sq_stale(w)
             if not _touch(w):
                 mg.zero_()
             hip.embedding_bwd(flat, dy2, mg)
@@ -756,7 +786,8 @@ def param_view(param: torch.Tensor, lo: Optional[int] = None, hi: Optional[int] 
         v.main_grad = g.view(shape) if shape is not None else g
         if not hasattr(param, "_mg_regions"):
             param._mg_regions = {}    # region -> "main_grad region holds a contribution from this accumulation window"; cleared by
-                                      # FlatUnit.begin_step, set only INSIDE the backward that writes the region (_mark_touched), so an
+                                      # FlatUnit.begin_step (parameters without a FlatUnit: ops.reset_main_grad_state before every
+                                      # window), set only INSIDE the backward that writes the region (_mark_touched), so an
                                       # eval / no_grad forward or an unused branch leaves the parameter untouched
         v._mg_region = (param, (lo, hi))
     return v

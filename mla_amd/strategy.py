@@ -181,8 +181,9 @@ class FSDPStrategy:
                 continue
             div = (len(vla_dataset) // self.global_batch_size) or 1
             epoch = (metrics.global_step + 1) // div
-            # train_step already advanced the schedule: the rate the step just used is the one the reference logs (:377)
-            metrics.commit(update_step_time=True, global_step=metrics.global_step + 1, epoch=epoch, lr=self.last_lr)
+            # the reference commits lr_scheduler.get_last_lr()[0] AFTER lr_scheduler.step() (base_strategy_mla.py:375-377), i.e. the rate
+            # the NEXT optimizer step will use; train_step has already advanced self.step, so current_lr() is that rate
+            metrics.commit(update_step_time=True, global_step=metrics.global_step + 1, epoch=epoch, lr=self.current_lr())
             metrics.push()
             if (self.max_steps is not None and metrics.global_step >= self.max_steps) or (
                     metrics.global_step % steps_per_epoch == 0 and epoch % save_interval == 0):

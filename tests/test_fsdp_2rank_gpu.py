@@ -59,6 +59,7 @@ def _run(rank, world, dev, accumulate=False):
         m.forward = lambda **kw: orig(**kw, noise=draws["noise"][rows].to(dev), timestep=draws["timestep"][rows].to(dev))
         return strat.train_step(b)
     losses, norms = [], []
+    grads0 = None
     for _ in range(STEPS):
         if accumulate:
             first = micro(0)
@@ -69,6 +70,13 @@ def _run(rank, world, dev, accumulate=False):
             out = micro(None if world == 1 else rank)
             losses.append(float(out["total_loss"]))
         norms.append(float(strat.sharded._norm))
+        if grads0 is None:
+            # the REDUCED gradients of the first step, as the collectives left them: this rank's 1/world shard of every unit's fp32
+            # gradient buffer (world 1: the whole buffer) + where each parameter sits in the unsharded buffer. AdamW only reads them.
+            torch.cuda.synchronize()
+            grads0 = dict(shards={u.name: u.gshard.detach().cpu().numpy().copy() for u in strat.sharded.units if u.trainable},
+                          where={n: (u.name, o, p.numel()) for u in strat.sharded.units if u.trainable for n, p, o in u.params
+                                 if p.requires_grad})
         if world == 1:
             # the clipping norm is assembled from the wgrad epilogues' sum-of-squares partials (superseded per micro-batch inside an
             # accumulation window) + a pass over what they did not write: it must equal the norm of the fp32 gradient buffers
@@ -80,7 +88,7 @@ def _run(rank, world, dev, accumulate=False):
             "vlm.projector_2d.mlp.2.weight", "vlm.final_layer.mlp.fc1.weight", "vlm.llm_backbone.llm.model.norm.weight",
             "vlm.x_embedder.mlp.fc1.bias")
     compute = dict(m.named_parameters())
-    return dict(losses=losses, norms=norms, weights={k: full[k].cpu().numpy() for k in keys},
+    return dict(losses=losses, norms=norms, grads0=grads0, weights={k: full[k].cpu().numpy() for k in keys},
                 compute={k: compute[k].detach().float().cpu().numpy() for k in keys})
 
 
@@ -134,10 +142,37 @@ def test_two_ranks_match_single_process(dev):
 # one build): loss 3.2e-3 / 4.6e-3, grad norm 3.0e-3 / 2.4e-3, min cos(update) 0.9913 / 0.9934, update norm 1.8e-3 / 7.3e-3.
 # Bounds = 2-3 x the larger observation (round 1 asserted 1e-2 / 5e-2 / 0.9 / 0.1).
 DP_LOSS_REL, DP_NORM_REL, DP_COS_MIN, DP_UPD_NORM_REL = 1.0e-2, 8e-3, 0.975, 2e-2
+# The reduced gradients themselves -- what reduce-scatter(mean) / the accumulation window produce, before AdamW's sign-like first steps
+# amplify anything: Frobenius distance of the WHOLE gradient (all trainable parameters) and of the worst single matrix, relative.
+DP_GRAD_FRO, DP_GRAD_FRO_WORST = 3e-3, 1.5e-2
+
+
+def _param_grads(*ranks):
+    """Per-parameter fp32 gradients of step 0 from the ranks' shards (concatenated in rank order = the unsharded buffer)."""
+    full = {name: np.concatenate([r["grads0"]["shards"][name] for r in ranks]) for name in ranks[0]["grads0"]["shards"]}
+    return {n: full[u][o:o + k] for n, (u, o, k) in ranks[0]["grads0"]["where"].items()}
+
+
+def _compare_grads(single, ranks, tag):
+    ref, got = _param_grads(single), _param_grads(*ranks)
+    assert ref.keys() == got.keys()
+    num = sum(float(((got[n].astype(np.float64) - ref[n]) ** 2).sum()) for n in ref) ** 0.5
+    den = sum(float((ref[n].astype(np.float64) ** 2).sum()) for n in ref) ** 0.5
+    worst_n, worst = "", 0.0
+    for n in ref:
+        if ref[n].size < 4096:
+            continue                                   # vectors (norm weights, biases): covered by the global figure
+        e = float(np.linalg.norm(got[n].astype(np.float64) - ref[n]) / (np.linalg.norm(ref[n]) + 1e-30))
+        if e > worst:
+            worst_n, worst = n, e
+    print(f"reduced gradients ({tag}) vs single-process fp32 gradient buffer: Frobenius rel {num / den:.2e} over {len(ref)} tensors, "
+          f"worst matrix {worst:.2e} ({worst_n})")
+    assert num / den < DP_GRAD_FRO and worst < DP_GRAD_FRO_WORST, (num / den, worst, worst_n)
 
 
 def _compare(single, r0, r1, tag):
     from oracle import recipe
+    _compare_grads(single, (r0,) if r0 is r1 else (r0, r1), tag)
     # every rank ends with the same weights (fp32 masters after gathering the shards, and the bf16 compute copies)
     for k in r0["weights"]:
         assert np.array_equal(r0["weights"][k], r1["weights"][k]), k
@@ -167,3 +202,43 @@ def test_gradient_accumulation_matches_one_big_batch(dev):
     single = _run(0, 1, dev)
     acc = _run(0, 1, dev, accumulate=True)
     _compare(single, acc, acc, tag="accumulation window of 2")
+
+
+def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_right(dev):
+    """Gradient-norm partials vs accumulation (round-2 advisor finding): micro-batch 1 has T = 2 x 544 = 1088 tokens (T % 64 == 0, so the
+    wgrad launches leave sum(dW^2) partials), micro-batch 2 is a shorter sample with its padding trimmed (T = 2 x 541, not a multiple
+    of 64 nor of 8: plain accumulate launches on zero-padded rows). The partials of micro-batch 1 describe values that micro-batch 2
+    has since added to -- they must be dropped, and the clipping norm must equal the norm of the fp32 gradient buffers."""
+    from mla_amd.strategy import FSDPStrategy
+    from oracle import recipe
+    R = 2
+    m = _build(dev)
+    strat = FSDPStrategy(m, dev.index or 0, global_batch_size=2, per_device_batch_size=1, learning_rate=1e-3, weight_decay=0.01,
+                         max_grad_norm=1.0, lr_scheduler_type="constant", enable_gradient_checkpointing=False, repeated_diffusion_steps=R)
+    assert strat.grad_accumulation_steps == 2
+    strat.run_setup(100)
+    batch, draws = recipe.make_batch(B=2, L=28, R=R, ragged=True)
+    lens = batch["attention_mask"].sum(1).tolist()
+    assert lens == [28, 25]
+    orig = m.forward
+
+    def micro(part):
+        L = lens[part]
+        b = {k: (v[part:part + 1] if torch.is_tensor(v) else v) for k, v in batch.items() if k not in ("images", "point_cloud")}
+        for k in ("input_ids", "attention_mask", "labels"):
+            b[k] = b[k][:, :L]
+        b["images"] = {"front_image": batch["images"]["front_image"][part:part + 1]}
+        rows = torch.tensor([part, part + 2])
+        m.forward = lambda **kw: orig(**kw, noise=draws["noise"][rows].to(dev), timestep=draws["timestep"][rows].to(dev))
+        return strat.train_step(b)
+
+    for step in range(2):
+        micro(0)
+        layer_units = [u for u in strat.sharded.units if u.name.endswith("layers.3")]
+        assert layer_units and len(layer_units[0].sq_entries) >= 4, "micro-batch 1 should have registered wgrad-epilogue partials"
+        micro(1)
+        assert not layer_units[0].sq_entries, "micro-batch 2 wrote the same ranges without partials: the entries must be gone"
+        got = float(strat.sharded._norm)
+        direct = sum(float((u.grad32.double() ** 2).sum()) for u in strat.sharded.units if u.trainable) ** 0.5
+        print(f"step {step}: clip norm {got:.6f} vs norm of the gradient buffers {direct:.6f}")
+        assert abs(got - direct) < 1e-5 * direct, (got, direct)
