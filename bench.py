@@ -167,6 +167,11 @@ def main():
                     help="BASELINE.json configs index: 1 = 7B SFT (the headline metric; also configs[2] when --gpus 8), "
                          "3 = post-training (image + point-cloud generation heads on top of config 1), "
                          "4 = pretrain shape, use_pointcloud=False, S=2048, activation checkpointing")
+    ap.add_argument("--keep-layers", type=int, default=-1,
+                    help="config 4: decoder layers (the last N) that keep their activations instead of being checkpointed; -1 = as many as "
+                         "fit under --mem-budget-gb, 0 = the reference's policy (checkpoint every layer)")
+    ap.add_argument("--keep-level", type=int, default=3, choices=[1, 2, 3], help="save level of the kept layers (3 = level 1 without act^T)")
+    ap.add_argument("--mem-budget-gb", type=float, default=262.0, help="peak-memory target of the automatic --keep-layers choice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
     args = ap.parse_args()
@@ -186,6 +191,9 @@ def main():
             os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                       "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
+        # never a silent smaller job: N ranks need N devices (one RCCL rank per GPU)
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:       # launched through torch.distributed.run (also with --gpus 1)
@@ -208,6 +216,17 @@ def main():
                          learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
                          enable_gradient_checkpointing=False, repeated_diffusion_steps=R_DIFF)
     strat.run_setup(n_train_examples=10_000)
+    keep_layers = 0
+    if args.config == 4 and not args.tiny:
+        # Mixed activation policy: the config names activation checkpointing because the reference targets 80 GB parts; with 288 GB the
+        # LAST k decoder layers keep their activations (level 3: h, qkv, o, lse, h_mid, gate|up = 93 KB per token and layer) and only the
+        # others recompute their forward. Bit-identical results for every k (tests/test_model_gpu.py::test_decoder_stack_mixed_...).
+        tok = B_PER_GPU * R_DIFF * 2048
+        per_layer = {1: (6 * 4096 + 3 * 11008) * 2, 3: (6 * 4096 + 2 * 11008) * 2, 2: (8 * 4096 + 4 * 11008) * 2}[args.keep_level] * tok \
+            - 4096 * 2 * tok                                     # minus the layer input a checkpointed layer keeps anyway
+        base = 158e9                                             # measured peak of the all-checkpointed step (profiles/r2_bench_config4_S2048.json: 156 GB)
+        keep_layers = args.keep_layers if args.keep_layers >= 0 else max(0, min(32, int((args.mem_budget_gb * 2**30 - base) // per_layer)))
+        mla.vlm.llm_backbone.set_activation_policy(keep_layers, keep_level=args.keep_level, rest_level=0)
     batch = make_batch(B=B_PER_GPU, L_text=l_text, seed=42 + rank, device=device, use_pointcloud=pc_on, with_next=gen_on)
     S = l_text + S_FUSED + 3
 
@@ -308,6 +327,8 @@ def main():
                                       + (" [TINY SMOKE MODEL - not the benchmark]" if args.tiny else ""),
                           "model": "mla-llama2-7b" if not args.tiny else "tiny", "global_batch": B_PER_GPU * world, "seq_len": S,
                           "parallelism": f"fsdp-rccl x{world}" if world > 1 else "single-gpu", "activation_save_level": args.save_level,
+                          **({"activation_policy": f"last {keep_layers} of 32 decoder layers keep activations (level {args.keep_level}), "
+                                                   f"{32 - keep_layers} checkpointed (level 0)"} if args.config == 4 and not args.tiny else {}),
                           "optimizer": "fused AdamW + grad clip inside the timed region"},
                "model_tflop_per_sample": round(tot_fl / 1e12, 2),
                **({"heads_encoders_tflop_per_sample_from_gemm_launches": round(heads_fl / 1e12, 2)} if heads_fl else {}),
@@ -319,6 +340,8 @@ def main():
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world > 1:
+            assert out["rccl_ranks"] == world == args.gpus, (out["rccl_ranks"], world, args.gpus)   # N GPUs means N RCCL ranks, never fewer
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

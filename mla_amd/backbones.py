@@ -151,6 +151,15 @@ class LLaMa2LLMBackbone(LLMBackbone):
     def enable_gradient_checkpointing(self) -> None:
         """base_llm.py: gradient checkpointing on the HF model == full recompute inside each decoder layer here."""
         self.llm.config.activation_save_level = 0
+        self.llm.config.activation_save_levels = None
+
+    def set_activation_policy(self, keep_layers: int, keep_level: int = 1, rest_level: int = 0) -> None:
+        """Mixed activation policy for 288 GB parts: the LAST `keep_layers` decoder layers keep their activations (`keep_level`: 1, 3
+        or 2 -- they are the first to be consumed and freed by the backward), the others run at `rest_level` (0 = the reference's
+        activation checkpointing, training/strategies/fsdp.py:211-223). Results are bit-identical for every mix."""
+        n = self.llm.config.num_hidden_layers
+        k = max(0, min(n, int(keep_layers)))
+        self.llm.config.activation_save_levels = tuple([rest_level] * (n - k) + [keep_level] * k)
 
     def embed_input_ids(self, input_ids: torch.LongTensor) -> torch.Tensor:
         return self.llm.model.embed(input_ids)

@@ -135,10 +135,10 @@ class CoordinateAwareContrastiveLoss(nn.Module):
             return torch.tensor(0.0, device=image_features.device, requires_grad=True)
         Mp = ((M + 127) // 128) * 128
         tgt_rows = (base + linear).reshape(-1)[vidx]
-        a = torch.zeros((Mp, D), dtype=pc_proj.dtype, device=pc_proj.device)
-        b = torch.zeros((Mp, D), dtype=pc_proj.dtype, device=pc_proj.device)
-        a = a.index_copy(0, torch.arange(M, device=vidx.device), pc_proj.reshape(-1, D).index_select(0, vidx))
-        b = b.index_copy(0, torch.arange(M, device=vidx.device), img_proj.reshape(-1, D).index_select(0, tgt_rows))
+        # HIP row gathers into the zero-padded [Mp, D] operands; tgt_rows repeats (several centres per patch): the backward sums the
+        # duplicates in a fixed order (ops.GatherRowsSumFn), so the whole step is bit-reproducible
+        a = ops.gather_rows_sum(pc_proj.reshape(-1, D), vidx, Mp)
+        b = ops.gather_rows_sum(img_proj.reshape(-1, D), tgt_rows, Mp)
         return ops.info_nce(a, b, M, self.temperature)
 
 

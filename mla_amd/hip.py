@@ -650,10 +650,13 @@ def swiglu_fwd_t(gu2d):
 
 
 def gather_rows(src2d, idx, out_rows=None, scatter=False):
-    """gather: out[r] = src[idx[r]] (out has len(idx) rows); scatter: out[idx[r]] = src[r] (out has out_rows rows, zero-filled)."""
+    """gather: out[r] = src[idx[r]] (out has len(idx) rows, or out_rows >= len(idx) rows with a zero tail);
+    scatter: out[idx[r]] = src[r] (out has out_rows rows, zero-filled)."""
     H = src2d.shape[1]
     n = idx.numel()
     if scatter:
+        out = torch.zeros((out_rows, H), dtype=torch.bfloat16, device=src2d.device)
+    elif out_rows is not None and out_rows != n:
         out = torch.zeros((out_rows, H), dtype=torch.bfloat16, device=src2d.device)
     else:
         out = torch.empty((n, H), dtype=torch.bfloat16, device=src2d.device)

@@ -46,9 +46,14 @@ class LlamaConfig:
     output_hidden_states: bool = False
     use_return_dict: bool = True
     # mla_amd extensions
-    activation_save_level: int = 2     # 2 keep all, 1 recompute cheap elementwise, 0 full recompute (checkpointing)
+    activation_save_level: int = 2     # 2 keep all, 1 recompute cheap elementwise, 3 = 1 without the kept SwiGLU product, 0 full recompute
+    activation_save_levels: Optional[tuple] = None   # per-layer override (mixed policy: keep as many layers as fit in HBM, checkpoint the rest)
     contrastive_tap_layer: int = 8     # index into hidden_states (reference hard-codes 8, modeling_llama.py:1274)
     compute_lm_logits: bool = True     # reference always materialises fp32 logits + CE even when unused (:1255-1269)
+
+    def layer_save_level(self, layer_idx: int) -> int:
+        lv = self.activation_save_levels
+        return self.activation_save_level if lv is None else int(lv[layer_idx])
 
     def __post_init__(self):
         if self.num_key_value_heads is None:
@@ -134,6 +139,7 @@ class LlamaDecoderLayer(nn.Module):
         super().__init__()
         self.config = config
         self.hidden_size = config.hidden_size
+        self.layer_idx = layer_idx
         self.self_attn = LlamaAttention(config, layer_idx)
         self.mlp = LlamaMLP(config)
         self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
@@ -155,7 +161,7 @@ class LlamaDecoderLayer(nn.Module):
         cos, sin = self.self_attn.rotary_emb.tables(S, hidden_states.device)
         h = ops.unit_boundary(hidden_states, self._grad_hook)
         out = ops.decoder_layer(h, seqlens, cos, sin, self.config.num_attention_heads, self.config.rms_norm_eps,
-                                self.config.activation_save_level, self._weights())
+                                self.config.layer_save_level(self.layer_idx), self._weights())
         return (out,)
 
 

@@ -517,9 +517,11 @@ class DecoderLayerFn(torch.autograd.Function):
               the epilogue) -> RMSNorm -> fused gate|up GEMM -> SwiGLU -> down GEMM (+residual in the epilogue)
     backward: hand-scheduled; residual-stream gradient adds are fused into the RMSNorm backward kernel, weight
               gradients are written by the wgrad GEMM epilogue into fp32 main_grad.
-    save_level: 2 = keep every intermediate; 1 = recompute the two normalised inputs and the SwiGLU product in
-                backward (3 HBM-bound kernels); 0 = keep only the layer input and recompute the whole forward
-                (activation checkpointing, training/strategies/fsdp.py:211-223).
+    save_level: 2 = keep every intermediate; 1 = recompute the two normalised inputs in the backward (HBM-bound passes) and keep
+                the SwiGLU product transposed; 3 = level 1 WITHOUT the kept product (it is recomputed from gate|up, one more
+                HBM-bound pass; 19 % less memory per layer -- the filler level of a mixed policy); 0 = keep only the layer input
+                and recompute the whole forward (activation checkpointing, training/strategies/fsdp.py:211-223).
+                Every level runs the same kernels on the same inputs: outputs and gradients are bit-identical across levels.
     """
 
     @staticmethod
@@ -581,6 +583,8 @@ class DecoderLayerFn(torch.autograd.Function):
             # every weight gradient, and are cut off again below
             h2 = torch.cat([h2, h2.new_zeros(Tp - T, H)], 0)
         keep_t = save_level == 1 and ctx.needs_input_grad[7 + 8] and _SWIGLU_DUAL   # down_proj trainable: its wgrad wants act^T
+        if save_level == 3:
+            save_level = 1                         # "1-lean": same saved set as level 1 minus act^T
         out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w,
                                                                                              save_t=keep_t)
         out = out[:T]
@@ -738,6 +742,33 @@ class GatherRowsFn(torch.autograd.Function):
 
 def gather_rows(src2d, idx):
     return GatherRowsFn.apply(src2d, idx.contiguous())
+
+
+class GatherRowsSumFn(torch.autograd.Function):
+    """out[r] = src[idx[r]] for r < len(idx), zero rows up to `out_rows`; idx MAY REPEAT (several point centres projecting into one
+    image patch, models/mla/fuser/contrastive.py:185-207). Backward: d src[s] = sum of dy[r] over idx[r] == s, accumulated in fp32
+    in ascending r by the deterministic embedding-backward kernel and rounded once -- torch's index_select backward adds bf16 values
+    with atomics in arrival order, which made the step's gradient norm reproducible only to 1e-5."""
+
+    @staticmethod
+    def forward(ctx, src2d, idx, out_rows):
+        _check_bf16_cuda(src2d)
+        ctx.save_for_backward(idx)
+        ctx.n_src = src2d.shape[0]
+        return hip.gather_rows(src2d.contiguous(), idx, out_rows=out_rows)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n = idx.numel()
+        g32 = torch.zeros((ctx.n_src, dy.shape[1]), dtype=torch.float32, device=dy.device)
+        hip.embedding_bwd(idx, dy[:n].contiguous(), g32)
+        return hip.cast_f32_to_bf16(g32), None, None
+
+
+def gather_rows_sum(src2d, idx, out_rows=None):
+    idx = idx.contiguous()
+    return GatherRowsSumFn.apply(src2d, idx, idx.numel() if out_rows is None else out_rows)
 
 
 class UnitBoundaryFn(torch.autograd.Function):

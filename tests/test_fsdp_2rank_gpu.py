@@ -206,8 +206,8 @@ def test_gradient_accumulation_matches_one_big_batch(dev):
 
 def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_right(dev):
     """Gradient-norm partials vs accumulation (round-2 advisor finding): micro-batch 1 has T = 2 x 544 = 1088 tokens (T % 64 == 0, so the
-    wgrad launches leave sum(dW^2) partials), micro-batch 2 is a shorter sample with its padding trimmed (T = 2 x 541, not a multiple
-    of 64 nor of 8: plain accumulate launches on zero-padded rows). The partials of micro-batch 1 describe values that micro-batch 2
+    wgrad launches leave sum(dW^2) partials), micro-batch 2 is a shorter sample (24 text tokens: T = 2 x 540 = 1080, not a multiple
+    of 64: plain accumulate launches). The partials of micro-batch 1 describe values that micro-batch 2
     has since added to -- they must be dropped, and the clipping norm must equal the norm of the fp32 gradient buffers."""
     from mla_amd.strategy import FSDPStrategy
     from oracle import recipe
@@ -217,16 +217,18 @@ def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_righ
                          max_grad_norm=1.0, lr_scheduler_type="constant", enable_gradient_checkpointing=False, repeated_diffusion_steps=R)
     assert strat.grad_accumulation_steps == 2
     strat.run_setup(100)
-    batch, draws = recipe.make_batch(B=2, L=28, R=R, ragged=True)
-    lens = batch["attention_mask"].sum(1).tolist()
-    assert lens == [28, 25]
+    batch, draws = recipe.make_batch(B=2, L=28, R=R, ragged=False)
+    lens = [28, 24]
     orig = m.forward
 
     def micro(part):
         L = lens[part]
         b = {k: (v[part:part + 1] if torch.is_tensor(v) else v) for k, v in batch.items() if k not in ("images", "point_cloud")}
         for k in ("input_ids", "attention_mask", "labels"):
-            b[k] = b[k][:, :L]
+            b[k] = b[k][:, :L].clone()
+        b["input_ids"][0, L - 1] = 2                      # </s> closes the (shortened) prompt
+        b["labels"][:] = -100
+        b["labels"][0, L - 1] = 2
         b["images"] = {"front_image": batch["images"]["front_image"][part:part + 1]}
         rows = torch.tensor([part, part + 2])
         m.forward = lambda **kw: orig(**kw, noise=draws["noise"][rows].to(dev), timestep=draws["timestep"][rows].to(dev))

@@ -133,16 +133,6 @@ def test_decoder_layer_fwd_bwd(dev, save_level, lens):
         assert fro_rel(w.grad, pr[n].grad) < 2e-2, n
 
 
-# (1.5 x, then widened to 2 x below) the values measured on MI355X in round 2 (printed by the test on every run): out 6.3e-3, dx 8.2e-3, ln1 1.04e-2,
-# q/k 1.10e-2, v 9.8e-3, o 9.7e-3, ln2 6.6e-3, gate 7.1e-3, up/down 6.7e-3 (weight gradients here are ROUNDED TO bf16 on delivery
-# because the test installs no fp32 main_grad; the training path writes them in fp32)
-DECODER_7B_BOUNDS = {"out": 9.4e-3, "dx": 1.23e-2, "input_layernorm.weight": 1.56e-2, "self_attn.q_proj.weight": 1.65e-2,
-                     "self_attn.k_proj.weight": 1.65e-2, "self_attn.v_proj.weight": 1.47e-2, "self_attn.o_proj.weight": 1.46e-2,
-                     "post_attention_layernorm.weight": 1.0e-2, "mlp.gate_proj.weight": 1.07e-2, "mlp.up_proj.weight": 1.0e-2,
-                     "mlp.down_proj.weight": 1.0e-2, "default": 1.65e-2}
-DECODER_7B_BOUNDS = {k: v * 4.0 / 3.0 for k, v in DECODER_7B_BOUNDS.items()}    # = 2 x measured: a kernel revision moves these by ~10 %
-
-
 def test_decoder_layer_at_7b_dimensions(dev):
     """One LlamaDecoderLayer at the benchmark's true dimensions (H 4096, I 11008, 32 heads x 128, S = 548; 2 sequences keep the fp32
     oracle at a few seconds of CPU time): the 256x256 GEMM with its split-K tail, the all-NT backward with its transposes, the
@@ -170,17 +160,25 @@ def test_decoder_layer_at_7b_dimensions(dev):
     out = ops.decoder_layer(xd, seqlens.to(dev).int(), cos.to(dev), sin.to(dev), nh, 1e-5, 1, wd)
     out.backward(dy.to(dev))
     valid = torch.arange(S)[None] < seqlens[:, None]
-    # Measured on MI355X (round 2, printed below on every run): bf16 storage of every intermediate puts the end-to-end layer at
-    # 3-6e-3 Frobenius-relative against the fp32 oracle (one bf16 rounding = 2^-9 = 2e-3 per stored tensor, ~6 stored tensors on the
-    # longest path); north_star's 1e-3 is met per KERNEL on fp32-accumulate outputs (tests/test_kernels_gpu.py: GEMM fp32-out
-    # 2e-4). Bounds = 1.5 x the measured values.
+    # Yardstick: the SAME oracle run the way the reference runs on the GPU -- bf16 weights and inputs under bf16
+    # autocast ("mode C"; every op rounds its result to bf16). The criterion is err(hip, fp32) <= 2 x err(C, fp32) per tensor: the HIP
+    # path may not be further from the fp32 truth than twice the reference's own bf16 arithmetic is. north_star's 1e-3 is met per
+    # KERNEL on fp32-accumulate outputs (tests/test_kernels_gpu.py: GEMM fp32-out 2e-4); end to end neither side can meet it
+    # with bf16 storage (one rounding = 2^-9 per stored tensor, ~6 stored tensors on the longest path).
+    xc = x.clone().requires_grad_(True)
+    pc = {n: v.to(BF).requires_grad_(True) for n, v in p32.items()}
+    with torch.autocast("cpu", dtype=BF):
+        refc = O.decoder_layer(xc, pc, cos, sin, nh, 1e-5, seqlens)
+    refc.backward(dy)
     errs = {"out": fro_rel(out[valid.to(dev)], ref[valid]), "dx": fro_rel(xd.grad[valid.to(dev)], xr.grad[valid])}
+    errc = {"out": fro_rel(refc[valid], ref[valid]), "dx": fro_rel(xc.grad[valid], xr.grad[valid])}
     for n, w in zip(names, wd):
         errs[n] = fro_rel(w.grad, pr[n].grad)
-    print("decoder layer @7B dims, Frobenius-relative error vs fp32 oracle: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
-    bounds = DECODER_7B_BOUNDS
-    for k, v in errs.items():
-        assert v < bounds.get(k, bounds["default"]), (k, v)
+        errc[n] = fro_rel(pc[n].grad, pr[n].grad)
+    print("decoder layer @7B dims, Frobenius-relative error vs the fp32 oracle, hip | reference-style bf16 autocast (mode C): " +
+          ", ".join(f"{k} {errs[k]:.2e} | {errc[k]:.2e}" for k in errs))
+    for k in errs:
+        assert errs[k] <= 2.0 * errc[k], (k, errs[k], errc[k])
 
 
 def test_decoder_layer_config4_recompute_is_bit_identical(dev):
@@ -218,6 +216,49 @@ def test_decoder_layer_config4_recompute_is_bit_identical(dev):
             assert torch.equal(a, b), lvl
     # ragged sequence: padded rows produce no gradient for their inputs through attention, and the output there is finite
     assert float(res[2][1][1, 1777:].float().abs().max()) < 1e4
+
+
+@pytest.mark.parametrize("policy", [(0, 1, 3, 2), (3, 3, 0, 0), (1, 0, 1, 0), (0, 0, 0, 0), (3, 3, 3, 3)])
+def test_decoder_stack_mixed_activation_policy_is_bit_identical(dev, policy):
+    """Mixed activation policy (bench.py --config 4: as many layers as fit in 288 GB keep their activations, the rest are
+    checkpointed; training/strategies/fsdp.py:211-223): a 4-layer stack at 7B dimensions, S = 2048, ragged -- every mix of the save
+    levels {0 = full recompute, 3 = level 1 without the kept SwiGLU product, 1, 2 = keep all} must give outputs, input gradients and
+    all 36 weight gradients BIT-identical to keeping everything."""
+    from mla_amd import ops
+    H, I, nh, B, S, L = 4096, 11008, 32, 2, 2048, 4
+    g = torch.Generator().manual_seed(13)
+    shapes = [(H,), (H, H), (H, H), (H, H), (H, H), (H,), (I, H), (I, H), (H, I)]
+    flats = []
+    for _ in range(L):
+        w32 = [((torch.ones(s) + 0.1 * torch.randn(s, generator=g)) if len(s) == 1 else 0.02 * torch.randn(s, generator=g)) for s in shapes]
+        flats.append(torch.cat([t.reshape(-1) for t in w32]).to(BF).to(dev))
+    x = torch.randn(B, S, H, generator=g).to(BF).to(dev)
+    dy = torch.randn(B, S, H, generator=g).to(BF).to(dev)
+    seqlens = torch.tensor([S, 1530], dtype=torch.int32, device=dev)
+    cos, sin = O.rope_tables(S, H // nh)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+
+    def run(levels):
+        wall = []
+        for flat in flats:
+            ws, off = [], 0
+            for sshape in shapes:
+                n = int(np.prod(sshape))
+                ws.append(flat[off:off + n].view(sshape).detach().requires_grad_(True))
+                off += n
+            wall.append(ws)
+        xd = x.clone().requires_grad_(True)
+        h = xd
+        for ws, lvl in zip(wall, levels):
+            h = ops.decoder_layer(h, seqlens, cos, sin, nh, 1e-5, lvl, ws)
+        h.backward(dy)
+        return h.detach(), xd.grad, [w.grad for ws in wall for w in ws]
+
+    ref = run((2,) * L)
+    got = run(policy)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), policy
+    for i, (a, b) in enumerate(zip(got[2], ref[2])):
+        assert torch.equal(a, b), (policy, i)
 
 
 def _run_hip_e2e(dev, save_level=2):
@@ -288,9 +329,9 @@ def test_mla_e2e_against_oracle_flash_semantics(dev):
 
 def test_full_size_step_is_deterministic_and_consistent(dev):
     """BASELINE configs[1] at full size (7B, 8 samples x 4 repeats x 548 tokens; what bench.py times): properties that need no CPU
-    reference -- the forward pass is bit-reproducible (same batch, zero learning rate -> the same loss) and the gradient norm
-    reproduces to 1e-5 (the only atomics on the path are torch's index_select backward in the contrastive row gather, which the
-    reference has as well), the global gradient norm equals the norm over the per-unit fp32 gradient buffers, the loss dict carries the reference's
+    reference -- the WHOLE step is bit-reproducible (same batch, zero learning rate -> the same loss, the same gradient norm and
+    bit-equal fp32 gradient buffers: no atomics anywhere on the path; the contrastive row gather with repeated targets sums its
+    duplicates in a fixed order, ops.GatherRowsSumFn), the global gradient norm equals the norm over the per-unit fp32 gradient buffers, the loss dict carries the reference's
     seven keys with `diff_loss` aliasing `total_loss`, and clipping scales the update (coefficient = 1 / norm for norm > 1)."""
     import math
     import bench
@@ -302,16 +343,22 @@ def test_full_size_step_is_deterministic_and_consistent(dev):
                          max_grad_norm=1.0, lr_scheduler_type="constant", enable_gradient_checkpointing=False, repeated_diffusion_steps=4)
     strat.run_setup(n_train_examples=100)
     batch = make_batch(B=8, L_text=32, seed=42, device=dev, use_pointcloud=True)
-    out = []
+    out, snaps = [], []
+    probe = [u for u in strat.sharded.units if u.trainable]
+    probe = [probe[0], probe[len(probe) // 2], probe[-1]]      # first (projectors / root side), a middle decoder layer, the last unit
     for _ in range(2):
         torch.manual_seed(123)                    # same noise / timesteps / FPS starts in both steps
         ld = strat.train_step(batch)
         out.append((float(ld["total_loss"]), float(strat.sharded._norm), float(strat.sharded._coef)))
+        snaps.append([u.grad32.clone() for u in probe])
     assert set(ld) == {"total_loss", "img_pc_contrastive_loss", "tactile_contrastive_loss", "diff_loss", "image_gen_loss",
                        "point_cloud_gen_loss", "tactile_gen_loss"}
     assert float(ld["diff_loss"]) == float(ld["total_loss"])                 # the reference's aliasing (model_mla.py:215-229)
     assert out[0][0] == out[1][0], out                                       # forward: bit-reproducible
-    assert abs(out[0][1] - out[1][1]) < 1e-5 * out[0][1], out
+    assert out[0][1] == out[1][1], out                                       # backward: bit-equal gradient norm ...
+    for a, b, u in zip(snaps[0], snaps[1], probe):
+        assert torch.equal(a, b), f"fp32 gradient buffer of unit {u.name} differs between two identical steps"
+    del snaps
     loss, norm, coef = out[1]
     assert math.isfinite(loss) and 0.5 < loss < 50.0
     units = [u for u in strat.sharded.units if u.trainable]
