@@ -60,6 +60,17 @@ def _run(rank, world, dev, accumulate=False):
         return strat.train_step(b)
     losses, norms = [], []
     grads0 = None
+    local0 = {}
+    if world > 1:
+        # snapshot of every unit's LOCAL fp32 gradient buffer at the moment its reduce-scatter is launched (first step only): the
+        # parent checks that the reduced shards are exactly the rank mean of these -- the collective itself, isolated from bf16 noise
+        inner = strat.sharded._reduce_scatter
+
+        def spy(u):
+            if u.name not in local0:
+                local0[u.name] = u.grad32.detach().clone()
+            inner(u)
+        strat.sharded._reduce_scatter = spy
     for _ in range(STEPS):
         if accumulate:
             first = micro(0)
@@ -88,7 +99,8 @@ def _run(rank, world, dev, accumulate=False):
             "vlm.projector_2d.mlp.2.weight", "vlm.final_layer.mlp.fc1.weight", "vlm.llm_backbone.llm.model.norm.weight",
             "vlm.x_embedder.mlp.fc1.bias")
     compute = dict(m.named_parameters())
-    return dict(losses=losses, norms=norms, grads0=grads0, weights={k: full[k].cpu().numpy() for k in keys},
+    return dict(losses=losses, norms=norms, grads0=grads0, local0={k: v.cpu().numpy() for k, v in local0.items()},
+                weights={k: full[k].cpu().numpy() for k in keys},
                 compute={k: compute[k].detach().float().cpu().numpy() for k in keys})
 
 
@@ -127,11 +139,17 @@ def test_two_rccl_ranks_match_single_process(dev):
     """The same comparison over the REAL collective path: two processes, one MI355X each, backend nccl (= RCCL over xGMI):
     reduce_scatter_tensor(AVG) launched from the backward on the side stream, in-place all_gather_into_tensor behind the optimizer,
     scalar all-reduce of the gradient norm (training/strategies/fsdp.py:181-209, 308-310)."""
-    _compare(_run(0, 1, dev), *_two_ranks("nccl"), tag="rccl")
+    r0, r1 = _two_ranks("nccl")
+    _check_collective_exact(r0, r1)
+    _compare_grads(_run(0, 1, dev, accumulate=True), (r0, r1), "rccl, vs accumulation window", ACC_GRAD_FRO, ACC_GRAD_FRO_WORST)
+    _compare(_run(0, 1, dev), r0, r1, tag="rccl")
 
 
 def test_two_ranks_match_single_process(dev):
-    _compare(_run(0, 1, dev), *_two_ranks("gloo"), tag="gloo")
+    r0, r1 = _two_ranks("gloo")
+    _check_collective_exact(r0, r1)
+    _compare_grads(_run(0, 1, dev, accumulate=True), (r0, r1), "gloo, vs accumulation window", ACC_GRAD_FRO, ACC_GRAD_FRO_WORST)
+    _compare(_run(0, 1, dev), r0, r1, tag="gloo")
 
 
 # Bounds = 1.5 x the values measured on MI355X (printed on every run). Rank-averaged and single-process runs execute DIFFERENT kernel
@@ -144,7 +162,17 @@ def test_two_ranks_match_single_process(dev):
 DP_LOSS_REL, DP_NORM_REL, DP_COS_MIN, DP_UPD_NORM_REL = 1.0e-2, 8e-3, 0.975, 2e-2
 # The reduced gradients themselves -- what reduce-scatter(mean) / the accumulation window produce, before AdamW's sign-like first steps
 # amplify anything: Frobenius distance of the WHOLE gradient (all trainable parameters) and of the worst single matrix, relative.
-DP_GRAD_FRO, DP_GRAD_FRO_WORST = 3e-3, 1.5e-2
+# Three comparisons, from exact to bf16-level:
+#  (1) reduced shards == rank mean of the ranks' local buffers at reduce-scatter time: EXACT (the collective, isolated);
+#  (2) reduced shards vs the one-process ACCUMULATION window over the same two samples -- the micro-batches have the per-rank shapes,
+#      so both sides run the same kernels on the same data and differ only in where the fp32 sum is formed (GEMM epilogue `+= C` vs
+#      the collective): fp32-rounding level, bound 1e-5 / 1e-4 (whole gradient / worst matrix);
+#  (3) reduced shards vs the single-process run on the batch of two: different tile counts / split-K tails / attention grids move
+#      individual bf16 activations by an ulp, and nine layers of that is a 1 % gradient difference. Measured on MI355X (round 3):
+#      1.01e-2 whole gradient, 2.78e-2 worst matrix (layers.3 q_proj); the same figure for one decoder layer against the fp32
+#      oracle is 0.7-1.1e-2 (test_decoder_layer_at_7b_dimensions), i.e. this is the bf16 floor, not a sharding artefact.
+DP_GRAD_FRO, DP_GRAD_FRO_WORST = 2e-2, 5e-2
+ACC_GRAD_FRO, ACC_GRAD_FRO_WORST = 1e-5, 1e-4
 
 
 def _param_grads(*ranks):
@@ -153,7 +181,21 @@ def _param_grads(*ranks):
     return {n: full[u][o:o + k] for n, (u, o, k) in ranks[0]["grads0"]["where"].items()}
 
 
-def _compare_grads(single, ranks, tag):
+def _check_collective_exact(r0, r1):
+    """(1) above: concat(rank shards) == (local_0 + local_1) / 2 bit for bit, for every trainable unit."""
+    n = 0
+    for name, l0 in r0["local0"].items():
+        want = (l0.astype(np.float32) + r1["local0"][name]) * np.float32(0.5)
+        got = np.concatenate([r0["grads0"]["shards"][name], r1["grads0"]["shards"][name]])
+        assert np.array_equal(got, want), f"unit {name}: reduce-scatter(mean) result differs from the mean of the local buffers"
+        n += 1
+    assert n >= 10, n
+    print(f"reduce-scatter(mean): {n} units, reduced shards == mean of the ranks' local fp32 buffers, bit for bit")
+
+
+def _compare_grads(single, ranks, tag, fro=None, fro_worst=None):
+    fro = DP_GRAD_FRO if fro is None else fro
+    fro_worst = DP_GRAD_FRO_WORST if fro_worst is None else fro_worst
     ref, got = _param_grads(single), _param_grads(*ranks)
     assert ref.keys() == got.keys()
     num = sum(float(((got[n].astype(np.float64) - ref[n]) ** 2).sum()) for n in ref) ** 0.5
@@ -167,7 +209,7 @@ def _compare_grads(single, ranks, tag):
             worst_n, worst = n, e
     print(f"reduced gradients ({tag}) vs single-process fp32 gradient buffer: Frobenius rel {num / den:.2e} over {len(ref)} tensors, "
           f"worst matrix {worst:.2e} ({worst_n})")
-    assert num / den < DP_GRAD_FRO and worst < DP_GRAD_FRO_WORST, (num / den, worst, worst_n)
+    assert num / den < fro and worst < fro_worst, (num / den, worst, worst_n)
 
 
 def _compare(single, r0, r1, tag):
