@@ -179,6 +179,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus:
+        # never a silent smaller job: N ranks need N devices (one RCCL rank per GPU)
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible")
     if args.gpus != world:
         if "RANK" not in os.environ and args.gpus > 1:
             # plain `python bench.py --gpus N`: re-launch ourselves as N ranks (one process per GPU) under torch.distributed.run --
@@ -191,9 +195,11 @@ def main():
             os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                       "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
-    if not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus:
-        # never a silent smaller job: N ranks need N devices (one RCCL rank per GPU)
-        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible")
+    # stdout carries exactly ONE line, the JSON: native libraries that print to fd 1 (RCCL's version banner at communicator
+    # creation) are pointed at stderr for the whole run, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:       # launched through torch.distributed.run (also with --gpus 1)
@@ -342,7 +348,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         if world > 1:
             assert out["rccl_ranks"] == world == args.gpus, (out["rccl_ranks"], world, args.gpus)   # N GPUs means N RCCL ranks, never fewer
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -80,7 +80,7 @@ class FlatUnit:
 
     def __init__(self, name: str, named_params: Sequence[Tuple[str, nn.Parameter]], device, world: int, rank: int, ops,
                  no_decay: Callable[[str, nn.Parameter], bool], process_group=None, sync_from_rank0: bool = True,
-                 collectives: Optional[bool] = None):
+                 collectives: Optional[bool] = None, inplace_reduce: bool = False):
         self.name, self.world, self.rank, self.ops, self.device = name, world, rank, ops, device
         coll = (world > 1) if collectives is None else collectives   # separate shard buffers + real collectives
         decay = [(n, p) for n, p in named_params if p.requires_grad and not no_decay(n, p)]
@@ -119,8 +119,17 @@ class FlatUnit:
             self.master_frozen = full32[self.n_train + rank * nf:self.n_train + (rank + 1) * nf].clone()
         del full32
         self.grad32 = torch.zeros(self.n_train, dtype=torch.float32, device=device) if self.trainable else None
+        # inplace_reduce (RCCL): the reduce-scatter writes this rank's shard INTO its own slice of the gradient buffer (NCCL's in-place
+        # form, recvbuff == sendbuff + rank * count) as a SUM; the 1 / world of the mean is folded into the norm and into AdamW's
+        # gradient scale (ShardedModel.grad_div). No separate shard buffer (27 GB / world at 7B), no copy when world == 1.
+        self.inplace_reduce = bool(coll and inplace_reduce)
         if self.trainable:
-            self.gshard = self.grad32 if not coll else torch.zeros(self.shard_train, dtype=torch.float32, device=device)
+            if not coll:
+                self.gshard = self.grad32
+            elif self.inplace_reduce:
+                self.gshard = self.grad32[rank * self.shard_train:(rank + 1) * self.shard_train]
+            else:
+                self.gshard = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
             self.exp_avg = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
             self.exp_avg_sq = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
         # ---- re-point the module parameters at the bf16 compute storage; install fp32 main_grad views
@@ -237,7 +246,7 @@ class FlatUnit:
         n = self.flat16.numel() * 2 + (self.master_train.numel() + self.master_frozen.numel()) * 4
         if self.trainable:
             n += self.grad32.numel() * 4 + (self.exp_avg.numel() + self.exp_avg_sq.numel()) * 4
-            if self.gshard is not self.grad32:
+            if self.gshard is not self.grad32 and not self.inplace_reduce:
                 n += self.gshard.numel() * 4
         return n
 
@@ -256,6 +265,9 @@ class ShardedModel:
         # used to validate the collective plumbing on a single-GPU box
         self.coll = self.world > 1 or (os.environ.get("MLA_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
         self.ops = ops if ops is not None else HipLocalOps()
+        # RCCL: in-place SUM reduce-scatter, mean folded into the scales (see FlatUnit). gloo (CPU tests) keeps separate mean shards.
+        self.inplace_reduce = bool(self.coll and dist.get_backend(process_group) == "nccl")
+        self.grad_div = float(self.world) if self.inplace_reduce else 1.0     # gshard holds grad_div x the mean gradient
         no_decay = no_decay or (lambda n, p: p.ndim <= 1 or n.endswith(".bias"))   # fsdp.py:236-256
         # ---- unit discovery (outermost matches of the policy; the remainder folds into the root unit)
         unit_mods: List[Tuple[str, nn.Module]] = []
@@ -333,7 +345,8 @@ class ShardedModel:
     def _add_unit(self, name, mod, named, no_decay):
         if not named:
             return
-        u = FlatUnit(name, named, self.device, self.world, self.rank, self.ops, no_decay, self.pg, collectives=self.coll)
+        u = FlatUnit(name, named, self.device, self.world, self.rank, self.ops, no_decay, self.pg, collectives=self.coll,
+                     inplace_reduce=self.inplace_reduce)
         u.module = mod
         self.units.append(u)
 
@@ -357,7 +370,10 @@ class ShardedModel:
     def _reduce_scatter(self, u: FlatUnit):
         backend = dist.get_backend(self.pg)
         if backend == "nccl":
-            dist.reduce_scatter_tensor(u.gshard, u.grad32, op=dist.ReduceOp.AVG, group=self.pg)
+            if u.inplace_reduce:
+                dist.reduce_scatter_tensor(u.gshard, u.grad32, op=dist.ReduceOp.SUM, group=self.pg)     # in place (gshard = own slice)
+            else:
+                dist.reduce_scatter_tensor(u.gshard, u.grad32, op=dist.ReduceOp.AVG, group=self.pg)
         else:  # gloo (CPU tests): all-reduce + slice
             dist.all_reduce(u.grad32, op=dist.ReduceOp.SUM, group=self.pg)
             u.gshard.copy_(u.grad32[self.rank * u.shard_train:(self.rank + 1) * u.shard_train] / self.world)
@@ -447,7 +463,11 @@ class ShardedModel:
             first = False
         if self.coll:
             dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.grad_div != 1.0:
+            self._sumsq.mul_(1.0 / (self.grad_div * self.grad_div))     # the shards hold SUMS over ranks: norm of the mean gradient
         self.ops.clip_coef(self._sumsq, float(max_norm) if max_norm is not None else 3.0e38, self._coef, self._norm)
+        if self.grad_div != 1.0:
+            self._coef.mul_(1.0 / self.grad_div)                        # AdamW's gradient scale = clip coefficient x 1 / world
         return self._norm
 
     def optimizer_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):

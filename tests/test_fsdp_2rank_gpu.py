@@ -85,7 +85,8 @@ def _run(rank, world, dev, accumulate=False):
             # the REDUCED gradients of the first step, as the collectives left them: this rank's 1/world shard of every unit's fp32
             # gradient buffer (world 1: the whole buffer) + where each parameter sits in the unsharded buffer. AdamW only reads them.
             torch.cuda.synchronize()
-            grads0 = dict(shards={u.name: u.gshard.detach().cpu().numpy().copy() for u in strat.sharded.units if u.trainable},
+            div = np.float32(strat.sharded.grad_div)     # RCCL path: in-place SUM shards, the mean's 1 / world lives in the scales
+            grads0 = dict(shards={u.name: u.gshard.detach().cpu().numpy().copy() / div for u in strat.sharded.units if u.trainable},
                           where={n: (u.name, o, p.numel()) for u in strat.sharded.units if u.trainable for n, p, o in u.params
                                  if p.requires_grad})
         if world == 1:
