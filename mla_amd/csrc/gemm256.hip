@@ -100,6 +100,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     nt = (int)((long long)(slice + 1) * nt / p.sk_split) - kt0;
     part = p.sk_ws + (size_t)u * 65536;
   }
+#ifdef MLA_EXPERIMENTAL_KERNELS
+  // Round-3 experiment (tools/exp_stagger.sh), NULL RESULT: 0 ... -2.8 % for delays of 20-70 us in either mode. The fused epilogues
+  // are bound by what ONE CU can move (768 KB per tile at ~12 B/clk, the same rate with 16 workgroups on the chip as with 256), not
+  // by 256 CUs bursting at once, so shifting bursts in time buys nothing; only stores issued under the SAME CU's next main loop
+  // could, and 160 KB of LDS (128 KB operand ring) cannot carry a staged 128-256 KB tile alongside.
+  if (EPI != 0 && p.stagger_mode && (int)blockIdx.x < 256) {     // see GemmArgs::stagger_mode
+    const bool late = p.stagger_mode == 1 ? (blockIdx.x & 1) : ((blockIdx.x >> 3) & 1);
+    if (late) {
+      const unsigned long long t0 = wall_clock64();
+      while ((long long)(wall_clock64() - t0) < (long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+#endif
   const int in_group = GROUP_M * num_n;
   const int group_id = pid / in_group;
   const int first_m = group_id * GROUP_M;
@@ -1178,6 +1191,18 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
     const char* e = getenv("MLA_GEMM_PERSIST");
     persist = (e && e[0] == '1') ? 1 : 0;
   }
+#ifdef MLA_EXPERIMENTAL_KERNELS
+  if (p.sf_I || p.sw_gu) {
+    static int st_mode = -1, st_ticks = 0;
+    if (st_mode < 0) {
+      const char* e = getenv("MLA_GEMM_STAGGER");      // "<mode>:<ticks of 10 ns>", e.g. 1:4500
+      st_mode = 0;
+      if (e && sscanf(e, "%d:%d", &st_mode, &st_ticks) != 2) st_mode = 0;
+    }
+    p.stagger_mode = st_mode;
+    p.stagger_ticks = st_ticks;
+  }
+#endif
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   if (p.sq_out) {   // sum-of-squares partials: fp32 output through the whole-row (fast) epilogue, plain instantiation only
     const bool ok = p.out_fp32 && a_mode == 0 && b_mode == 0 && !p.sf_I && !p.sw_gu && !p.rope_cos && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&

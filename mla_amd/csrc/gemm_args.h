@@ -46,4 +46,8 @@ struct GemmArgs {
   bf16_t* sw_dguT;
   int sw_I;
   long long sw_ldt;
+  // fused-epilogue launches only (EPI != 0), experiment switch MLA_GEMM_STAGGER=<mode>:<ticks>: part of the FIRST round of workgroups
+  // starts `stagger_ticks` (10 ns units) late, so that the HBM-bound epilogue bursts of one half of the chip fall into the other
+  // half's main loops instead of all 256 CUs storing at once. mode 1: odd XCDs late, mode 2: every other workgroup of each XCD late.
+  int stagger_mode, stagger_ticks;
 };
