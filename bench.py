@@ -283,12 +283,14 @@ def main():
             # so it is not done inline): profiles/r1_gemm256_hbm_traffic.json, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE
             traffic = None
             tprov = None
-            for tname in ("r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
+            hit = None
+            for tname in ("r3_gemm256_hbm_traffic.json", "r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and args.config == 1 and not args.tiny:
                     with open(tpath) as fh:
                         tj = json.load(fh)
                     traffic = round(tj["hbm_bytes_per_launch"])
+                    hit = tj.get("tcc_hit_rate")
                     tprov = f"profiles/{tname} (collected {tj.get('collected', 'round 1')}; separate --pmc passes over this command, not this run)"
                     break
             if os.environ.get("MLA_BENCH_GEMM_SHAPES"):
@@ -318,7 +320,10 @@ def main():
                                                        "achieved_gemm_flops_only": round(ach_fused, 1), "launches_per_step": len(fused) // args.steps}
                                                       if fused else None),
                     "all_gemm_launches_achieved": round(ach_all, 1),
-                    "traffic": traffic, "traffic_source": tprov, "traffic_unit": "HBM+MALL bytes per launch (fabric-side counters), avg over the same launches",
+                    "traffic": traffic, "traffic_source": tprov,
+                    "traffic_unit": "HBM+MALL bytes per launch (fabric-side counters), avg over the plain gemm256_kernel<0,0,0> launches >= 0.1 TFLOP "
+                                    "(the population of algorithmic_bytes_per_launch)",
+                    "l2_hit_rate": (round(hit, 4) if hit is not None else None),
                     "algorithmic_bytes_per_launch_2B_outputs": round(abytes), "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
                     "gemm_ms_per_step": round(tsum / args.steps * 1e3, 1)}
         out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
