@@ -413,6 +413,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         // beyond the operand ring -- as [channel][token] lines of 128 B whose token slot is XORed with 2 x piece index (bank-
         // conflict-free 2-byte writes); (c) the lines are read back as 16-B pieces of 8 tokens (undoing the XOR: piece index and a
         // dword permutation) and stored to d(gate|up)^T. d(act) costs no HBM traffic at all (was: 1 write + 1 read per element).
+        // Where its time goes (round 3, ablation build, per launch at the 7B shape; 1 555 us with the full epilogue, 1 094 us with
+        // none, the plain GEMM of the same shape incl. its own epilogue 1 153 us): gate|up loads 88 us, row-major stores 107, transposed
+        // stores 116, LDS transposition 27-40, arithmetic (one full-precision divide per element) + image reads + barriers ~120 --
+        // additive. Each 256-KB-per-tile stream costs what 772 MB cost at ~7.5 TB/s: all 256 CUs run their epilogues at the same
+        // time and share the memory system, so the I/O is already at the chip's rate and only overlap with OTHER workgroups' main
+        // loops could hide it. Tried and measured: gate|up fetched one strip ahead (-0.5 %, noise), all 32 loads up front from
+        // inline assembly with counted waits (+2 %: 256 KB of reads per CU queue in front of the stores), first-round stagger (0 ... -3 %).
         const int I = p.sw_I;
         char* scrB = smem + 2 * BUF;
         const size_t ld2 = (size_t)2 * I;
