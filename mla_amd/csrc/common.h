@@ -88,15 +88,19 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 
 // SwiGLU forward of one element: silu(g) * u on bf16-rounded inputs, fp32 arithmetic, rounded once by the caller
 // (LlamaMLP.forward, modeling_llama.py:240). One definition for the stand-alone kernels and the fused GEMM epilogue.
+// sigmoid: v_exp_f32 + v_rcp_f32 (1 ulp). The IEEE-exact `1.f / x` compiles to v_div_scale x 2 + v_rcp + 4 fma + v_div_fmas +
+// v_div_fixup = 9 more VALU per element -- in the fused GEMM epilogues that was a third of the arithmetic the CU does while its
+// matrix pipe idles (round 3). The result is rounded to bf16 right after; fused and stand-alone kernels share this definition.
+__device__ __forceinline__ float mla_sigmoid(float g) { return __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
 __device__ __forceinline__ float swiglu_fwd_elem(float g, float u) {
-  const float sg = 1.f / (1.f + __expf(-g));
+  const float sg = mla_sigmoid(g);
   return (g * sg) * u;
 }
 
 // SwiGLU backward of one element (autograd of LlamaMLP.forward, modeling_llama.py:240): d = d(act), act = silu(g) * u.
 // ONE definition for the stand-alone kernel (transpose.hip) and the fused GEMM epilogue (gemm256.hip): identical results, bit for bit.
 __device__ __forceinline__ void swiglu_bwd_elem(float d, float g, float u, float& dg, float& du) {
-  const float sg = 1.f / (1.f + __expf(-g));
+  const float sg = mla_sigmoid(g);
   const float sl = g * sg;
   dg = d * u * (sg + sl * (1.f - sg));
   du = d * sl;

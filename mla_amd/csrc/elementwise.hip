@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
     unpack8(*(const u32x4_t*)(gu + r * 2 * I + c * 8), g);
     unpack8(*(const u32x4_t*)(gu + r * 2 * I + I + c * 8), u);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float s = 1.f / (1.f + __expf(-g[j])); o[j] = (g[j] * s) * u[j]; }
+    for (int j = 0; j < 8; ++j) o[j] = swiglu_fwd_elem(g[j], u[j]);
     *(u32x4_t*)(act + r * I + c * 8) = pack8(o);
   }
 }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
     unpack8(*(const u32x4_t*)(dact + r * I + c * 8), d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float s = 1.f / (1.f + __expf(-g[j]));
+      const float s = mla_sigmoid(g[j]);
       const float sl = g[j] * s;
       dg[j] = d[j] * u[j] * (s + sl * (1.f - s));
       du[j] = d[j] * sl;
@@ -469,7 +469,7 @@ __device__ __forceinline__ float act_df(int kind, float x) {
       return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
     }
     case 2: return x > 0.f ? 1.f : 0.f;
-    default: { const float s = 1.f / (1.f + __expf(-x)); return s + x * s * (1.f - s); }
+    default: { const float s = mla_sigmoid(x); return s + x * s * (1.f - s); }
   }
 }
 __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long n,

@@ -39,9 +39,8 @@ struct SwigluOp {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float g0 = bflo(g[j]), g1 = bfhi(g[j]);
-      const float s0 = 1.f / (1.f + __expf(-g0)), s1 = 1.f / (1.f + __expf(-g1));
-      v[2 * j] = (g0 * s0) * bflo(u[j]);
-      v[2 * j + 1] = (g1 * s1) * bfhi(u[j]);
+      v[2 * j] = swiglu_fwd_elem(g0, bflo(u[j]));
+      v[2 * j + 1] = swiglu_fwd_elem(g1, bfhi(u[j]));
     }
   }
 };
