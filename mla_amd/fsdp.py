@@ -255,7 +255,8 @@ class ShardedModel:
     """Owns the FlatUnits of a model and runs the step-level collectives + optimizer."""
 
     def __init__(self, model: nn.Module, unit_policy: Callable[[nn.Module], bool], device, ops=None,
-                 process_group=None, no_decay: Optional[Callable[[str, nn.Parameter], bool]] = None):
+                 process_group=None, no_decay: Optional[Callable[[str, nn.Parameter], bool]] = None,
+                 inplace_reduce: Optional[bool] = None):
         self.model, self.device = model, device
         self.pg = process_group
         import os
@@ -266,7 +267,8 @@ class ShardedModel:
         self.coll = self.world > 1 or (os.environ.get("MLA_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
         self.ops = ops if ops is not None else HipLocalOps()
         # RCCL: in-place SUM reduce-scatter, mean folded into the scales (see FlatUnit). gloo (CPU tests) keeps separate mean shards.
-        self.inplace_reduce = bool(self.coll and dist.get_backend(process_group) == "nccl")
+        # (inplace_reduce=True with gloo is for the CPU tests: it runs the same SUM-shard bookkeeping over an in-place all-reduce)
+        self.inplace_reduce = bool(self.coll and (dist.get_backend(process_group) == "nccl" if inplace_reduce is None else inplace_reduce))
         self.grad_div = float(self.world) if self.inplace_reduce else 1.0     # gshard holds grad_div x the mean gradient
         no_decay = no_decay or (lambda n, p: p.ndim <= 1 or n.endswith(".bias"))   # fsdp.py:236-256
         # ---- unit discovery (outermost matches of the policy; the remainder folds into the root unit)
@@ -376,7 +378,8 @@ class ShardedModel:
                 dist.reduce_scatter_tensor(u.gshard, u.grad32, op=dist.ReduceOp.AVG, group=self.pg)
         else:  # gloo (CPU tests): all-reduce + slice
             dist.all_reduce(u.grad32, op=dist.ReduceOp.SUM, group=self.pg)
-            u.gshard.copy_(u.grad32[self.rank * u.shard_train:(self.rank + 1) * u.shard_train] / self.world)
+            if not u.inplace_reduce:            # (in place: gshard IS the rank's slice of grad32 and now holds the SUM)
+                u.gshard.copy_(u.grad32[self.rank * u.shard_train:(self.rank + 1) * u.shard_train] / self.world)
 
     def _all_gather(self, u: FlatUnit):
         """bf16 all-gather of the trainable region (frozen weights never change)."""

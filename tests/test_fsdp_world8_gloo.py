@@ -94,14 +94,16 @@ def _int_grad(shape, step, rank, pidx):
     return torch.randint(-4, 5, shape, generator=g).to(torch.float32) / 64.0
 
 
-def _worker(rank, world, port, grouped, ret):
+def _worker(rank, world, port, grouped, inplace, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mla_amd.fsdp import ShardedModel
         ops = GroupedOps() if grouped else TorchLocalOps()
         model = _make()
-        sm = ShardedModel(model, lambda mod: isinstance(mod, (Block, Tower)), torch.device("cpu"), ops=ops, no_decay=_no_decay)
+        sm = ShardedModel(model, lambda mod: isinstance(mod, (Block, Tower)), torch.device("cpu"), ops=ops, no_decay=_no_decay,
+                          inplace_reduce=inplace)
+        assert sm.grad_div == (float(world) if inplace else 1.0)
         names = [u.name for u in sm.units]
         assert names == ["frozen_tower", "tower", "<root>", "layers.0", "layers.1", "layers.2"], names
         assert not sm.units[0].trainable and sm.units[1].trainable
@@ -145,17 +147,19 @@ def _worker(rank, world, port, grouped, ret):
                 for n, p, o in u.params:
                     if p.requires_grad:
                         full[o:o + p.numel()] = mean[n].reshape(-1)
-                assert torch.equal(u.gshard, full[rank * u.shard_train:(rank + 1) * u.shard_train]), (u.name, "reduced shard")
+                # (in-place form: the shard is the rank's slice of the gradient buffer and holds the SUM; 1 / world lives in the scales)
+                assert torch.equal(u.gshard / sm.grad_div, full[rank * u.shard_train:(rank + 1) * u.shard_train]), (u.name, "reduced shard")
             norm = sm.grad_norm_and_clip(max_norm)
             want_norm = torch.sqrt(sum((g.double() ** 2).sum() for g in mean.values()).float())
             assert torch.equal(norm.reshape(()), want_norm.reshape(())), (float(norm), float(want_norm))
-            assert float(sm._coef) < 1.0                                   # the clip is active
+            assert float(sm._coef) * sm.grad_div < 1.0                     # the clip is active
             sm.optimizer_step(lr, betas=betas, eps=eps, weight_decay=wd)
             for n, p in order:
                 if not p.requires_grad:
                     continue
                 p16 = torch.empty(p.shape, dtype=torch.bfloat16)
-                ref_ops.adamw(rp[n], mean[n], rm[n], rv[n], p16, lr, betas, eps, 0.0 if _no_decay(n, p) else wd, step, sm._coef)
+                ref_ops.adamw(rp[n], mean[n], rm[n], rv[n], p16, lr, betas, eps, 0.0 if _no_decay(n, p) else wd, step,
+                              sm._coef * sm.grad_div)
             full = sm.full_state_dict_fp32()
             for n, p in order:
                 assert torch.equal(full[n], rp[n]), (step, n, "fp32 master")
@@ -176,7 +180,8 @@ def _worker(rank, world, port, grouped, ret):
         # (fresh moments on the reference side would diverge from the sharded state: rebuild the sharded model from the same weights)
         model2 = _make()
         model2.load_state_dict({n: rp[n] for n, _ in order})
-        sm2 = ShardedModel(model2, lambda mod: isinstance(mod, (Block, Tower)), torch.device("cpu"), ops=ops, no_decay=_no_decay)
+        sm2 = ShardedModel(model2, lambda mod: isinstance(mod, (Block, Tower)), torch.device("cpu"), ops=ops, no_decay=_no_decay,
+                           inplace_reduce=inplace)
         for step in range(2):
             sm2.begin_step()
             xs = [torch.randn(5, 7, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
@@ -213,12 +218,15 @@ def _worker(rank, world, port, grouped, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grouped", [False, True], ids=["adamw_per_range", "adamw_groups"])
-def test_sharded_model_world8_gloo_bit_exact(grouped):
+@pytest.mark.parametrize("grouped,inplace", [(False, False), (True, False), (True, True)],
+                         ids=["adamw_per_range-mean_shards", "adamw_groups-mean_shards", "adamw_groups-inplace_sum_shards"])
+def test_sharded_model_world8_gloo_bit_exact(grouped, inplace):
+    """inplace = the RCCL path's bookkeeping (reduce-scatter as an in-place SUM into the rank's slice of the gradient buffer, 1 / world
+    folded into the norm and into AdamW's gradient scale) run over gloo."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(WORLD, port, grouped, ret), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(WORLD, port, grouped, inplace, ret), nprocs=WORLD, join=True)
     assert dict(ret) == {r: "ok" for r in range(WORLD)}
