@@ -168,6 +168,16 @@ int mla_attn_bwd_t(const void* q, const void* k, const void* v, const void* o, c
                    void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
                    float scale, const float* rope_cos, const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT,
                    long long ldt, mla_stream_t stream);
+/* Five-product form of the backward (opt-in in mla_amd: measured no faster than the seven-product pair on MI355X):
+ * the dK / dV kernel hands dS^T to a one-product dQ kernel through the
+ * caller-owned workspace `ws` (mla_attn_bwd_ws_bytes(B, S, H) bytes, 16-B aligned) instead of both kernels recomputing Q K^T and
+ * dO V^T; delta = rowsum(O o dO) is its own pass. Same outputs and argument meaning as mla_attn_bwd_t (dqT / dkT / dvT / oT: all or
+ * none); deterministic (no atomics). Replaces the flash-attn backward behind modeling_llama.py:531-553. */
+long long mla_attn_bwd_ws_bytes(int B, int S, int H);
+int mla_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
+                    void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
+                    float scale, const float* rope_cos, const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt,
+                    void* ws, long long ws_bytes, mla_stream_t stream);
 
 /* ---- losses: CrossEntropyLoss modeling_llama.py:1258-1269; InfoNCE models/mla/fuser/contrastive.py:208-215 */
 int mla_ce_fwd(const void* logits, int logits_fp32, long long ld, const long long* labels, float* loss, float* lse, int rows,

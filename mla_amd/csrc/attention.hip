@@ -160,6 +160,7 @@ struct AttnArgs {
   float scale;
   const float* rope_cos; const float* rope_sin;        // backward only: [S, 64] fp32 tables; non-null = dq / dk leave the kernels with
                                                        // the RoPE backward already applied (replaces a separate in-place pass)
+  bf16_t* ds_ws;                                       // backward, 5-product form: dS^T tiles handed from the dK / dV kernel to the dQ kernel
   bf16_t* dqT; bf16_t* dkT; bf16_t* dvT; bf16_t* oT;   // backward only, all or none: [H*D, ldT] token-contiguous copies of dq / dk / dv
   long long ldT;                                       // / o (the wgrad GEMM operands), written from the registers that hold the rows
 };
@@ -451,6 +452,109 @@ constexpr int ASW = MLA_ATTN_BWD_SW;   // LDS swizzle of the backward kernels' t
                                        // forms -- and measures the same: 410 / 268 us at S = 548; the loops are latency-bound)
 
 // ------------------------------------------------------------------------------------------------ dQ
+// A dQ block that is padding as a whole: zero dq (and dq^T), o^T of whatever the forward wrote (zeros for padded rows).
+template <int RB>
+__device__ __forceinline__ void dq_pad_block(const AttnArgs& p, const int (&myq)[RB], int b, int h, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+    if (myq[rb] < p.S) {
+      bf16_t* dqrow = p.dq + ((long long)b * p.S + myq[rb]) * p.ld + h * D;
+#pragma unroll
+      for (int fd = 0; fd < 8; ++fd) *(u32x2_t*)(dqrow + fd * 16 + g * 4) = u32x2_t{0u, 0u};
+      if (p.dqT) {   // (S % 4 == 0: a quad of tokens is inside the sequence or outside as a whole)
+        const long long tok4 = (long long)b * p.S + (myq[rb] & ~3);
+#pragma unroll
+        for (int fd = 0; fd < 8; ++fd)
+          *(u32x2_t*)(p.dqT + ((long long)h * D + fd * 16 + g * 4 + (lane & 3)) * p.ldT + tok4) = u32x2_t{0u, 0u};
+        bf16x8_t of[4];   // o^T of these rows: whatever the forward wrote (zeros for padded rows)
+        load_row_frags(p.o + ((long long)b * p.S + myq[rb]) * p.ld_o + h * D, lane, of);
+        store_frags_t(p.oT + (long long)h * D * p.ldT, p.ldT, tok4, of, lane, true);
+      }
+    }
+}
+
+// Epilogue shared by the two dQ kernels: scale, RoPE backward, dq rows + dq^T + o^T through LDS (see the dK / dV kernel).
+template <int RB, int NW>
+__device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4_t (&dqt)[RB][8], const int (&myq)[RB], const bool (&padq)[RB],
+                                            int b, int h, int q0, int wave, int lane) {
+  constexpr int BQ = 16 * NW * RB;
+  const int g = lane >> 4;
+  // ---- epilogue: everything leaves through LDS (the K / V ring is free now) as whole row runs, see the dK / dV kernel. Images
+  // (32 KiB each, BQ = 128 queries): dq [128 q][128 ch], 8-B chunk index XOR-swizzled by (q & 15) << 1; dq^T and, in a second
+  // round, o^T [128 ch][128 q], chunk index swizzled by (ch & 7) << 2. O is re-read here (L2) for its transposed copy.
+  static_assert(BQ == 128, "the epilogue stages 128-query images");
+  const bool tr = p.dqT != nullptr;
+  const int pq = lane & 3;
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const bool valid = myq[rb] < p.S;
+    const float sc = padq[rb] ? 0.f : p.scale;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) dqt[rb][fd] *= sc;
+    if (p.rope_cos) rope_bwd_row(dqt[rb], p.rope_cos, p.rope_sin, valid ? myq[rb] : 0, g);
+    const int grp = row_group<RB>(wave, rb);
+    const int row = grp * 16 + (lane & 15);
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) {
+      u32x2_t w;
+      w[0] = valid ? pack2bf(dqt[rb][fd][0], dqt[rb][fd][1]) : 0u;
+      w[1] = valid ? pack2bf(dqt[rb][fd][2], dqt[rb][fd][3]) : 0u;
+      *(u32x2_t*)(smem + row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8)) = w;
+      if (tr) {
+        const int c = fd * 16 + g * 4 + pq;
+        *(u32x2_t*)(smem + 32768 + c * 256 + (((grp * 4 + ((lane & 15) >> 2)) ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(w[0], w[1], lane);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NT = 64 * NW;
+  {
+    const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
+#pragma unroll
+    for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
+      const int r = ps * (NT / 16) + (threadIdx.x >> 4);
+      if (q0 + r < p.S)
+        *(u32x4_t*)(p.dq + ((long long)b * p.S + q0 + r) * p.ld + h * D + j * 8) =
+            *(const u32x4_t*)(smem + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
+    }
+  }
+  if (tr) {
+    const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3
+    const bool jv = q0 + j * 4 < p.S;
+    const long long tok = (long long)b * p.S + q0 + j * 4;
+#pragma unroll
+    for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
+      const int c = ps * (NT / 32) + (threadIdx.x >> 5);
+      if (jv) *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 32768 + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
+      bf16x8_t of[4];
+      load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        union { bf16x8_t v; uint32_t u[4]; } f;
+        f.v = of[ks];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int c = ks * 32 + g * 8 + half * 4 + pq;
+          *(u32x2_t*)(smem + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
+      const int c = ps * (NT / 32) + (threadIdx.x >> 5);
+      if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
+    }
+  }
+}
+
 // Same row-group pairing and per-(wave, group, tile) skipping as the forward kernel.
 template <int RB, int MASK>
 __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], const bf16x8_t (&dof)[RB][4],
@@ -538,22 +642,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   const int kt_lim = (seqlen + 63) / 64;
   if (nkt > kt_lim) nkt = kt_lim;
   if (nkt <= 0 || q0 >= row_lim) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-      if (myq[rb] < p.S) {
-        bf16_t* dqrow = p.dq + ((long long)b * p.S + myq[rb]) * p.ld + h * D;
-#pragma unroll
-        for (int fd = 0; fd < 8; ++fd) *(u32x2_t*)(dqrow + fd * 16 + g * 4) = u32x2_t{0u, 0u};
-        if (p.dqT) {   // (S % 4 == 0: a quad of tokens is inside the sequence or outside as a whole)
-          const long long tok4 = (long long)b * p.S + (myq[rb] & ~3);
-#pragma unroll
-          for (int fd = 0; fd < 8; ++fd)
-            *(u32x2_t*)(p.dqT + ((long long)h * D + fd * 16 + g * 4 + (lane & 3)) * p.ldT + tok4) = u32x2_t{0u, 0u};
-          bf16x8_t of[4];   // o^T of these rows: whatever the forward wrote (zeros for padded rows)
-          load_row_frags(p.o + ((long long)b * p.S + myq[rb]) * p.ld_o + h * D, lane, of);
-          store_frags_t(p.oT + (long long)h * D * p.ldT, p.ldT, tok4, of, lane, true);
-        }
-      }
+    dq_pad_block<RB>(p, myq, b, h, lane);
     return;
   }
   bf16x8_t qf[RB][4], dof[RB][4];
@@ -615,61 +704,190 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
       dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
     }
   }
-  // ---- epilogue: everything leaves through LDS (the K / V ring is free now) as whole row runs, see the dK / dV kernel. Images
-  // (32 KiB each, BQ = 128 queries): dq [128 q][128 ch], 8-B chunk index XOR-swizzled by (q & 15) << 1; dq^T and, in a second
-  // round, o^T [128 ch][128 q], chunk index swizzled by (ch & 7) << 2. O is re-read here (L2) for its transposed copy.
-  static_assert(BQ == 128, "the epilogue stages 128-query images");
+  dq_epilogue<RB, NW>(p, smem, dqt, myq, padq, b, h, q0, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ 5-product backward (round 3)
+// The two-kernel backward above computes S = Q K^T and dP = dO V^T twice (dQ kernel: S, dP, dQ; dK / dV kernel: S, dP, dV, dK = 7 matrix
+// products). Here the dK / dV kernel, which holds dS^T = P^T o (dP^T - delta) of its 16 keys x 64 queries in registers anyway, also
+// stores it as bf16 tiles, and the dQ kernel shrinks to ONE product, dQ^T += K^T dS^T, with both operands gathered by transposing
+// LDS reads: 5 products, no atomics, no fp32 partial slabs (S^2 / 2 x 2 B per head of scratch instead of S^2 / 256 x 512 B), every
+// output bit-reproducible. dS^T reaches the second MFMA rounded to bf16 in both forms, so the results agree to fp32 rounding of delta.
+//   scratch: per (b, h) the lower-triangular 64 x 64 tiles (key block kb <= query tile qt), tile index qt (qt + 1) / 2 + kb, each tile
+//   4096 bf16 blocked as [key / 16][q / 16][16 keys][16 q]: what one wave's store instruction writes (16 keys x 16 q) is 512 contiguous
+//   bytes, and the dQ kernel's LDS-DMA staging re-assembles any 16-B piece (8 q of one key) wherever its image wants it.
+//   delta = rowsum(O o dO) comes from its own pass (the dK / dV kernel now runs first).
+__device__ __forceinline__ long long ds_tile_off(int bh, int ntri, int kb, int qt) {
+  return ((long long)bh * ntri + (qt * (qt + 1)) / 2 + kb) * 4096;
+}
+
+// delta[b, h, s] = sum_d O[b, s, h, d] * dO[b, s, h, d]  (fp32; padded rows give 0 because the forward wrote zeros there).
+// One wave per token: a 16-lane group covers one head's 128 channels per step (16 B per lane and operand); all of a token's loads are
+// issued before the first reduction (H / 4 steps x 2 operands in flight per lane).
+template <int HSTEPS>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
+                                                         int B, int S, int H, long long ld_o) {
+  const int lane = threadIdx.x & 63;
+  const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= (long long)B * S) return;
+  const int b = (int)(tok / S), sidx = (int)(tok % S);
+  const bf16_t* orow = o + tok * ld_o + (lane >> 4) * D + (lane & 15) * 8;
+  const bf16_t* drow = dout + tok * ld_o + (lane >> 4) * D + (lane & 15) * 8;
+  u32x4_t a[HSTEPS], d[HSTEPS];
+#pragma unroll
+  for (int st = 0; st < HSTEPS; ++st) {
+    const bool ok = st * 4 + (lane >> 4) < H;
+    a[st] = ok ? *(const u32x4_t*)(orow + st * 4 * D) : u32x4_t{0u, 0u, 0u, 0u};
+    d[st] = ok ? *(const u32x4_t*)(drow + st * 4 * D) : u32x4_t{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int st = 0; st < HSTEPS; ++st) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += bflo(a[st][j]) * bflo(d[st][j]) + bfhi(a[st][j]) * bfhi(d[st][j]);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    const int h = st * 4 + (lane >> 4);
+    if (h < H && (lane & 15) == 0) delta[((long long)b * H + h) * S + sidx] = acc;
+  }
+}
+
+// swizzle of the 16-B chunk index inside the 128-B rows of the dS^T image [64 keys][64 q]: conflict-free ds_read_b64_tr_b16 over 8
+// consecutive rows (two rows span the 64 banks; the four rows of one parity get four different chunk pairs)
+__device__ __forceinline__ int swz64(int row, int c) { return c ^ (((row >> 1) & 3) << 1); }
+// B fragment from the dS^T image: lane (i -> query fq * 16 + i, g) gets dS^T[key row(g, j)][q], the reduction mapping of frag_tr
+__device__ __forceinline__ bf16x8_t frag_tr64(const char* tile, int fq, int ks2, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  union { bf16x8_t v; short4_t h[2]; } u;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = ks2 * 32 + jj * 16 + g * 4 + (i >> 2);
+    u.h[jj] = lds_tr16_b64(tile + (row * 8 + swz64(row, fq * 2 + ((i & 3) >> 1))) * 16 + (i & 1) * 8);
+  }
+  return u.v;
+}
+
+// dQ from the stored dS^T: block = 4 waves x 16 query rows = ONE query tile qt, key tiles kt = 0 .. qt. Per tile and wave: two B
+// fragments (this wave's 16 queries x 64 keys of dS^T, gathered the way the forward gathers V^T -- the tile is a [key][q] image and q
+// plays d's role) and 16 MFMAs against the K^T fragments. No softmax, no score recomputation: the kernel streams dS^T (64 flop / B),
+// so it is built for memory parallelism -- 48 KiB of LDS per block, three blocks (12 waves) per CU, every block one tile ahead.
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq5_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = TILE_BYTES + TILE_BYTES / 2;        // K tile 16 KiB + dS^T tile 8 KiB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nqt = (p.S + 63) / 64;
+  int qt, h, b;
+  if (!decode_block(nqt, p.H, p.B, qt, h, b)) return;
+  qt = nqt - 1 - qt;                               // heaviest first
+  const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
+  const int row_lim = seqlen < p.S ? seqlen : p.S;
+  const int q0 = qt * 64;
+  const int g = lane >> 4;
+  int myq[1];
+  bool padq[1];
+  const int grow0 = q0 + wave * 16;
+  myq[0] = grow0 + (lane & 15);
+  padq[0] = (myq[0] >= seqlen) || (myq[0] >= p.S);
+  int nkt = qt + 1;
+  const int kt_lim = (seqlen + 63) / 64;
+  if (nkt > kt_lim) nkt = kt_lim;
+  if (nkt <= 0 || q0 >= row_lim) {
+    dq_pad_block<1>(p, myq, b, h, lane);
+    return;
+  }
+  const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* ds_head = p.ds_ws + ds_tile_off(b * p.H + h, nqt * (nqt + 1) / 2, 0, qt);   // tiles (kt, qt), kt = 0 .. qt, are consecutive
+  int dsoff[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int pp = (wave * 2 + it) * 64 + lane;
+    const int row = pp >> 3, c = swz64(row, pp & 7);
+    dsoff[it] = (((row >> 4) * 4 + (c >> 1)) * 16 + (row & 15)) * 16 + (c & 1) * 8;
+  }
+  auto stage_ds = [&](int kt, char* tile) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) ATTN_GLDS(ds_head + (long long)kt * 4096 + dsoff[it], tile + (wave * 2 + it) * 1024);
+  };
+  f32x4_t dqt[1][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dqt[0][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  unsigned koff[4];
+  stage_offs<1>(p.ld, wave, lane, koff);
+  stage_rows64<1>(kb_, p.ld, 0, p.S, smem, wave, lane);
+  stage_ds(0, smem + TILE_BYTES);
+  const bool active = grow0 < row_lim;                   // wave-uniform: a row group of padding computes nothing
+  for (int kt = 0; kt < nkt; ++kt) {
+    ATTN_WAIT_VM0();
+    __syncthreads();
+    const char* kt_ = smem + (kt & 1) * STAGE;
+    const char* ds_ = kt_ + TILE_BYTES;
+    if (kt + 1 < nkt) {
+      char* nx = smem + ((kt + 1) & 1) * STAGE;
+      if ((kt + 2) * 64 <= p.S) stage_fast(kb_ + (long long)(kt + 1) * 64 * p.ld, koff, nx, wave);
+      else stage_rows64<1>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
+      stage_ds(kt + 1, nx + TILE_BYTES);
+    }
+    if (active) {
+      const bf16x8_t b0 = frag_tr64(ds_, wave, 0, lane), b1 = frag_tr64(ds_, wave, 1, lane);
+#pragma unroll
+      for (int fd = 0; fd < 8; ++fd) {
+        dqt[0][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<1>(kt_, fd, 0, lane), b0, dqt[0][fd], 0, 0, 0);
+        dqt[0][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<1>(kt_, fd, 1, lane), b1, dqt[0][fd], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue (the dK / dV kernel's, for one output): dq rows as 256 B, dq^T and then o^T as 128-B runs per channel row.
+  // Images: dq [64 q][128 ch] at 0 (8-B chunk index ^ (q & 15) << 1), dq^T / o^T [128 ch][64 q] at 16 KiB (chunk ^ ((ch >> 1) & 3) << 2).
   const bool tr = p.dqT != nullptr;
   const int pq = lane & 3;
+  const bool valid = myq[0] < p.S;
+  {
+    const float sc = padq[0] ? 0.f : p.scale;
+#pragma unroll
+    for (int fd = 0; fd < 8; ++fd) dqt[0][fd] *= sc;
+  }
+  if (p.rope_cos) rope_bwd_row(dqt[0], p.rope_cos, p.rope_sin, valid ? myq[0] : 0, g);
   __syncthreads();
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const bool valid = myq[rb] < p.S;
-    const float sc = padq[rb] ? 0.f : p.scale;
-#pragma unroll
-    for (int fd = 0; fd < 8; ++fd) dqt[rb][fd] *= sc;
-    if (p.rope_cos) rope_bwd_row(dqt[rb], p.rope_cos, p.rope_sin, valid ? myq[rb] : 0, g);
-    const int grp = row_group<RB>(wave, rb);
-    const int row = grp * 16 + (lane & 15);
+  {
+    const int row = wave * 16 + (lane & 15);
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
       u32x2_t w;
-      w[0] = valid ? pack2bf(dqt[rb][fd][0], dqt[rb][fd][1]) : 0u;
-      w[1] = valid ? pack2bf(dqt[rb][fd][2], dqt[rb][fd][3]) : 0u;
+      w[0] = valid ? pack2bf(dqt[0][fd][0], dqt[0][fd][1]) : 0u;
+      w[1] = valid ? pack2bf(dqt[0][fd][2], dqt[0][fd][3]) : 0u;
       *(u32x2_t*)(smem + row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8)) = w;
       if (tr) {
         const int c = fd * 16 + g * 4 + pq;
-        *(u32x2_t*)(smem + 32768 + c * 256 + (((grp * 4 + ((lane & 15) >> 2)) ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(w[0], w[1], lane);
+        *(u32x2_t*)(smem + 16384 + c * 128 + (((wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(w[0], w[1], lane);
       }
     }
   }
   __syncthreads();
-  constexpr int NT = 64 * NW;
   {
     const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
 #pragma unroll
-    for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
-      const int r = ps * (NT / 16) + (threadIdx.x >> 4);
+    for (int ps = 0; ps < 4; ++ps) {
+      const int r = ps * 16 + (threadIdx.x >> 4);
       if (q0 + r < p.S)
         *(u32x4_t*)(p.dq + ((long long)b * p.S + q0 + r) * p.ld + h * D + j * 8) =
             *(const u32x4_t*)(smem + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
     }
   }
   if (tr) {
-    const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3
+    const int j = threadIdx.x & 15;                       // 8-B chunk = queries q0 + 4 j .. + 3
     const bool jv = q0 + j * 4 < p.S;
     const long long tok = (long long)b * p.S + q0 + j * 4;
 #pragma unroll
-    for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
-      const int c = ps * (NT / 32) + (threadIdx.x >> 5);
-      if (jv) *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 32768 + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
+    for (int ps = 0; ps < 8; ++ps) {
+      const int c = ps * 16 + (threadIdx.x >> 4);
+      if (jv) *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 16384 + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
     }
     __syncthreads();
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
+    {   // o^T: O is re-read here (L2) for its transposed copy
+      const int chunk0 = wave * 4 + ((lane & 15) >> 2);
       bf16x8_t of[4];
-      load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
+      load_row_frags(p.o + ((long long)b * p.S + (valid ? myq[0] : p.S - 1)) * p.ld_o + h * D, lane, of);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         union { bf16x8_t v; uint32_t u[4]; } f;
@@ -677,20 +895,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int c = ks * 32 + g * 8 + half * 4 + pq;
-          *(u32x2_t*)(smem + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
+          *(u32x2_t*)(smem + 16384 + c * 128 + ((chunk0 ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
         }
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
-      const int c = ps * (NT / 32) + (threadIdx.x >> 5);
-      if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
+    for (int ps = 0; ps < 8; ++ps) {
+      const int c = ps * 16 + (threadIdx.x >> 4);
+      if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 16384 + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+template <bool STORE_DS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles + 2 x (64 lse + 64 delta) floats
   const int lane = threadIdx.x & 63;
@@ -721,6 +940,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   int qend = seqlen < p.S ? seqlen : p.S;
   const int nqt_end = (qend + 63) / 64;
   const int qt0 = kb;
+  const int ds_ntri = nkb * (nkb + 1) / 2;
   unsigned qoff[4], dooff[4];
   stage_offs<ASW>(p.ld, wave, lane, qoff);
   stage_offs<ASW>(p.ld_o, wave, lane, dooff);
@@ -782,6 +1002,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
     const bf16x8_t p0 = pack_frag(pr[0], pr[1]), p1 = pack_frag(pr[2], pr[3]);
     const bf16x8_t ds0 = pack_frag(s[0], s[1]), ds1 = pack_frag(s[2], s[3]);
+    if (STORE_DS) {   // hand dS^T (16 keys x 64 queries of this wave) to the one-product dQ kernel: 4 x 512 contiguous bytes
+      union { bf16x8_t v; u32x2_t h2[2]; } u0, u1;
+      u0.v = ds0;
+      u1.v = ds1;
+      bf16_t* tile = p.ds_ws + ds_tile_off(b * p.H + h, ds_ntri, kb, qt) + (lane & 15) * 16 + g * 4;
+      *(u32x2_t*)(tile + (wave * 4 + 0) * 256) = u0.h2[0];
+      *(u32x2_t*)(tile + (wave * 4 + 1) * 256) = u0.h2[1];
+      *(u32x2_t*)(tile + (wave * 4 + 2) * 256) = u1.h2[0];
+      *(u32x2_t*)(tile + (wave * 4 + 3) * 256) = u1.h2[1];
+    }
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
       dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(dot_, fd, 0, lane), p0, dvt[fd], 0, 0, 0);
@@ -888,7 +1118,8 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
 static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                          const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
                          int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
-                         const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, hipStream_t stream) {
+                         const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, hipStream_t stream,
+                         void* ws = nullptr, long long ws_bytes = 0) {
   const int nT = (dqT != nullptr) + (dkT != nullptr) + (dvT != nullptr) + (oT != nullptr);
   MLA_CHECK_ARG(nT == 0 || nT == 4, "mla_attn_bwd_t: dqT / dkT / dvT / oT must all be given or all be null");
   MLA_CHECK_ARG(nT == 0 || (S % 4 == 0 && ldt % 4 == 0 && ldt >= (long long)B * S && ((uintptr_t)dqT & 7) == 0 &&
@@ -910,15 +1141,32 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_RB, DQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
     attr = true;
   }
-  // delta = rowsum(O * dO) is computed by the dQ kernel's prologue (p.o set) and read by the dK / dV kernel launched behind it
   p.o = (bf16_t*)o;
+  if (ws) {
+    // 5-product form: delta pass -> dK / dV kernel (stores dS^T) -> one-product dQ kernel
+    const long long nqt = (S + 63) / 64, need = (long long)B * H * (nqt * (nqt + 1) / 2) * 8192;
+    MLA_CHECK_ARG(ws_bytes >= need && AL16(ws), "mla_attn_bwd_ws: workspace of %lld bytes needed (mla_attn_bwd_ws_bytes), got %lld", need, ws_bytes);
+    MLA_CHECK_ARG(ld_o % 8 == 0, "mla_attn_bwd_ws: ld_o must be a multiple of 8");
+    p.ds_ws = (bf16_t*)ws;
+    MLA_CHECK_ARG(H <= 64, "mla_attn_bwd_ws: at most 64 heads (got %d)", H);
+    static bool attr5 = false;
+    if (!attr5) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TILE_BYTES); attr5 = true; }
+    const long long tokens = (long long)B * S;
+    if (H <= 32) hipLaunchKernelGGL(attn_delta_kernel<8>, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta, B, S, H, ld_o);
+    else hipLaunchKernelGGL(attn_delta_kernel<16>, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta, B, S, H, ld_o);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dq5_kernel, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 3 * TILE_BYTES, stream, p);
+    MLA_LAUNCH_CHECK();
+  }
+  // delta = rowsum(O * dO) is computed by the dQ kernel's prologue (p.o set) and read by the dK / dV kernel launched behind it
   constexpr int BQ = 16 * DQ_NW * DQ_RB;
   static_assert(BQ == 128, "the transposed-output epilogue of the dQ kernel stages a 128-query image");
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DQ_RB, DQ_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * DQ_NW), 4 * TILE_BYTES, stream, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
   MLA_LAUNCH_CHECK();
 }
 extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
@@ -937,4 +1185,20 @@ extern "C" int mla_attn_bwd_t(const void* q, const void* k, const void* v, const
                               const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, hipStream_t stream) {
   return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
                        dqT, dkT, dvT, oT, ldt, stream);
+}
+
+// 5-product backward: same outputs as mla_attn_bwd_t (dqT / dkT / dvT / oT optional, all or none) with the
+// caller-owned workspace `ws` of mla_attn_bwd_ws_bytes(B, S, H) bytes carrying dS^T from the dK / dV kernel to the dQ kernel.
+extern "C" long long mla_attn_bwd_ws_bytes(int B, int S, int H) {
+  if (B <= 0 || S <= 0 || H <= 0) return -1;
+  const long long nqt = (S + 63) / 64;
+  return (long long)B * H * (nqt * (nqt + 1) / 2) * 8192;
+}
+extern "C" int mla_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                               const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim,
+                               long long ld_qkv, long long ld_o, float scale, const float* rope_cos, const float* rope_sin, void* dqT,
+                               void* dkT, void* dvT, void* oT, long long ldt, void* ws, long long ws_bytes, hipStream_t stream) {
+  MLA_CHECK_ARG(ws != nullptr, "mla_attn_bwd_ws: null workspace");
+  return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
+                       dqT, dkT, dvT, oT, ldt, stream, ws, ws_bytes);
 }

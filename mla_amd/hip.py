@@ -77,6 +77,10 @@ _SIGNATURES = {
     "mla_attn_bwd_t": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
+    "mla_attn_bwd_ws_bytes": [c_int, c_int, c_int],          # returns long long (restype fixed up in lib())
+    "mla_attn_bwd_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                        c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p],
     "mla_ce_fwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p],
     "mla_ce_bwd": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong, c_int, c_int,
                    c_longlong, c_void_p],
@@ -119,6 +123,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argt
             fn.restype = c_int
+        L.mla_attn_bwd_ws_bytes.restype = c_longlong
         _lib = L
     return _lib
 
@@ -512,11 +517,21 @@ def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale, rope_cos=None, rope_sin=None, transposed=None):
-    """rope_cos / rope_sin ([S, D/2] fp32): dq / dk come out with the RoPE backward already applied (no separate pass).
+# The five-product backward is OPT-IN (MLA_ATTN_BWD5=1): measured on MI355X it is not faster than the two-kernel, seven-product form
+# (S = 548: delta 81 + dK/dV 438 + dQ 262 us vs 419 + 352; S = 2048: 189 + 3420 + 1681 vs 3039 + 2218) -- MFMA work is cheap here
+# and the one-product dQ kernel is bound by streaming dS^T and re-streaming K through LDS.
+ATTN_BWD5 = os.environ.get("MLA_ATTN_BWD5", "0") == "1"
+
+
+def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale, rope_cos=None, rope_sin=None, transposed=None,
+             five: Optional[bool] = None):
+    """five (default: off, see ATTN_BWD5): the five-product form -- the dK / dV kernel hands dS^T (bf16 tiles in a torch-owned scratch
+    buffer) to a one-product dQ kernel instead of both kernels recomputing Q K^T and dO V^T (mla_attn_bwd_ws).
+    rope_cos / rope_sin ([S, D/2] fp32): dq / dk come out with the RoPE backward already applied (no separate pass).
     transposed = (dqkvT [3*H*D, ldt], oT [H*D, ldt]) bf16: also filled with the token-contiguous copies of dq|dk|dv and o (columns
     b*S + s; columns >= B*S are left alone) -- the wgrad operands, without transpose passes. Needs S % 4 == 0, ldt % 4 == 0."""
     delta = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    five = ATTN_BWD5 if five is None else five
     if rope_cos is not None:
         _req(rope_cos, torch.float32, "rope cos")
         _req(rope_sin, torch.float32, "rope sin")
@@ -527,6 +542,18 @@ def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, sca
         _req(oT, torch.bfloat16, "oT")
         ldt = dqkvT.stride(0)
         assert dqkvT.shape[0] == 3 * H * D and oT.shape[0] == H * D and oT.stride(0) == ldt and dqkvT.stride(1) == 1 and oT.stride(1) == 1
+    if five:
+        nbytes = int(lib().mla_attn_bwd_ws_bytes(B, S, H))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)           # transient: freed (to torch's pool) after the launches are queued
+        if transposed is not None:
+            tq, tk, tv, to_ = dqkvT[:H * D], dqkvT[H * D:2 * H * D], dqkvT[2 * H * D:], oT
+        else:
+            tq = tk = tv = to_ = None
+            ldt = 0
+        call("mla_attn_bwd_ws", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
+             H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(tq), _p(tk), _p(tv), _p(to_), ldt, _p(ws), nbytes)
+        return
+    if transposed is not None:
         call("mla_attn_bwd_t", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
              H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(dqkvT[:H * D]), _p(dqkvT[H * D:2 * H * D]),
              _p(dqkvT[2 * H * D:]), _p(oT), ldt)

@@ -375,6 +375,38 @@ def test_attention_bwd_transposed_outputs_are_bit_identical(dev, S, lens):
     assert bool((dT[:, T:] == marker).all()) and bool((oT[:, T:] == marker).all())
 
 
+@pytest.mark.parametrize("S,lens", [(548, None), (548, [548, 511, 100, 64]), (200, [200, 3, 65, 128]), (1024, None), (72, [72, 5])])
+def test_attention_bwd_five_product_form_matches_seven(dev, S, lens):
+    """mla_attn_bwd_ws (delta pass -> dK / dV kernel storing dS^T -> one-product dQ kernel) against the two-kernel, seven-product
+    backward on the same inputs, with the fused RoPE backward and the transposed copies: dk, dv (and their transposes, and o^T) come from
+    the same dK / dV kernel and must be bit-equal up to what a last-bit difference of delta (another summation order) does through
+    dS; dq goes through bf16 dS^T in both forms. Ragged lengths, padding-only blocks, S not a multiple of 64 or 128."""
+    from mla_amd import hip
+    B, H, D = (4 if lens else 3), 3, 128
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn(B * S, 3 * H * D, generator=g) * 0.5).to(BF).to(dev)
+    do = (torch.randn(B * S, H * D, generator=g) * 0.5).to(BF).to(dev)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    cos, sin = O.rope_tables(S, D)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, sl, D ** -0.5)
+    outs = {}
+    for five in (False, True):
+        dqkv = torch.full_like(qkv, float("nan"))
+        tr = (torch.full((3 * H * D, B * S), float("nan"), dtype=BF, device=dev), torch.full((H * D, B * S), float("nan"), dtype=BF, device=dev))
+        hip.attn_bwd(q, k, v, o, do, lse, sl, dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:], B, S, H, D, 3 * H * D, D ** -0.5,
+                     rope_cos=cos, rope_sin=sin, transposed=tr, five=five)
+        outs[five] = (dqkv, tr[0], tr[1])
+    for name, a, b in zip(("dqkv", "dqkvT", "oT"), outs[True], outs[False]):
+        assert torch.isfinite(a.float()).all(), name
+        assert fro_rel(a, b) < 2e-3, (name, fro_rel(a, b))
+        same = float((a == b).float().mean())
+        assert same > 0.97, (name, same)
+    assert torch.equal(outs[True][2], outs[False][2])                      # o^T: a copy either way
+    assert torch.equal(outs[True][1], outs[True][0].t().contiguous())      # the transposed copies are transposes of what was written
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 1088), (768, 512, 256), (4096 + 256 * 3, 4096, 640)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_gemm_sum_of_squares_partials(dev, M, N, K, accumulate):
