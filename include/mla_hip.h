@@ -51,6 +51,11 @@ int mla_gemm_bf16_ws(const void* A, const void* B, void* C, const void* R, const
  * weight gradient to the clipping norm (training/strategies/fsdp.py:308-310) without a second pass over the fp32 gradient buffer.
  * Fixed partial order, deterministic. Shapes of the 256x256 kernel only (M, N >= 256, K % 64 == 0, N % 8 == 0): error otherwise. */
 int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes);   /* partials the launch below writes; -1 = shape not supported */
+/* Main loop of the 256x256 kernel's k-contiguous instantiations (all fused forms included): 1 = hand-scheduled assembly (default; needs
+ * K % 128 == 0 and the whole-row epilogue, otherwise the launch uses the other one by itself), 0 = compiler-scheduled; any other value
+ * only queries. Returns the mode in force. Results are bit-identical either way -- the switch exists for A/B measurements and tests.
+ * Environment MLA_GEMM_KLOOP=0 sets the initial mode. */
+int mla_gemm_kloop(int mode);
 int mla_gemm_bf16_ws_sq(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
                         float alpha, float* workspace, size_t workspace_bytes, float* sq_out, int sq_capacity, int* sq_slots,
                         mla_stream_t stream);

@@ -22,6 +22,8 @@
 
 #include "gemm_args.h"
 
+#include "gemm256_kloop_clobbers.inc"
+
 namespace {
 
 constexpr int SLOT = 16384;
@@ -66,7 +68,7 @@ __device__ __forceinline__ const bf16_t* stage_src(const bf16_t* g, int ld, int 
 #ifndef MLA_GEMM256_UNTRACKED
 #define MLA_GEMM256_UNTRACKED 0   // 1: k-contiguous instantiations stage untracked too (A/B)
 #endif
-template <int AMODE, int BMODE, int EPI = 0>
+template <int AMODE, int BMODE, int EPI = 0, bool ASM = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const bool LGKM_BEFORE = false;
   const int GROUP_M = MLA_GROUP_M;
@@ -96,8 +98,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int u = blockIdx.x - p.sk_full;
     const int slice = u % p.sk_split;
     pid = p.sk_full + u / p.sk_split;
+    if ((nt & 1) == 0) {   // the assembly loop walks pairs of K-tiles: slice boundaries on even tiles (for both loops: same bits)
+      const int np = nt >> 1;
+      kt0 = 2 * (int)((long long)slice * np / p.sk_split);
+      nt = 2 * (int)((long long)(slice + 1) * np / p.sk_split) - kt0;
+    } else {
     kt0 = (int)((long long)slice * nt / p.sk_split);
     nt = (int)((long long)(slice + 1) * nt / p.sk_split) - kt0;
+    }
     part = p.sk_ws + (size_t)u * 65536;
   }
 #ifdef MLA_EXPERIMENTAL_KERNELS
@@ -121,6 +129,70 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   const int pid_n = (pid % in_group) / gsz;
   const int m0 = pid_m * 256, n0 = pid_n * 256;
 
+  f32x4_t acc[8][4];
+  if constexpr (ASM) {
+    // ---- hand-scheduled main loop (gemm256_kloop.inc, generated by tools/gen_gemm_asm.py; k-contiguous operands, an even number of
+    // K-tiles). Same LDS operand image, same K order and the same accumulation order per output as the compiler-scheduled loop below:
+    // bit-identical results. Three barriers per K-tile instead of eight, no vmcnt(0) in the loop, and the 8 loads of a wave spread over
+    // ~100 of its 128 MFMA gaps: the waves of a workgroup run in lockstep, so a burst of loads in one wave is a burst of eight times as
+    // many in the CU's single address path and stalls every issuer (round 3: MfmaUtil 65 % -> 84 % on the 4-wave form of this loop).
+    // The accumulators leave the assembly through LDS: the loop's tail writes the tile image the epilogues below read.
+    static_assert(AMODE == 0 && BMODE == 0, "the assembly loop takes k-contiguous operands");
+    const unsigned c0 = ((unsigned)lg ^ ((unsigned)li & 7u)) << 4;
+    const unsigned vA0 = (unsigned)((wr * 64 + li) * 128) + c0, vB0 = 32768u + (unsigned)((wc * 32 + li) * 128) + c0;
+    // staging: instruction q (0..3) of this wave writes LDS rows wave*32 + q*8 + (lane >> 3) of A and of B, lane's 16-B chunk pre-swizzled
+    const unsigned lchunk = ((unsigned)lane & 7u) ^ (((unsigned)lane >> 3) & 7u);
+    const int rt0 = wave * 32 + (lane >> 3);
+    const int lastA = (p.M - 1 - m0) < 255 ? (p.M - 1 - m0) : 255;
+    int lastB = (p.N - 1 - n0) < 255 ? (p.N - 1 - n0) : 255, bshift = 0;
+    const bf16_t* pB = p.B + (size_t)n0 * p.ldb + (size_t)kt0 * 64;
+    if (EPI == 1) {   // rows 0..127 of the B half-tiles = gate channels [128 pid_n, +128), rows 128..255 = the matching up channels
+      pB = p.B + (size_t)pid_n * 128 * p.ldb;
+      bshift = wave >= 4 ? p.sf_I - 128 : 0;
+      lastB = 255;
+    }
+    const unsigned oA0 = (unsigned)rt0 * (unsigned)p.lda * 2u + lchunk * 16u;
+    const unsigned oB0 = (unsigned)(rt0 + bshift) * (unsigned)p.ldb * 2u + lchunk * 16u;
+    const unsigned oAmax = (unsigned)lastA * (unsigned)p.lda * 2u + lchunk * 16u;
+    const unsigned oBmax = (unsigned)(lastB + bshift) * (unsigned)p.ldb * 2u + lchunk * 16u;
+    const int sA8 = p.lda * 16, sB8 = p.ldb * 16;
+    const bf16_t* pA = p.A + (size_t)m0 * p.lda + (size_t)kt0 * 64;
+    const int kmax = nt * 128 - 128, nit = nt >> 1, ldsw = wave * 4096;   // kmax, nit: VGPR operands (selects of uniform values)
+    const bool img_bf16 = !part && !p.out_fp32 && p.R == nullptr && p.bias == nullptr;     // uniform; mirrors the epilogue's choice below
+    const int emode = img_bf16 ? 0 : 1;       // (a VGPR operand: hipcc hands a select of uniform values to an "s" constraint in a VGPR)
+    const float alpha = part ? 1.f : p.alpha;
+    const unsigned vImg = img_bf16 ? (unsigned)((wr * 64 + li) * 512) + ((((unsigned)(wc * 4 + (lg >> 1))) ^ (unsigned)li) << 4) + (unsigned)(lg & 1) * 8u
+                                   : (unsigned)((wr * 64 + li) * 1024) + ((((unsigned)(wc * 8 + lg)) ^ (unsigned)li) << 4);
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass would validate the register names against x86
+    asm volatile(
+#include "gemm256_kloop.inc"
+        : : [pA] "s"(pA), [pB] "s"(pB), [kmax] "v"(kmax), [nit] "v"(nit), [ldsw] "s"(ldsw), [sA8] "s"(sA8), [sB8] "s"(sB8),
+            [emode] "v"(emode), [alpha] "v"(alpha), [vA0] "v"(vA0), [vB0] "v"(vB0), [oA0] "v"(oA0), [oB0] "v"(oB0), [oAmax] "v"(oAmax),
+            [oBmax] "v"(oBmax), [vImg] "v"(vImg)
+        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", G256K_CLOBBERS);
+#endif
+    if (part) {     // K-slice of a tail tile: the raw fp32 image leaves as whole rows of the tile-local [256][256] partial
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        if (hf) {
+          __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
+          asm volatile(
+#include "gemm256_kloop_half1.inc"
+              : : [alpha] "v"(alpha), [vImg] "v"(vImg) : "memory", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11",
+                "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19");
+#endif
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int row = wave * 16 + it;
+          *(f32x4_t*)(part + (hf * 128 + row) * 256 + lane * 4) = *(const f32x4_t*)(smem + row * 1024 + ((lane ^ (row & 63)) << 4));
+        }
+      }
+      return;
+    }
+  } else {
   // ---- staging pointers: [slot][it]; each advances one K-tile per use
   // dbg & 64: every K-tile re-loads K-tile 0 (always an L2 hit, no fabric traffic); timing / power experiments only
   const size_t stepA = (dbg & 64) ? 0 : (dbg & 2) ? 64 : (AMODE == 0 ? 64 : (size_t)64 * p.lda);
@@ -218,7 +290,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
   };
 
-  f32x4_t acc[8][4];
 #pragma unroll
   for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -302,9 +373,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef TILE_BODY
   if (wr == 0) __builtin_amdgcn_s_barrier();          // re-balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the dummy tail loads before the wave retires
+  }   // !ASM
 
   // ---- epilogue (operands were passed swapped: lane holds C[m][n..n+3])
-  if (part) {      // K-slice of a tail tile: raw accumulators, tile-local [256][256] fp32; the fix-up kernel finishes the job
+  if constexpr (!ASM) if (part) {      // K-slice of a tail tile: raw accumulators, tile-local [256][256] fp32; the fix-up kernel finishes the job
 #pragma unroll
     for (int ri = 0; ri < 8; ++ri) {
       const int ml = (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
@@ -329,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
   if (fast) {
     __syncthreads();     // every wave is done with the operand image (and has drained its own LDS-DMA loads above)
     if (!p.out_fp32 && p.R == nullptr && p.bias == nullptr) {
+      if constexpr (!ASM) {     // (the assembly loop's tail has written this image already)
 #pragma unroll
       for (int ri = 0; ri < 8; ++ri) {
         const int ml = (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
@@ -340,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
           o[1] = pack2bf(acc[ri][ci][2] * p.alpha, acc[ri][ci][3] * p.alpha);
           *(u32x2_t*)(smem + ml * 512 + ((((nl >> 3) ^ (ml & 31))) << 4) + ((nl >> 2) & 1) * 8) = o;
         }
+      }
       }
       __syncthreads();
       if (EPI == 1) {
@@ -531,6 +605,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       if (hf) __syncthreads();                     // the readers of the first half are done
+      if constexpr (ASM) {    // the first half was written by the loop's tail; the second is still in the accumulator registers, which
+                              // nothing between the two statements touches (build.sh checks the kernel's disassembly for that)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (hf) {
+          const unsigned vImg2 = (unsigned)((wr * 64 + li) * 1024) + ((((unsigned)(wc * 8 + lg)) ^ (unsigned)li) << 4);
+          asm volatile(
+#include "gemm256_kloop_half1.inc"
+              : : [alpha] "v"(p.alpha), [vImg] "v"(vImg2) : "memory", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10",
+                "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19");
+        }
+#endif
+      } else {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int ri = hf * 4 + r4;
@@ -540,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
           const int nl = (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
           *(f32x4_t*)(smem + ml * 1024 + (((nl >> 2) ^ (ml & 63)) << 4)) = acc[ri][ci] * p.alpha;
         }
+      }
       }
       __syncthreads();
       if (p.out_fp32) {
@@ -608,6 +695,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
     return;
   }
+  if constexpr (!ASM) {  // (the dispatcher gives the assembly-loop instantiations fast-epilogue launches only)
 #pragma unroll
   for (int ri = 0; ri < 8; ++ri) {
     const int m = m0 + (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
@@ -654,6 +742,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         }
       }
     }
+  }
   }
 #undef STAGE
 #undef READ_A
@@ -1034,6 +1123,27 @@ inline int choose_split(int tiles, int ncu, int nt, size_t ws_bytes, int* full_o
   return best;
 }
 
+// Main loop of the k-contiguous instantiations: 1 = hand-scheduled assembly (default), 0 = compiler-scheduled. Both give the same bits;
+// MLA_GEMM_KLOOP=0 in the environment or mla_gemm_kloop(0) select the compiler's (A/B measurements, tests).
+int g_kloop = -1;
+int kloop_mode() {
+  if (g_kloop < 0) {
+    const char* e = getenv("MLA_GEMM_KLOOP");
+    g_kloop = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_kloop;
+}
+
+template <int EPI>
+void launch_asm(const GemmArgs& p, dim3 grid, size_t lds, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<0, 0, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<0, 0, EPI, true>), grid, dim3(512), lds, stream, p);
+}
+
 template <int AM, int BM_>
 int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
   if constexpr (AM != 0 || BM_ != 0) {   // reduction-major operands: the plain one-tile-per-workgroup launch only
@@ -1063,6 +1173,28 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
     attr_set = true;
   }
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
+  // hand-scheduled main loop (template parameter ASM): an even number of K-tiles and the whole-row epilogue
+  const bool fast = (p.N & 7) == 0 && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
+                    (p.R == nullptr || ((p.ldr & 7) == 0 && (((uintptr_t)p.R) & 15) == 0)) && (p.bias == nullptr || (((uintptr_t)p.bias) & 15) == 0);
+  if (kloop_mode() && (p.K % 128) == 0 && fast && persistent_grid <= 0) {
+    if (p.sk_split > 1) {
+      const int tail = num_m * num_n - p.sk_full;
+      launch_asm<0>(p, dim3(p.sk_full + tail * p.sk_split), 2 * BUF, stream);
+      hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
+    } else if (p.sw_gu) {
+      launch_asm<2>(p, dim3(num_m * num_n), 2 * BUF + 32768, stream);
+    } else if (p.sf_I) {
+      launch_asm<1>(p, dim3(num_m * num_n), 2 * BUF, stream);
+    } else {
+      launch_asm<0>(p, dim3(num_m * num_n), 2 * BUF, stream);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      mla_set_error("gemm256 launch failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    return 0;
+  }
 #ifdef MLA_EXPERIMENTAL_KERNELS
   if (AM == 0 && BM_ == 0 && persistent_grid > 0) {
     static bool attr_p = false;
@@ -1107,6 +1239,13 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
 }  // namespace
 
 int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_bytes, hipStream_t stream, int* sq_slots = nullptr);
+
+// Selects the main loop of gemm256's k-contiguous instantiations: 1 = hand-scheduled assembly (default), 0 = compiler-scheduled, any other
+// value only queries. Returns the mode in force afterwards. Results do not depend on it (same accumulation order); it exists for A/B runs.
+extern "C" int mla_gemm_kloop(int mode) {
+  if (mode == 0 || mode == 1) g_kloop = mode;
+  return kloop_mode();
+}
 
 // Fused QKV projection + rotary embedding: C[M, N] = A[M, K] B[N, K]^T (bf16), columns [0, rope_cols) rotated per head of 128 with
 // position = row % S. Replaces hip.gemm + mla_rope_inplace on the packed q|k|v buffer (LlamaAttention.forward :351-361).

@@ -39,6 +39,7 @@ _SIGNATURES = {
                             c_void_p, c_int, c_void_p, c_void_p],
     "mla_sum_partials": [c_void_p, c_int, c_void_p, c_int, c_void_p],
     "mla_gemm_sq_slots": [c_int, c_int, c_int, c_size_t],
+    "mla_gemm_kloop": [c_int],
     "mla_gemm_gateup_swiglu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
                                c_void_p],
     "mla_gemm_dact_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
@@ -221,6 +222,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *
         ev1.record()
         prof.append((ev0, ev1, 2.0 * M * N * K, (a_mode, b_mode, M, N, K)))
     return out
+
+
+def gemm_kloop(mode: int = -1) -> int:
+    """Selects (0 / 1) or queries (-1) the main loop of the 256x256 GEMM's k-contiguous instantiations: 1 = hand-scheduled assembly
+    (default), 0 = compiler-scheduled. Same bits either way; for A/B measurements and tests."""
+    return int(lib().mla_gemm_kloop(int(mode)))
 
 
 def gemm_sq_slots(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> int:

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import fro_rel, max_rel
+from conftest import fro_rel, max_rel, poison_free_memory
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -705,3 +705,62 @@ def test_gemm256_persistent_walk_is_bit_identical(dev, M, N, K):
         assert torch.equal(hip.gemm(av, bv, force_generic=P), hip.gemm(av, bv, force_generic=O))
     ref = a[:512].float() @ b[:640].float().t()
     assert fro_rel(hip.gemm(a, b, force_generic=P)[:512, :640], ref.cpu()) < 4e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (1096, 768, 128), (17536, 4096, 1024), (2200, 7424, 2048), (4352, 4104, 384)])
+def test_gemm256_assembly_main_loop_is_bit_identical(dev, M, N, K):
+    """The hand-scheduled main loop of gemm256's k-contiguous instantiations (gemm256_kloop.inc: three barriers per K-tile, loads spread
+    over the tile, accumulators handed to the epilogue through the LDS tile image) against the compiler-scheduled loop, bit for bit, on
+    every epilogue: bf16, fp32 (+ accumulate, + sum-of-squares partials), bias + residual + alpha, the split-K tail (slices + fix-up),
+    fused RoPE, fused SwiGLU forward / backward. Shapes: ragged M (rows beyond M are clamped loads), N % 256 != 0, two K-tiles."""
+    from mla_amd import hip
+    assert hip.gemm_kloop(-1) in (0, 1)
+    a, b = bfr(M, K, seed=71).to(dev), bfr(N, K, seed=72, scale=0.1).to(dev)
+    bias, res = bfr(N, seed=73).to(dev), bfr(M, N, seed=74).to(dev)
+    base = (torch.randn(M, N, generator=torch.Generator().manual_seed(75)) * 0.1).to(dev)
+    S = 137
+    cos, sin = (torch.randn(S, 64, generator=torch.Generator().manual_seed(76 + i)).to(dev) for i in range(2))
+    I = (N // 256) * 128
+    wgu = bfr(2 * I, K, seed=77, scale=0.1).to(dev)
+    gu_in = bfr(M - M % 8, 2 * I, seed=78).to(dev)
+
+    def run():
+        poison_free_memory()          # the outputs below come from torch.empty inside the wrappers
+        out = {}
+        out["bf16"] = hip.gemm(a, b)
+        out["bf16_nosplit"] = hip.gemm(a, b, force_generic=3)
+        out["f32"] = hip.gemm(a, b, out_dtype=torch.float32)
+        out["epi"] = hip.gemm(a, b, bias=bias, residual=res, alpha=0.5)
+        acc = base.clone()
+        hip.gemm(a, b, out=acc, accumulate=True, alpha=0.25)
+        out["acc"] = acc
+        if N % 8 == 0:
+            acc2 = base.clone()
+            r = hip.gemm_sq(a, b, acc2, True)
+            assert r is not None
+            out["sq_out"], out["sq_part"] = acc2, r[0][:r[1]].clone()
+        if N % 256 == 0:
+            o = torch.empty((M, N), dtype=BF, device=dev)
+            assert hip.gemm_qkv_rope(a, b, o, cos, sin, S, 256 * (N // 256 - 1) if N >= 512 else 256)
+            out["rope"] = o
+        r = hip.gemm_gateup_swiglu(a[:M - M % 8], wgu, True)
+        assert r is not None
+        out["gu"], out["act"], out["actT"] = r
+        r = hip.gemm_dact_swiglu_bwd(a[:M - M % 8], wgu[:I], gu_in)
+        assert r is not None
+        out["dgu"], out["dguT"] = r
+        return out
+
+    prev = hip.gemm_kloop(-1)
+    try:
+        assert hip.gemm_kloop(1) == 1
+        asm = run()
+        assert hip.gemm_kloop(0) == 0
+        ref = run()
+    finally:
+        hip.gemm_kloop(prev)
+    for k in ref:
+        assert torch.equal(asm[k], ref[k]), (k, float((asm[k].float() - ref[k].float()).abs().max()))
+    want = a.float().cpu() @ b.float().cpu().t()
+    assert fro_rel(asm["f32"], want) < 1e-5 if K <= 256 else fro_rel(asm["f32"], want) < 1e-4

@@ -80,6 +80,10 @@ class Cfg:
         return bundles
 
     def mfma_order(self):
+        if "rowmaj" in self.flags:      # src0 fixed for FI consecutive MFMAs (the order hipBLASLt's hand-written kernel uses)
+            return [(i, j) for j in range(self.FJ) for i in range(self.FI)]
+        if "colmaj" in self.flags:      # src1 fixed for FJ consecutive MFMAs
+            return [(i, j) for i in range(self.FI) for j in range(self.FJ)]
         order = []
         for ib in range(0, self.FI, 2):
             for jb in range(0, self.FJ, 2):
@@ -196,7 +200,10 @@ class CfgK64(Cfg):
 
     def ds_read(self, dst, is_b, tset, ks, idx):
         reg = self.vbase + (4 if is_b else 0) + 2 * ks + tset
-        return f"ds_read_b128 {dst}, v{reg} offset:{idx * 2048}"
+        off = idx * 2048
+        if "map256" in self.flags:      # gemm256's wave -> sub-tile map: A fragments at rows (i>>2)*128 + wr*64 + (i&3)*16, B at (j>>1)*128 + wc*32 + (j&1)*16
+            off = ((idx >> 1) * 16384 + (idx & 1) * 2048) if is_b else ((idx >> 2) * 16384 + (idx & 3) * 2048)
+        return f"ds_read_b128 {dst}, v{reg} offset:{off}"
 
     def reads_for(self, tset, ks, buf):
         a = [self.ds_read(self.afrag(buf, x), False, tset, ks, x) for x in range(self.FI)]
@@ -370,10 +377,117 @@ class CfgK64(Cfg):
         lines += [f"; ---- tile set {tset}, k-step 1 (pgr2)"] + self.mfmas(1, aux)
         return lines
 
+
+    def tile_hbl(self, tset):
+        """One K-tile in the shape hipBLASLt's hand-written 4-wave kernel shows (round 3, disassembly of its MT256x256x64 custom kernel):
+        never more than TWO non-MFMA instructions between two MFMAs (a 16x16x32 MFMA occupies the matrix pipe for 16 cycles and the only
+        wave of the SIMD issues one instruction per 4: anything beyond two pushes the next MFMA back), no vmcnt(0), three barriers:
+          k-step 0 (MFMA buf0): read A(t, ks1) -> buf1 | lgkmcnt(0), BARRIER 1: every wave has read all of A(t) | pointer update, 8 x
+                                load A(t+2) into this set (m0 for the next load is written AFTER each load: no hazard nop) interleaved
+                                with the reads of B(t, ks1) | lgkmcnt(0), BARRIER 2 | 8 x load B(t+2)
+          k-step 1 (MFMA buf1): vmcnt(16) (= tile t+1 has landed: the 16 loads of t+2 are the only ones allowed in flight), BARRIER 3 |
+                                read (t+1, ks0) -> buf0, one per gap | lgkmcnt(0) in front of the last MFMA
+        Every load is issued >= 165 MFMAs (1.3 tiles) before the wait that covers it."""
+        nm = self.FI * self.FJ
+        NL = self.NLOAD
+        va, vb = self.vbase + 8, self.vbase + 8 + NL
+        ra1 = [self.ds_read(self.afrag(1, x), False, tset, 1, x) for x in range(self.FI)]
+        rb1 = [self.ds_read(self.bfrag(1, x), True, tset, 1, x) for x in range(self.FJ)]
+        ra0 = [self.ds_read(self.afrag(0, x), False, tset ^ 1, 0, x) for x in range(self.FI)]
+        rb0 = [self.ds_read(self.bfrag(0, x), True, tset ^ 1, 0, x) for x in range(self.FJ)]
+        ptr = ["s_min_u32 s52, s44, s45", "s_add_u32 s48, s40, s52", "s_addc_u32 s49, s41, 0", "s_add_u32 s50, s42, s52",
+               "s_addc_u32 s51, s43, 0", "s_add_u32 s44, s44, 128"]
+        bar = [] if "nobarrier" in self.flags else ["s_barrier"]
+
+        def put(aux, gap, *ins):
+            if "noglds" in self.flags:      # timing only
+                ins = ["s_nop 0" if x.startswith("global_load_lds") else x for x in ins]
+            if "noreads" in self.flags:     # timing only
+                ins = ["s_nop 0" if x.startswith("ds_read") else x for x in ins]
+            aux.setdefault(gap, []).extend(ins)
+            assert len(aux[gap]) <= 2, (gap, aux[gap])
+
+        # ---- k-step 0. Gap positions are derived from nm (MFMAs per k-step) so that the 4-wave (nm 64, 8 + 8 reads, 16 loads) and the
+        # 8-wave (nm 32, 8 + 4 reads, 8 loads) configurations share the schedule; for 4 waves they are the hand-placed ones of the
+        # first version (reads 0..14, pointer update 15..19, barrier 1 at 21, loads from 22, barrier 2 at 43, barrier 3 at 94/95).
+        aux = {}
+        dense = 2 * self.FI >= nm // 2                            # 8 waves: one read per gap (a gap is 32 wall cycles with 2 waves/SIMD)
+        rstep, lat = (1, 3) if dense else (2, 6)
+        for k, r in enumerate(ra1):
+            put(aux, rstep * k, r)
+        last = rstep * (self.FI - 1)
+        put(aux, last + 1, ptr[0], ptr[1])
+        put(aux, last + (2 if dense else 3), ptr[2], ptr[3])
+        put(aux, last + (3 if dense else 5), ptr[4], ptr[5])
+        L1 = last + (4 if dense else 6)
+        put(aux, L1, "s_waitcnt lgkmcnt(0)")
+        bar1, bar2, bar3 = ([] if f"nb{k}" in self.flags else bar for k in (1, 2, 3))     # timing only: drop one of the barriers
+        put(aux, L1 + 1, *bar1, f"s_add_i32 m0, s47, {tset * 65536}")
+        g = L1 + 2
+        # load stride in MFMA gaps ("ls<S>", default 2 = back to back behind barriers 1 / 2). The four waves of the workgroup run in
+        # lockstep (every barrier re-aligns them), so a cluster of loads in one wave is a cluster of 4x as many in the CU's one
+        # address path: 16 loads in 36 gaps stall the issuers (MfmaUtil 65 % with the barriers, 83 % without ANY barrier, 84 % with
+        # barriers but without the loads -- round 3 timing variants). hipBLASLt spreads its 16 loads over ~100 of the 128 gaps.
+        S = max([int(f[2:]) for f in self.flags if f.startswith("ls") and f[2:].isdigit()] or [0])
+        nrb = self.FJ
+        g2 = g + 2 * nrb + (4 if not dense else 2)                # lgkmcnt(0) for the B(ks1) reads
+        if S:
+            pos = [g + q * S for q in range(2 * NL)]
+            assert pos[NL] >= g2 + 2 and pos[-1] < 2 * nm - 4, (pos, g2)
+        else:
+            pos = [g + 2 * q for q in range(NL)] + [g2 + 2 + 2 * q for q in range(NL)]
+        m0_of = lambda q: tset * 65536 + (q * 1024 if q < NL else 32768 + (q - NL) * 1024)
+        load_at = {}
+        for q in range(2 * NL):
+            ins = [f"global_load_lds_dwordx4 v{va + q if q < NL else vb + q - NL}, s[{'48:49' if q < NL else '50:51'}]"]
+            if q + 1 < 2 * NL:
+                ins.append(f"s_add_i32 m0, s47, {m0_of(q + 1)}")
+            load_at[pos[q]] = ins
+        for gp, ins in load_at.items():
+            if gp < nm:
+                put(aux, gp, *ins)
+        free = [x for x in range(g + 1, g2 - (lat - 2)) if x not in load_at]
+        assert len(free) >= nrb, (free, nrb)
+        for q in range(nrb):                                       # B(ks1) reads in the gaps between the A loads
+            put(aux, free[(q * len(free)) // nrb], rb1[q])
+        put(aux, g2, "s_waitcnt lgkmcnt(0)")
+        put(aux, g2 + 1, *bar2)
+        assert max(aux) < nm, (max(aux), nm)
+        lines = [f"; ---- tile set {tset}, k-step 0 (hbl)"] + self.mfmas(0, aux)
+        # ---- k-step 1
+        aux = {}
+        w = nm // 2 - 2
+        while (nm + w) in load_at or (nm + w + 1) in load_at:
+            w += 1
+        issued = sum(1 for gp in load_at if gp < nm + w)           # loads of THIS iteration already issued at the wait
+        put(aux, w, f"s_waitcnt vmcnt({issued})")
+        put(aux, w + 1, *bar3)
+        for gp, ins in load_at.items():
+            if gp >= nm:
+                put(aux, gp - nm, *ins)
+        rd = []
+        a, b = list(ra0), list(rb0)
+        while a or b:
+            if a:
+                rd.append(a.pop(0))
+            if b:
+                rd.append(b.pop(0))
+            if a and len(a) > len(b):
+                rd.append(a.pop(0))
+        free = [x for x in range(w + 2, nm - 2) if (x + nm) not in load_at]
+        assert len(free) >= len(rd), (len(free), len(rd))
+        for k, r in enumerate(rd):
+            put(aux, free[(k * len(free)) // len(rd)], r)
+        put(aux, nm - 2, "s_waitcnt lgkmcnt(0)")
+        assert max(aux) < nm, (max(aux), nm)
+        lines += [f"; ---- tile set {tset}, k-step 1 (hbl)"] + self.mfmas(1, aux)
+        return lines
+
     def prologue(self):
         vb = self.vbase
-        lines = ["; ---- prologue", "s_mov_b64 s[40:41], %[pA]", "s_mov_b64 s[42:43], %[pB]", "s_mov_b32 s44, 0", "s_mov_b32 s45, %[kmax]",
-                 "s_mov_b32 s46, %[nit]", "s_mov_b32 s47, %[ldsw]",
+        knit = (["v_readfirstlane_b32 s45, %[kmax]", "v_readfirstlane_b32 s46, %[nit]"] if "tail256" in self.flags      # VGPR operands, see gemm256.hip
+                else ["s_mov_b32 s45, %[kmax]", "s_mov_b32 s46, %[nit]"])
+        lines = ["; ---- prologue", "s_mov_b64 s[40:41], %[pA]", "s_mov_b64 s[42:43], %[pB]", "s_mov_b32 s44, 0"] + knit + ["s_mov_b32 s47, %[ldsw]",
                  f"v_mov_b32 v{vb}, %[vA0]", f"v_add_u32 v{vb + 1}, 0x10000, v{vb}", f"v_xor_b32 v{vb + 2}, 64, v{vb}",
                  f"v_add_u32 v{vb + 3}, 0x10000, v{vb + 2}",
                  f"v_mov_b32 v{vb + 4}, %[vB0]", f"v_add_u32 v{vb + 5}, 0x10000, v{vb + 4}", f"v_xor_b32 v{vb + 6}, 64, v{vb + 4}",
@@ -397,10 +511,66 @@ class CfgK64(Cfg):
         return lines
 
     def body(self, two_schedules=False):
-        tile = self.tile_pgr2 if "pgr2" in self.flags else self.tile
-        out = self.prologue() + ["1:"] + tile(0) + tile(1)
+        tile = self.tile_hbl if "hbl" in self.flags else self.tile_pgr2 if "pgr2" in self.flags else self.tile
+        # code placement of a hand-written stream (MI355X_MICROARCH: a uniform shift = 4 mod 8 bytes costs up to 13 %): "align" puts the
+        # loop head on a 256-B boundary, "align4" 4 bytes behind one
+        head = [".p2align 8"] if "align" in self.flags else [".p2align 8", "s_nop 0"] if "align4" in self.flags else []
+        if "hbl" in self.flags:
+            head = ["s_waitcnt lgkmcnt(0)"] + head           # the other schedules wait at the top of every k-step 0
+        out = self.prologue() + head + ["1:"] + tile(0) + tile(1)
         out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 1b"]
+        if "tail256" in self.flags:
+            return out + self.tail256()
         return out + ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7", "s_nop 7"]
+
+    # ---- gemm256 product loop: the accumulators leave the assembly through LDS, never through registers the compiler also allocates.
+    # After the last K-tile the operand ring is dead, so the tile image the C++ epilogues read (gemm256.hip "fast epilogue") is written
+    # right here: emode 0 = bf16 image [256][256] (row pitch 512 B, 16-B chunk ^ (row & 31)), emode 1 = fp32 image of accumulator rows
+    # ri = 0..3 ([128][256], row pitch 1 KiB, chunk ^ (row & 63)); the second half (ri = 4..7) is written by the separate statement
+    # image_f32(1) after the C++ side has consumed the first. %[vImg] = the lane's address of fragment (0, 0) in the image of the mode.
+    def image_bf16(self):
+        ln = ["; ---- bf16 tile image", "v_mov_b32 v0, %[vImg]", "v_xor_b32 v1, 32, v0", "v_add_u32 v2, 0x10000, v0", "v_add_u32 v3, 0x10000, v1"]
+        k = 0
+        for ri in range(self.FI):
+            for ci in range(self.FJ):
+                t = 4 + 4 * (k % 4)
+                k += 1
+                a = (ri * self.FJ + ci) * 4
+                base = (ci & 1) + 2 * (ri >> 2)
+                off = (ri & 3) * 16 * 512 + (((ci >> 1) ^ (ri & 1)) << 8)
+                ln += [f"v_accvgpr_read_b32 v{t + r}, a{a + r}" for r in range(4)]
+                ln += [f"v_mul_f32 v{t + r}, %[alpha], v{t + r}" for r in range(4)]
+                ln += [f"v_cvt_pk_bf16_f32 v{t}, v{t}, v{t + 1}", f"v_cvt_pk_bf16_f32 v{t + 1}, v{t + 2}, v{t + 3}",
+                       f"ds_write_b64 v{base}, v[{t}:{t + 1}] offset:{off}"]
+        return ln
+
+    def image_f32(self, half):
+        ln = [f"; ---- fp32 image of accumulator rows {4 * half}..{4 * half + 3}", "v_mov_b32 v0, %[vImg]", "v_xor_b32 v1, 64, v0",
+              "v_xor_b32 v2, 0x100, v0", "v_xor_b32 v3, 0x100, v1"]
+        k = 0
+        for r4 in range(4):
+            for ci in range(self.FJ):
+                t = 4 + 4 * (k % 4)
+                k += 1
+                a = ((4 * half + r4) * self.FJ + ci) * 4
+                base = (ci & 1) + 2 * (r4 & 1)
+                off = r4 * 16384 + (((ci >> 1) ^ (r4 >> 1)) << 9)
+                ln += [f"v_accvgpr_read_b32 v{t + r}, a{a + r}" for r in range(4)]
+                ln += [f"v_mul_f32 v{t + r}, %[alpha], v{t + r}" for r in range(4)]
+                ln += [f"ds_write_b128 v{base}, v[{t}:{t + 3}] offset:{off}"]
+        return ln
+
+    def tail256(self):
+        assert (self.FI, self.FJ) == (8, 4)
+        return (["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_barrier", "v_readfirstlane_b32 s53, %[emode]", "s_cmp_eq_u32 s53, 0",
+                 "s_cbranch_scc0 2f"]
+                + self.image_bf16() + ["s_branch 3f", "2:"] + self.image_f32(0) + ["3:", "s_waitcnt lgkmcnt(0)"])
+
+    def emit_lines(self, fname, lines):
+        with open(os.path.join(CSRC, fname), "w") as f:
+            f.write("// generated by tools/gen_gemm_asm.py -- do not edit\n")
+            for ln in lines:
+                f.write('"' + ln + '\\n"\n')
 
 
 VARIANTS = {1: {"noglds"}, 2: {"noreads"}, 3: {"noglds", "noreads"}, 4: {"nobarrier"}, 5: {"noprio"}, 6: {"noglds", "noreads", "nobarrier"}}
@@ -412,6 +582,13 @@ def main():
     c.emit_clobbers("gemm_asm_8w_clobbers.inc", "G8W_CLOBBERS")
     print(f"8w/k64: {n} lines, {c.nvgpr} VGPRs + {c.nacc} AGPRs")
     # 4 waves = 2 x 2, 128 x 128 per wave (8 x 8 fragments in a[0:255], two 64-VGPR fragment buffers), one wave per SIMD: -25 % LDS
+    # PRODUCT main loop of gemm256's k-contiguous instantiations (gemm256.hip, template parameter ASM): the 8-wave loop with gemm256's
+    # sub-tile map, the three-barrier / spread-load schedule, and the tile image written from the assembly
+    ck = CfgK64("8w", 8, 4, 4, {"hbl", "noprio", "ls6", "map256", "tail256"})
+    nk = ck.emit("gemm256_kloop.inc")
+    ck.emit_lines("gemm256_kloop_half1.inc", ck.image_f32(1) + ["s_waitcnt lgkmcnt(0)"])
+    ck.emit_clobbers("gemm256_kloop_clobbers.inc", "G256K_CLOBBERS")
+    print(f"gemm256 k-loop: {nk} lines")
     # traffic per K-tile; every wave stages 64 rows of A and of B (8 + 8 loads per tile)
     c4 = CfgK64("4w", 8, 8, 8, set(os.environ.get("GEN4W_FLAGS", "spread").split(",")))      # GEN4W_FLAGS: timing experiments
     n4 = c4.emit("gemm_asm_4w_loop.inc")

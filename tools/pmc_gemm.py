@@ -12,7 +12,9 @@ M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (16384, 4096
 a = torch.randn((M, K), device=dev).to(torch.bfloat16)
 b = torch.randn((N, K), device=dev).to(torch.bfloat16)
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+FG = [int(v) for v in os.environ.get("PMC_GEMM_FG", "0").split(",")]      # force_generic values to run (4 / 5: assembly kernels, experiment build)
 for _ in range(4):
-    hip.gemm(a, b, out=out)
+    for fg in FG:
+        hip.gemm(a, b, out=out, force_generic=fg)
     torch.matmul(a, b.t(), out=out)
 torch.cuda.synchronize()

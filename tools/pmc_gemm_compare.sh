@@ -1,7 +1,8 @@
 # gemm256 vs hipBLASLt (torch.matmul) on the same shapes under the same counters: where does the library kernel's edge come from?
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for shape in "16384 4096 4096" "17536 4096 4096" "4096 11008 17536" "17536 12288 4096"; do
+if [ -n "$ONE" ]; then set -- "$ONE"; else set -- "16384 4096 4096" "17536 4096 4096" "4096 11008 17536" "17536 12288 4096"; fi
+for shape in "$@"; do
   rm -rf /tmp/pg1 /tmp/pg2
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pg1 -o p -- python $R/tools/pmc_gemm.py $shape > /dev/null 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d /tmp/pg2 -o p -- python $R/tools/pmc_gemm.py $shape > /dev/null 2>&1
@@ -14,7 +15,7 @@ def load(d):
     per = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        fam = "gemm256" if "gemm256_kernel" in n else ("hipBLASLt " + re.sub(r"^.*?(MT\d+x\d+x\d+).*$", r"\1", n)[:20] if "Cijk" in n else None)
+        fam = "gemm256" if "gemm256_kernel" in n else "asm8w" if "gemm_asm_kernel" in n or "gemm8w" in n else "asm4w" if "gemm4w" in n else ("hipBLASLt " + re.sub(r"^.*?(MT\d+x\d+x\d+).*$", r"\1", n)[:20] if "Cijk" in n else None)
         if fam is None: continue
         d_ = per[fam][r["Dispatch_Id"]]
         v = float(r["Counter_Value"]); s, m = d_.get(r["Counter_Name"], (0.0, 0.0)); d_[r["Counter_Name"]] = (s + v, max(m, v))
