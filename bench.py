@@ -284,7 +284,7 @@ def main():
             traffic = None
             tprov = None
             hit = None
-            for tname in ("r3_gemm256_hbm_traffic.json", "r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
+            for tname in ("r3b_gemm256_hbm_traffic.json", "r3_gemm256_hbm_traffic.json", "r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and args.config == 1 and not args.tiny:
                     with open(tpath) as fh:
@@ -314,6 +314,7 @@ def main():
             ach_fused = (sum(fl for _, fl in fused) / (sum(t for t, _ in fused) * 1e-3) / 1e12) if fused else None
             abytes = sum(2.0 * (k[2] * k[4] + k[3] * k[4]) + 2.0 * k[2] * k[3] for _, _, k in big) / len(big)
             roof = {"bound": "mfma", "kernel": "gemm256_kernel<0,0,0> (+ gemm128_kernel for small shapes): bf16 MFMA GEMM launches >= 0.1 TFLOP",
+                    "main_loop": ("hand-scheduled assembly (gemm256_kloop.inc)" if hip.gemm_kloop(-1) == 1 else "compiler-scheduled (MLA_GEMM_KLOOP=0)"),
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "fused_swiglu_epilogue_kernels": ({"kernel": "gemm256_kernel<0,0,1> (gate|up + SwiGLU) and <0,0,2> (d(act) + SwiGLU backward): GEMM flops "
                                                                  "over a duration that also contains the HBM-bound SwiGLU pass",

@@ -456,7 +456,7 @@ class CfgK64(Cfg):
         lines = [f"; ---- tile set {tset}, k-step 0 (hbl)"] + self.mfmas(0, aux)
         # ---- k-step 1
         aux = {}
-        w = nm // 2 - 2
+        w = max([int(f[2:]) for f in self.flags if f.startswith("wb") and f[2:].isdigit()] or [nm // 2 - 2])     # "wb<N>": gap of barrier 3
         while (nm + w) in load_at or (nm + w + 1) in load_at:
             w += 1
         issued = sum(1 for gp in load_at if gp < nm + w)           # loads of THIS iteration already issued at the wait

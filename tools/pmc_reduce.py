@@ -6,7 +6,7 @@ Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is in KiB and reports
 WRITE_SIZE x 1024 (uncalibrated). Both are fabric-side (L2 <-> Infinity Cache / HBM) counters: Infinity-Cache hits are included."""
 import csv, json, re, sys, datetime
 
-PLAIN = r"gemm256_kernel<0, ?0, ?0>"     # the plain instantiation only: the population bench.py's algorithmic_bytes_per_launch is over
+PLAIN = r"gemm256_kernel<0, ?0, ?0(, ?(true|false))?>"     # the plain instantiation only: the population bench.py's algorithmic_bytes_per_launch is over
 
 
 def load(path, counter, min_us):
