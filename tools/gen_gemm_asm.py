@@ -577,7 +577,7 @@ VARIANTS = {1: {"noglds"}, 2: {"noreads"}, 3: {"noglds", "noreads"}, 4: {"nobarr
 
 
 def main():
-    c = CfgK64("8w", 8, 4, 4, set(os.environ.get("GEN8W_FLAGS", "loadsfirst").split(",")))    # GEN8W_FLAGS: schedule experiments
+    c = CfgK64("8w", 8, 4, 4, set(os.environ.get("GEN8W_FLAGS", "hbl,noprio,ls6").split(",")))    # GEN8W_FLAGS: schedule experiments
     n = c.emit("gemm_asm_8w_loop.inc")
     c.emit_clobbers("gemm_asm_8w_clobbers.inc", "G8W_CLOBBERS")
     print(f"8w/k64: {n} lines, {c.nvgpr} VGPRs + {c.nacc} AGPRs")
@@ -590,7 +590,7 @@ def main():
     ck.emit_clobbers("gemm256_kloop_clobbers.inc", "G256K_CLOBBERS")
     print(f"gemm256 k-loop: {nk} lines")
     # traffic per K-tile; every wave stages 64 rows of A and of B (8 + 8 loads per tile)
-    c4 = CfgK64("4w", 8, 8, 8, set(os.environ.get("GEN4W_FLAGS", "spread").split(",")))      # GEN4W_FLAGS: timing experiments
+    c4 = CfgK64("4w", 8, 8, 8, set(os.environ.get("GEN4W_FLAGS", "hbl,noprio,ls6").split(",")))      # GEN4W_FLAGS: timing experiments
     n4 = c4.emit("gemm_asm_4w_loop.inc")
     c4.emit_clobbers("gemm_asm_4w_clobbers.inc", "G4W_CLOBBERS")
     print(f"4w/k64: {n4} lines, {c4.nvgpr} VGPRs + {c4.nacc} AGPRs")
