@@ -378,7 +378,7 @@ class CfgK64(Cfg):
         return lines
 
 
-    def tile_hbl(self, tset):
+    def tile_hbl(self, tset, final=0):
         """One K-tile in the shape hipBLASLt's hand-written 4-wave kernel shows (round 3, disassembly of its MT256x256x64 custom kernel):
         never more than TWO non-MFMA instructions between two MFMAs (a 16x16x32 MFMA occupies the matrix pipe for 16 cycles and the only
         wave of the SIMD issues one instruction per 4: anything beyond two pushes the next MFMA back), no vmcnt(0), three barriers:
@@ -400,6 +400,12 @@ class CfgK64(Cfg):
         bar = [] if "nobarrier" in self.flags else ["s_barrier"]
 
         def put(aux, gap, *ins):
+            if final:
+                # peeled last iteration ("peel"): tiles nt-2 (final 1) and nt-1 (final 2) prefetch nothing -- no pointer update, no loads,
+                # no barriers 1 / 2 (they only hand LDS regions back to the loads); the last tile does not read a next tile either
+                drop = ("global_load_lds", "s_add_i32 m0", "s_min_u32 s52", "s_add_u32 s48", "s_addc_u32 s49", "s_add_u32 s50",
+                        "s_addc_u32 s51", "s_add_u32 s44")
+                ins = [x for x in ins if not x.startswith(drop)]
             if "noglds" in self.flags:      # timing only
                 ins = ["s_nop 0" if x.startswith("global_load_lds") else x for x in ins]
             if "noreads" in self.flags:     # timing only
@@ -422,6 +428,10 @@ class CfgK64(Cfg):
         L1 = last + (4 if dense else 6)
         put(aux, L1, "s_waitcnt lgkmcnt(0)")
         bar1, bar2, bar3 = ([] if f"nb{k}" in self.flags else bar for k in (1, 2, 3))     # timing only: drop one of the barriers
+        if final:
+            bar1 = bar2 = []
+            if final == 2:
+                bar3, ra0, rb0 = [], [], []
         put(aux, L1 + 1, *bar1, f"s_add_i32 m0, s47, {tset * 65536}")
         g = L1 + 2
         # load stride in MFMA gaps ("ls<S>", default 2 = back to back behind barriers 1 / 2). The four waves of the workgroup run in
@@ -460,7 +470,10 @@ class CfgK64(Cfg):
         while (nm + w) in load_at or (nm + w + 1) in load_at:
             w += 1
         issued = sum(1 for gp in load_at if gp < nm + w)           # loads of THIS iteration already issued at the wait
-        put(aux, w, f"s_waitcnt vmcnt({issued})")
+        if final == 1:
+            issued = 0                                             # nothing of this iteration is in flight: tile nt-1 has to have landed
+        if final != 2:
+            put(aux, w, f"s_waitcnt vmcnt({issued})")
         put(aux, w + 1, *bar3)
         for gp, ins in load_at.items():
             if gp >= nm:
@@ -478,6 +491,7 @@ class CfgK64(Cfg):
         assert len(free) >= len(rd), (len(free), len(rd))
         for k, r in enumerate(rd):
             put(aux, free[(k * len(free)) // len(rd)], r)
+        aux = {g_: i_ for g_, i_ in aux.items() if i_}
         put(aux, nm - 2, "s_waitcnt lgkmcnt(0)")
         assert max(aux) < nm, (max(aux), nm)
         lines += [f"; ---- tile set {tset}, k-step 1 (hbl)"] + self.mfmas(1, aux)
@@ -517,8 +531,15 @@ class CfgK64(Cfg):
         head = [".p2align 8"] if "align" in self.flags else [".p2align 8", "s_nop 0"] if "align4" in self.flags else []
         if "hbl" in self.flags:
             head = ["s_waitcnt lgkmcnt(0)"] + head           # the other schedules wait at the top of every k-step 0
-        out = self.prologue() + head + ["1:"] + tile(0) + tile(1)
-        out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 1b"]
+        if "peel" in self.flags:
+            # the loop runs nit - 1 times; the last iteration is a copy without the (dummy) prefetch of tiles nt, nt + 1: 2 / nt of the
+            # L2 -> LDS traffic and the tail's wait for loads nobody reads
+            assert "hbl" in self.flags
+            out = self.prologue() + head + ["s_cmp_le_u32 s46, 1", "s_cbranch_scc1 4f", "1:"] + tile(0) + tile(1)
+            out += ["s_sub_u32 s46, s46, 1", "s_cmp_gt_u32 s46, 1", "s_cbranch_scc1 1b", "4:"] + self.tile_hbl(0, 1) + self.tile_hbl(1, 2)
+        else:
+            out = self.prologue() + head + ["1:"] + tile(0) + tile(1)
+            out += ["s_sub_u32 s46, s46, 1", "s_cmp_lg_u32 s46, 0", "s_cbranch_scc1 1b"]
         if "tail256" in self.flags:
             return out + self.tail256()
         return out + ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 7", "s_nop 7"]
@@ -584,7 +605,7 @@ def main():
     # 4 waves = 2 x 2, 128 x 128 per wave (8 x 8 fragments in a[0:255], two 64-VGPR fragment buffers), one wave per SIMD: -25 % LDS
     # PRODUCT main loop of gemm256's k-contiguous instantiations (gemm256.hip, template parameter ASM): the 8-wave loop with gemm256's
     # sub-tile map, the three-barrier / spread-load schedule, and the tile image written from the assembly
-    ck = CfgK64("8w", 8, 4, 4, {"hbl", "noprio", "ls6", "map256", "tail256"})
+    ck = CfgK64("8w", 8, 4, 4, {"hbl", "map256", "tail256"} | set(os.environ.get("GEN256_FLAGS", "noprio,ls6,peel").split(",")))   # GEN256_FLAGS: A/B builds
     nk = ck.emit("gemm256_kloop.inc")
     ck.emit_lines("gemm256_kloop_half1.inc", ck.image_f32(1) + ["s_waitcnt lgkmcnt(0)"])
     ck.emit_clobbers("gemm256_kloop_clobbers.inc", "G256K_CLOBBERS")
