@@ -515,11 +515,11 @@ class CfgK64(Cfg):
             lines += [f"v_min_u32 v{va + q}, v{va + q}, %[oAmax]", f"v_min_u32 v{vbb + q}, v{vbb + q}, %[oBmax]"]
         if "l2pf" in self.flags:
             lines += [f"v_mov_b32 v{self.nvgpr}, %[pfA]", f"v_mov_b32 v{self.nvgpr + 1}, %[pfB]"]
-        for r in range(self.nacc):
-            lines.append(f"v_accvgpr_write_b32 a{r}, 0")
-        for g in range(2):
+        for g in range(2):                     # the first two K-tiles are on their way before the accumulators are cleared
             for b in self.load_group(g):
                 lines.extend(b)
+        for r in range(self.nacc):
+            lines.append(f"v_accvgpr_write_b32 a{r}, 0")
         lines += [f"s_waitcnt vmcnt({2 * self.NLOAD + 2 * self.npf})", "s_barrier"]
         lines += self.reads_for(0, 0, 0)
         return lines
