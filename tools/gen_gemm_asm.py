@@ -605,7 +605,7 @@ def main():
     # 4 waves = 2 x 2, 128 x 128 per wave (8 x 8 fragments in a[0:255], two 64-VGPR fragment buffers), one wave per SIMD: -25 % LDS
     # PRODUCT main loop of gemm256's k-contiguous instantiations (gemm256.hip, template parameter ASM): the 8-wave loop with gemm256's
     # sub-tile map, the three-barrier / spread-load schedule, and the tile image written from the assembly
-    ck = CfgK64("8w", 8, 4, 4, {"hbl", "map256", "tail256"} | set(os.environ.get("GEN256_FLAGS", "noprio,ls6,peel").split(",")))   # GEN256_FLAGS: A/B builds
+    ck = CfgK64("8w", 8, 4, 4, {"hbl", "map256", "tail256"} | set(os.environ.get("GEN256_FLAGS", "noprio,ls6,peel,wb8").split(",")))   # GEN256_FLAGS: A/B builds
     nk = ck.emit("gemm256_kloop.inc")
     ck.emit_lines("gemm256_kloop_half1.inc", ck.image_f32(1) + ["s_waitcnt lgkmcnt(0)"])
     ck.emit_clobbers("gemm256_kloop_clobbers.inc", "G256K_CLOBBERS")
