@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             [oBmax] "v"(oBmax), [vImg] "v"(vImg)
         : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", G256K_CLOBBERS);
 #endif
-    if (part) {     // K-slice of a tail tile: the raw fp32 image leaves as whole rows of the tile-local [256][256] partial
+    if constexpr (EPI == 0) if (part) {     // K-slice of a tail tile: the raw fp32 image leaves as whole rows of the tile-local [256][256] partial
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         if (hf) {
@@ -497,9 +497,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         const int I = p.sw_I;
         char* scrB = smem + 2 * BUF;
         const size_t ld2 = (size_t)2 * I;
+        // Assembly-loop kernels fetch gate / up ONE STRIP AHEAD (the loop below stays a loop, so the values are carried in registers and
+        // the compiler cannot sink the loads to their use as it did in the compiler-loop kernel, where 128 accumulator registers are
+        // live): the load latency of strips 1..3 disappears behind the previous strip's arithmetic, stores and LDS transposition.
+        u32x4_t gq[4], uq[4];
+        auto fetch_gu = [&](int strip, u32x4_t* g4, u32x4_t* u4) {
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int idx = tid + 512 * k4;
+            const int m = m0 + strip * 64 + (idx >> 5), n = n0 + (idx & 31) * 8;
+            g4[k4] = u32x4_t{0u, 0u, 0u, 0u};
+            u4[k4] = g4[k4];
+            if (m < p.M && n < p.N) {
+              g4[k4] = *(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + n);
+              u4[k4] = *(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + I + n);
+            }
+          }
+        };
+        if constexpr (ASM) fetch_gu(0, gq, uq);
         for (int s4 = 0; s4 < 4; ++s4) {
           char* scrA = smem + s4 * 64 * 512;
           u32x4_t pg[4], pu[4];
+          u32x4_t gn[4], un[4];
+          if constexpr (ASM) if (s4 < 3) fetch_gu(s4 + 1, gn, un);
 #pragma unroll
           for (int k4 = 0; k4 < 4; ++k4) {
             const int idx = tid + 512 * k4;
@@ -511,8 +531,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             if (m < p.M && n < p.N) {
               float dv[8], gv[8], uv[8], dg[8], du[8];
               unpack8(*(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)), dv);
+              if constexpr (ASM) {
+                unpack8(gq[k4], gv);
+                unpack8(uq[k4], uv);
+              } else {
               unpack8(*(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + n), gv);
               unpack8(*(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + I + n), uv);
+              }
 #pragma unroll
               for (int j = 0; j < 8; ++j) swiglu_bwd_elem(dv[j], gv[j], uv[j], dg[j], du[j]);
               pg[k4] = pack8(dg);
@@ -557,6 +582,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
           }
           // no barrier here: the next strip's compute phase touches only ITS rows of the image and ends with a barrier before
           // anything is written to scrB / its scrA again
+          if constexpr (ASM) {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) { gq[k4] = gn[k4]; uq[k4] = un[k4]; }
+          }
         }
         return;
       }
@@ -601,7 +630,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
       }
       return;
     }
+    if constexpr (EPI == 0 || !ASM) {   // the fused-epilogue assembly-loop kernels have the bf16 image only: ONE inline-asm statement, no
+                                        // accumulator outlives it (tools/check_kloop_asm.py looks between the first and the last statement)
     float sq = 0.f;                                // sum of squares of this lane's FINAL fp32 outputs (p.sq_out)
+    // bf16 output + residual (o / down projection of the decoder layer): the residual rows of BOTH halves are requested here, before the
+    // barriers and the image reads they would otherwise queue behind (assembly-loop kernels: the accumulators are not in compiler
+    // registers, so 64 registers of prefetch are free). Same values, same arithmetic.
+    u32x4_t rpre[2][8];
+    const bool r_pre = ASM && p.R != nullptr && !p.out_fp32;
+    if (r_pre) {
+      const int nn = n0 + (lane & 31) * 8;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int m = m0 + h2 * 128 + wave * 16 + it * 2 + (lane >> 5);
+          rpre[h2][it] = u32x4_t{0u, 0u, 0u, 0u};
+          if (m < p.M && nn < p.N) rpre[h2][it] = *(const u32x4_t*)(p.R + (size_t)m * p.ldr + nn);
+        }
+    }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       if (hf) __syncthreads();                     // the readers of the first half are done
@@ -671,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
               float v[8] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3], b[0] + bv[4], b[1] + bv[5], b[2] + bv[6], b[3] + bv[7]};
               if (p.R) {
                 float rv[8];
-                unpack8(*(const u32x4_t*)(p.R + (size_t)m * p.ldr + n), rv);
+                unpack8(r_pre ? rpre[hf][it] : *(const u32x4_t*)(p.R + (size_t)m * p.ldr + n), rv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += rv[j];
               }
@@ -692,6 +739,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         for (int w = 0; w < 8; ++w) t += ((float*)smem)[w];
         p.sq_out[pid] = t;
       }
+    }
     }
     return;
   }

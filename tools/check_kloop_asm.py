@@ -1,33 +1,58 @@
 """Build-time check of gemm256's assembly-loop instantiations (gemm256_kernel<0, 0, EPI, true>).
 
-The accumulators of the hand-scheduled main loop live in a0..a127 across TWO inline-asm statements when the output is fp32 (the loop's
-tail writes accumulator rows 0..3 to the LDS image, gemm256_kloop_half1.inc writes rows 4..7 after the C++ side has consumed the first
-half). The compiler does not know that, so this script proves from the device assembly that it never touches an accumulation register
-(or spills) outside the inline-asm blocks of those kernels. Usage: check_kloop_asm.py <gemm256 device assembly .s>; exit status 1 on a finding."""
+The accumulators of the hand-scheduled main loop live in a0..a127. In the plain kernel (EPI 0) they cross from the main inline-asm statement
+to a second one when the output needs the fp32 tile image (the loop's tail writes accumulator rows 0..3, gemm256_kloop_half1.inc rows 4..7
+after the C++ side has consumed the first half). The compiler does not know that, so this script proves from the device assembly that
+  * in a kernel with MORE than one inline-asm statement, no compiler-generated instruction after the first statement touches an
+    accumulation register (the fused-epilogue kernels have a single statement that consumes every accumulator itself: there the
+    compiler may use the registers afterwards), and
+  * no assembly-loop kernel spills (scratch_ access) anywhere.
+hipcc prints its own instructions behind a tab and the text of an inline-asm statement verbatim from column 0; that is how the two are told
+apart. Usage: check_kloop_asm.py <gemm256 device assembly .s>; exit status 1 on a finding."""
 import re
 import sys
 
 
 def main(path):
-    fn, bad, seen = None, [], 0
-    agpr = re.compile(r"(?<![\w.])a(\[\d+:\d+\]|\d+)\b|accvgpr|scratch_")
+    agpr = re.compile(r"(?<![\w.])a(\[\d+:\d+\]|\d+)\b|accvgpr")
+    bad, seen = [], 0
+    fn, cand, statements, prev_asm = None, [], 0, False
+
+    def close():
+        if fn is not None and statements >= 2:
+            bad.extend(cand)
+
     for n, ln in enumerate(open(path), 1):
         m = re.match(r"^(_Z\w*gemm256_kernel\w*):", ln)
         if m:
+            close()
             fn = m.group(1) if "ELb1EEE" in m.group(1) else None
             seen += fn is not None
+            cand, statements, prev_asm = [], 0, False
             continue
         if fn is None:
             continue
-        if ln.startswith(".Lfunc_end") or ln.lstrip().startswith(".end_amdhsa_kernel"):
+        if ln.startswith(".Lfunc_end"):
+            close()
             fn = None
             continue
         s = ln.strip()
-        # hipcc prints its own instructions behind a tab and the text of an inline-asm statement verbatim, i.e. from column 0
-        if ln.startswith("\t") and s and not s.startswith((";", ".")) and agpr.search(s.split(";")[0]):
-            bad.append((fn, n, s))
-    for fn, n, s in bad:
-        print(f"{path}:{n}: {fn}: accumulator register / scratch access outside the inline assembly: {s}")
+        if not s or s.startswith((";", ".")) or s.endswith(":"):
+            continue
+        if ln.startswith(("\t", " ")):       # compiler-generated instruction
+            prev_asm = False
+            code = s.split(";")[0]
+            if "scratch_" in code:
+                bad.append((fn, n, s))
+            elif statements >= 1 and agpr.search(code):
+                cand.append((fn, n, s))
+        else:                                 # a line of an inline-asm statement
+            if not prev_asm:
+                statements += 1
+            prev_asm = True
+    close()
+    for f, n, s in bad:
+        print(f"{path}:{n}: {f}: accumulator register / scratch access outside the inline assembly: {s}")
     if not seen:
         print(f"{path}: no assembly-loop instantiation of gemm256_kernel found")
         return 1
