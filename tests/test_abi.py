@@ -46,3 +46,51 @@ def test_no_cpu_fallback():
         ops.linear(torch.zeros(4, 8, dtype=torch.bfloat16), (torch.zeros(8, 8, dtype=torch.bfloat16),))
     with pytest.raises((RuntimeError, TypeError)):
         ops.rmsnorm(torch.zeros(4, 8), torch.ones(8), 1e-5)
+
+
+def test_generated_assembly_is_what_the_generator_writes(tmp_path):
+    """The committed main-loop assembly (gemm256_kloop*.inc = the product GEMM loop, gemm_asm_*.inc = the experiment kernels) is exactly what
+    tools/gen_gemm_asm.py emits with its default flags: nobody edits the .inc files by hand, nobody changes the generator without
+    regenerating them."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GEN_OUT_DIR=str(tmp_path))
+    for k in ("GEN256_FLAGS", "GEN8W_FLAGS", "GEN4W_FLAGS"):
+        env.pop(k, None)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gemm_asm.py")], check=True, env=env, capture_output=True)
+    names = ["gemm256_kloop.inc", "gemm256_kloop_half1.inc", "gemm256_kloop_clobbers.inc", "gemm_asm_8w_loop.inc", "gemm_asm_4w_loop.inc",
+             "gemm_asm_8w_clobbers.inc", "gemm_asm_4w_clobbers.inc"]
+    for n in names:
+        new, old = open(tmp_path / n).read(), open(os.path.join(ROOT, "mla_amd", "csrc", n)).read()
+        assert new == old, f"{n} differs from the generator's output: run python tools/gen_gemm_asm.py"
+    # the product loop's shape: three barriers per K-tile in the loop body, no vmcnt(0) inside it, at most two non-MFMA instructions per gap
+    body = [ln.strip('"\\n \n') for ln in open(tmp_path / "gemm256_kloop.inc") if ln.startswith('"')]
+    lo, hi = body.index("1:"), body.index("4:")
+    loop = body[lo + 1:hi]
+    assert sum(ln == "s_barrier" for ln in loop) == 6 and not any(ln.startswith("s_waitcnt vmcnt(0)") for ln in loop)      # two K-tiles per iteration
+    assert sum(ln.startswith("v_mfma") for ln in loop) == 128 and sum(ln.startswith("global_load_lds") for ln in loop) == 16
+    gap = worst = 0
+    for ln in loop:
+        if ln.startswith("v_mfma"):
+            gap = 0
+        elif not ln.startswith(";") and not ln.startswith("s_sub_u32 s46") and not ln.startswith("s_cmp") and not ln.startswith("s_cbranch"):
+            gap += 1
+            worst = max(worst, gap)
+    assert worst <= 2, worst
+
+
+def test_kloop_checker_flags_an_accumulator_touch_between_two_statements(tmp_path):
+    """tools/check_kloop_asm.py (run by build.sh on the real device assembly): a compiler instruction that touches an accumulation
+    register between two inline-asm statements of an assembly-loop kernel is a finding; after a single statement it is not; a spill
+    always is."""
+    import subprocess
+    import sys
+    head = "_ZN1x14gemm256_kernelILi0ELi0ELi0ELb1EEEv8GemmArgs:\n\ts_load_dword s0, s[0:1], 0x0\nv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]\n"
+    cases = {"two_statements": (head + "\tv_accvgpr_write_b32 a5, v1\nv_accvgpr_read_b32 v4, a64\n\ts_endpgm\n.Lfunc_end0:\n", 1),
+             "one_statement": (head + "\tv_accvgpr_write_b32 a5, v1\n\ts_endpgm\n.Lfunc_end0:\n", 0),
+             "spill": (head + "\tscratch_store_dword off, v1, s0\n\ts_endpgm\n.Lfunc_end0:\n", 1)}
+    for name, (src, want) in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(src)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kloop_asm.py"), str(f)], capture_output=True, text=True)
+        assert r.returncode == want, (name, r.stdout)

@@ -21,7 +21,7 @@ Usage: python tools/gen_gemm_asm.py   (re-run after editing; the .inc files are 
 """
 import os
 
-CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mla_amd", "csrc")
+CSRC = os.environ.get("GEN_OUT_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mla_amd", "csrc")   # GEN_OUT_DIR: tests
 NSLOT, SLOT_BYTES = 4, 32768
 AHEAD = NSLOT - 1
 
