@@ -722,6 +722,8 @@ def test_gemm256_assembly_main_loop_is_bit_identical(dev, M, N, K):
     S = 137
     cos, sin = (torch.randn(S, 64, generator=torch.Generator().manual_seed(76 + i)).to(dev) for i in range(2))
     I = (N // 256) * 128
+    a_wide, b_wide = torch.zeros((M, K + 64), dtype=BF, device=dev), torch.zeros((N, K + 32), dtype=BF, device=dev)
+    a_wide[:, 8:8 + K], b_wide[:, 16:16 + K] = a, b
     wgu = bfr(2 * I, K, seed=77, scale=0.1).to(dev)
     gu_in = bfr(M - M % 8, 2 * I, seed=78).to(dev)
 
@@ -730,6 +732,10 @@ def test_gemm256_assembly_main_loop_is_bit_identical(dev, M, N, K):
         out = {}
         out["bf16"] = hip.gemm(a, b)
         out["bf16_nosplit"] = hip.gemm(a, b, force_generic=3)
+        # row pitches larger than the row (views into wider buffers), output into a column block of a wider buffer
+        wide = torch.full((M, N + 64), 7.0, dtype=BF, device=dev)
+        hip.gemm(a_wide[:, 8:8 + K], b_wide[:, 16:16 + K], out=wide[:, 32:32 + N])
+        out["strided"] = wide.clone()
         out["f32"] = hip.gemm(a, b, out_dtype=torch.float32)
         out["epi"] = hip.gemm(a, b, bias=bias, residual=res, alpha=0.5)
         acc = base.clone()
@@ -764,3 +770,5 @@ def test_gemm256_assembly_main_loop_is_bit_identical(dev, M, N, K):
         assert torch.equal(asm[k], ref[k]), (k, float((asm[k].float() - ref[k].float()).abs().max()))
     want = a.float().cpu() @ b.float().cpu().t()
     assert fro_rel(asm["f32"], want) < 1e-5 if K <= 256 else fro_rel(asm["f32"], want) < 1e-4
+    assert torch.equal(asm["strided"][:, 32:32 + N], asm["bf16_nosplit"]) or fro_rel(asm["strided"][:, 32:32 + N], asm["bf16_nosplit"]) < 2e-3
+    assert bool((asm["strided"][:, :32] == 7.0).all()) and bool((asm["strided"][:, 32 + N:] == 7.0).all())      # nothing outside the block is written
