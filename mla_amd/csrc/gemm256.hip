@@ -134,8 +134,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // ---- hand-scheduled main loop (gemm256_kloop.inc, generated by tools/gen_gemm_asm.py; k-contiguous operands, an even number of
     // K-tiles). Same LDS operand image, same K order and the same accumulation order per output as the compiler-scheduled loop below:
     // bit-identical results. Three barriers per K-tile instead of eight, no vmcnt(0) in the loop, and the 8 loads of a wave spread over
-    // ~100 of its 128 MFMA gaps: the waves of a workgroup run in lockstep, so a burst of loads in one wave is a burst of eight times as
-    // many in the CU's single address path and stalls every issuer (round 3: MfmaUtil 65 % -> 84 % on the 4-wave form of this loop).
+    // 43 of its 64 MFMA gaps (one per 6): the waves of a workgroup run in lockstep, so a burst of loads in one wave is a burst of eight
+    // times as many in the CU's single address path and stalls every issuer (round 3: MfmaUtil 65 % -> 84 % on the 4-wave form of this
+    // loop). The last pair of K-tiles runs in a peeled copy of the loop body that prefetches nothing.
     // The accumulators leave the assembly through LDS: the loop's tail writes the tile image the epilogues below read.
     static_assert(AMODE == 0 && BMODE == 0, "the assembly loop takes k-contiguous operands");
     const unsigned c0 = ((unsigned)lg ^ ((unsigned)li & 7u)) << 4;
