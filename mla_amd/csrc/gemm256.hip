@@ -23,6 +23,17 @@
 #include "gemm_args.h"
 
 #include "gemm256_kloop_clobbers.inc"
+// bf16 epilogue outputs (and the residual / gate|up rows the epilogues read) are touched once per launch and consumed by a LATER kernel:
+// non-temporal accesses keep them from displacing the operand panels 4-8 CUs of an XCD share through its L2. Round 3, same-box A/B of
+// whole steps: 587.4 -> 581.6 ms (-1.0 %), fused-epilogue kernels +4.7 % (GEMM flops over their duration); non-temporal fp32 stores
+// (wgrad outputs, read by AdamW) measured 0.2 % worse and stay plain. MLA_GEMM_PLAIN_STORES restores the old behaviour (A/B builds).
+#ifndef MLA_GEMM_PLAIN_STORES
+#define MLA_ST16(ADDR, VAL) __builtin_nontemporal_store((u32x4_t)(VAL), (u32x4_t*)(ADDR))
+#define MLA_LD16(ADDR) __builtin_nontemporal_load((const u32x4_t*)(ADDR))
+#else
+#define MLA_ST16(ADDR, VAL) (*(u32x4_t*)(ADDR) = (VAL))
+#define MLA_LD16(ADDR) (*(const u32x4_t*)(ADDR))
+#endif
 
 namespace {
 
@@ -433,8 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             const int rl = idx >> 5, ch = idx & 31;
             const int row = s4 * 64 + rl, m = m0 + row;
             if (m < p.M)
-              *(u32x4_t*)((bf16_t*)p.C + (size_t)m * ld2 + (ch < 16 ? cbase + ch * 8 : I + cbase + (ch - 16) * 8)) =
-                  *(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4));
+              MLA_ST16((bf16_t*)p.C + (size_t)m * ld2 + (ch < 16 ? cbase + ch * 8 : I + cbase + (ch - 16) * 8), *(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)));
           }
 #pragma unroll
           for (int k2 = 0; k2 < 2; ++k2) {
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = swiglu_fwd_elem(gv[j], uv[j]);
             pa[k2] = pack8(o);
-            if (m < p.M) *(u32x4_t*)(p.sf_act + (size_t)m * I + cbase + c * 8) = pa[k2];
+            if (m < p.M) MLA_ST16(p.sf_act + (size_t)m * I + cbase + c * 8, pa[k2]);
           }
           if (p.sf_actT == nullptr) continue;          // uniform: the caller does not keep the transposed product
           __syncthreads();
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
               u32x4_t w = *(const u32x4_t*)(scrA + col * 128 + ((rc ^ (chc >> 2)) << 4));
               if (b & 1) w = u32x4_t{w[1], w[0], w[3], w[2]};
               if (b & 2) w = u32x4_t{w[2], w[3], w[0], w[1]};
-              *(u32x4_t*)(p.sf_actT + (size_t)(cbase + col) * p.sf_ldt + m) = w;
+              MLA_ST16(p.sf_actT + (size_t)(cbase + col) * p.sf_ldt + m, w);
             }
           }
         }
@@ -510,8 +520,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             g4[k4] = u32x4_t{0u, 0u, 0u, 0u};
             u4[k4] = g4[k4];
             if (m < p.M && n < p.N) {
-              g4[k4] = *(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + n);
-              u4[k4] = *(const u32x4_t*)(p.sw_gu + (size_t)m * ld2 + I + n);
+              g4[k4] = MLA_LD16(p.sw_gu + (size_t)m * ld2 + n);
+              u4[k4] = MLA_LD16(p.sw_gu + (size_t)m * ld2 + I + n);
             }
           }
         };
@@ -543,8 +553,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
               for (int j = 0; j < 8; ++j) swiglu_bwd_elem(dv[j], gv[j], uv[j], dg[j], du[j]);
               pg[k4] = pack8(dg);
               pu[k4] = pack8(du);
-              *(u32x4_t*)(p.sw_dgu + (size_t)m * ld2 + n) = pg[k4];
-              *(u32x4_t*)(p.sw_dgu + (size_t)m * ld2 + I + n) = pu[k4];
+              MLA_ST16(p.sw_dgu + (size_t)m * ld2 + n, pg[k4]);
+              MLA_ST16(p.sw_dgu + (size_t)m * ld2 + I + n, pu[k4]);
             }
           }
           __syncthreads();           // the strip's rows of the d(act) image have been consumed by everyone
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 u32x4_t w = *(const u32x4_t*)((which ? scrB : scrA) + off);
                 if (b & 1) w = u32x4_t{w[1], w[0], w[3], w[2]};
                 if (b & 2) w = u32x4_t{w[2], w[3], w[0], w[1]};
-                *(u32x4_t*)(p.sw_dguT + (size_t)(which * I + n) * p.sw_ldt + m) = w;
+                MLA_ST16(p.sw_dguT + (size_t)(which * I + n) * p.sw_ldt + m, w);
               }
             }
           }
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
               for (int j = 0; j < 8; ++j)
                 o[j] = lo ? fmaf(own[j], c[j], -(par[j] * sn[j])) : fmaf(own[j], c[j], par[j] * sn[j]);
-              *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8(o);
+              MLA_ST16((bf16_t*)p.C + (size_t)m * p.ldc + n, pack8(o));
             }
           }
         }
@@ -626,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
           const int row = wave * 32 + it * 2 + (lane >> 5);
           const int m = m0 + row;
           if (m < p.M)
-            *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = *(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4));
+            MLA_ST16((bf16_t*)p.C + (size_t)m * p.ldc + n, *(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)));
         }
       }
       return;
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         for (int it = 0; it < 8; ++it) {
           const int m = m0 + h2 * 128 + wave * 16 + it * 2 + (lane >> 5);
           rpre[h2][it] = u32x4_t{0u, 0u, 0u, 0u};
-          if (m < p.M && nn < p.N) rpre[h2][it] = *(const u32x4_t*)(p.R + (size_t)m * p.ldr + nn);
+          if (m < p.M && nn < p.N) rpre[h2][it] = MLA_LD16(p.R + (size_t)m * p.ldr + nn);
         }
     }
 #pragma unroll
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += rv[j];
               }
-              *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8(v);
+              MLA_ST16((bf16_t*)p.C + (size_t)m * p.ldc + n, pack8(v));
             }
           }
         }
