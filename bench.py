@@ -284,7 +284,7 @@ def main():
             traffic = None
             tprov = None
             hit = None
-            for tname in ("r3c_gemm256_hbm_traffic.json", "r3b_gemm256_hbm_traffic.json", "r3_gemm256_hbm_traffic.json", "r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
+            for tname in ("r3d_gemm256_hbm_traffic.json", "r3c_gemm256_hbm_traffic.json", "r3b_gemm256_hbm_traffic.json", "r3_gemm256_hbm_traffic.json", "r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tpath) and args.config == 1 and not args.tiny:
                     with open(tpath) as fh:
