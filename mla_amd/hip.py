@@ -20,7 +20,7 @@ ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 
 # split-K tail of the 256x256 GEMM (mla_gemm_bf16_ws): on by default; MLA_GEMM_SPLITK=0 turns it off for A/B measurements
 SPLITK = os.environ.get("MLA_GEMM_SPLITK", "1") != "0"
-SPLITK_WS_BYTES = 64 << 20
+SPLITK_WS_BYTES = int(os.environ.get("MLA_GEMM_SPLITK_WS_MB", "64")) << 20     # fp32 partial tiles of the K-slices (256 KiB each); 256 MiB would also split the 688-tile down-projection wgrad (176 tail tiles x 4): measured 1.2 % SLOWER per launch
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream (roofline.achieved)
 GEMM_PROFILE = None
