@@ -17,7 +17,20 @@ Register map (per lane), 8w:  a[0:127] accumulators, frag (i, j) at a[(i*4+j)*4 
   v96/v97 A read base (+0 / +65536)   v98/v99 B read base   v100,v101 A load voffsets   v102,v103 B load voffsets
   s[40:41] A tile base  s[42:43] B tile base  s44 next k byte offset  s45 last valid k byte offset  s46 loop counter
   s47 this wave's LDS store base  s[48:49]/s[50:51] current A/B source  s52 scratch
-Usage: python tools/gen_gemm_asm.py   (re-run after editing; the .inc files are committed)
+Usage: python tools/gen_gemm_asm.py   (re-run after editing; the .inc files are committed; tests/test_abi.py checks they are in sync)
+
+Round 3. The class that matters now is CfgK64 (64-k tiles with 128-B rows, two 64 KiB tile sets) and its schedule `tile_hbl`
+(flag "hbl"): three barriers per K-tile, never more than two non-MFMA instructions between two MFMAs, no vmcnt(0), and the loads
+of a tile spread over the K-tile ("ls<S>": one load per S MFMA gaps) -- the waves of a workgroup run in lockstep, so a wave's burst
+of loads is the whole CU's burst and stalls every MFMA issuer. main() emits
+  * gemm256_kloop.inc / _half1.inc / _clobbers.inc: the PRODUCT main loop of gemm256's k-contiguous instantiations (8 waves,
+    gemm256's sub-tile map "map256", peeled last iteration "peel", barrier 3 at gap 8 "wb8", LDS tile-image tail "tail256");
+    GEN256_FLAGS overrides the schedule flags for A/B builds;
+  * gemm_asm_8w_loop.inc, gemm_asm_4w_loop.inc (+ clobbers, + the timing variants v1..v9): the stand-alone experiment kernels of
+    gemm_asm.hip (MLA_EXPERIMENTAL=1 builds); GEN8W_FLAGS / GEN4W_FLAGS select schedules.
+Other flags: "wb<N>" gap of barrier 3, "rowmaj" / "colmaj" MFMA order, "noprio", "align" / "align4" loop-head placement, "spread" /
+"loadsfirst" / "midbarrier" / "pgr2" the older schedules, and the TIMING-ONLY ablations (wrong results!) "noglds", "noreads",
+"nobarrier", "nb1".."nb3", "novmwait", "vgprload", "vgprload_w", "l2pf". GEN_OUT_DIR redirects the output (tests).
 """
 import os
 
