@@ -167,11 +167,13 @@ def main():
                     help="BASELINE.json configs index: 1 = 7B SFT (the headline metric; also configs[2] when --gpus 8), "
                          "3 = post-training (image + point-cloud generation heads on top of config 1), "
                          "4 = pretrain shape, use_pointcloud=False, S=2048, activation checkpointing")
-    ap.add_argument("--keep-layers", type=int, default=-1,
-                    help="config 4: decoder layers (the last N) that keep their activations instead of being checkpointed; -1 = as many as "
-                         "fit under --mem-budget-gb, 0 = the reference's policy (checkpoint every layer)")
+    ap.add_argument("--keep-layers", type=int, default=0,
+                    help="config 4: decoder layers (the last N) that keep their activations instead of being checkpointed. 0 (default) = "
+                         "the reference's policy and what BASELINE.json configs[4] names: every layer checkpointed "
+                         "(training/strategies/fsdp.py:211-223). -1 = opt-in MIXED policy: as many layers as fit next to the MEASURED "
+                         "peak of an all-checkpointed step in --mem-frac of this device's memory (torch.cuda.mem_get_info)")
     ap.add_argument("--keep-level", type=int, default=3, choices=[1, 2, 3], help="save level of the kept layers (3 = level 1 without act^T)")
-    ap.add_argument("--mem-budget-gb", type=float, default=262.0, help="peak-memory target of the automatic --keep-layers choice")
+    ap.add_argument("--mem-frac", type=float, default=0.91, help="share of the device's total memory the automatic --keep-layers -1 choice may plan for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
     args = ap.parse_args()
@@ -180,9 +182,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev < args.gpus:
-        # never a silent smaller job: N ranks need N devices (one RCCL rank per GPU)
-        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible")
+    if "RANK" not in os.environ:
+        # the parent (plain `python bench.py --gpus N`): never a silent smaller job, N ranks need N devices (one RCCL rank per GPU)
+        if ndev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible")
+    elif local_rank >= max(ndev, 1) and ndev != 1:
+        # a launcher's worker: launchers that bind ONE visible device per rank (per-rank HIP_VISIBLE_DEVICES, SLURM --gpus-per-task=1)
+        # show ndev == 1 with WORLD_SIZE == --gpus, which is fine; what must not happen is a rank without a device of its own
+        raise SystemExit(f"bench.py rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     if args.gpus != world:
         if "RANK" not in os.environ and args.gpus > 1:
             # plain `python bench.py --gpus N`: re-launch ourselves as N ranks (one process per GPU) under torch.distributed.run --
@@ -200,8 +207,9 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if local_rank < ndev else 0      # one-visible-device-per-rank launchers: every rank's device is index 0
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or "RANK" in os.environ:       # launched through torch.distributed.run (also with --gpus 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
@@ -218,7 +226,7 @@ def main():
     stage = "post-training" if gen_on else ("pretrain" if args.config == 4 else "finetune")   # config 4: the vision tokenizer trains too
     mla = build(device, args.save_level, args.tiny, use_pointcloud=pc_on, generation=gen_on, stage=stage)
     torch.manual_seed(42 + rank)               # rank-local noise / timesteps / FPS starts, like the reference's per-rank RNG
-    strat = FSDPStrategy(mla, local_rank, stage=stage, global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
+    strat = FSDPStrategy(mla, dev_index, stage=stage, global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
                          learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
                          enable_gradient_checkpointing=False, repeated_diffusion_steps=R_DIFF)
     strat.run_setup(n_train_examples=10_000)
@@ -227,11 +235,7 @@ def main():
         # Mixed activation policy: the config names activation checkpointing because the reference targets 80 GB parts; with 288 GB the
         # LAST k decoder layers keep their activations (level 3: h, qkv, o, lse, h_mid, gate|up = 93 KB per token and layer) and only the
         # others recompute their forward. Bit-identical results for every k (tests/test_model_gpu.py::test_decoder_stack_mixed_...).
-        tok = B_PER_GPU * R_DIFF * 2048
-        per_layer = {1: (6 * 4096 + 3 * 11008) * 2, 3: (6 * 4096 + 2 * 11008) * 2, 2: (8 * 4096 + 4 * 11008) * 2}[args.keep_level] * tok \
-            - 4096 * 2 * tok                                     # minus the layer input a checkpointed layer keeps anyway
-        base = 158e9                                             # measured peak of the all-checkpointed step (profiles/r2_bench_config4_S2048.json: 156 GB)
-        keep_layers = args.keep_layers if args.keep_layers >= 0 else max(0, min(32, int((args.mem_budget_gb * 2**30 - base) // per_layer)))
+        keep_layers = max(0, args.keep_layers)
         mla.vlm.llm_backbone.set_activation_policy(keep_layers, keep_level=args.keep_level, rest_level=0)
     batch = make_batch(B=B_PER_GPU, L_text=l_text, seed=42 + rank, device=device, use_pointcloud=pc_on, with_next=gen_on)
     S = l_text + S_FUSED + 3
@@ -242,9 +246,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.config == 4 and not args.tiny and args.keep_layers < 0:
+        # opt-in mixed policy, sized from THIS rank's measurements (advisor, round 3: no constants): one all-checkpointed step gives the
+        # base peak (weights, optimizer shards, gradients, one layer's recompute, logits); every kept layer adds its saved activations
+        strat.train_step(batch)
+        strat.synchronize()
+        torch.cuda.synchronize()
+        base = torch.cuda.max_memory_allocated()                 # bytes
+        total = torch.cuda.mem_get_info()[1]                     # bytes, this device
+        tok = B_PER_GPU * R_DIFF * 2048
+        per_layer = ({1: (6 * 4096 + 3 * 11008) * 2, 3: (6 * 4096 + 2 * 11008) * 2, 2: (8 * 4096 + 4 * 11008) * 2}[args.keep_level]
+                     - 4096 * 2) * tok                           # bytes; minus the layer input a checkpointed layer keeps anyway
+        keep_layers = max(0, min(32, int((args.mem_frac * total - base) // per_layer)))
+        if world > 1:                                            # every rank must run the same policy: take the smallest choice
+            kt = torch.tensor([keep_layers], device=device)
+            dist.all_reduce(kt, op=dist.ReduceOp.MIN)
+            keep_layers = int(kt.item())
+        print(f"# mixed activation policy: base peak {base / 2**30:.1f} GiB, device {total / 2**30:.1f} GiB, {per_layer / 2**30:.2f} GiB per kept "
+              f"layer -> keep {keep_layers}", file=sys.stderr)
+        mla.vlm.llm_backbone.set_activation_policy(keep_layers, keep_level=args.keep_level, rest_level=0)
+        torch.cuda.reset_peak_memory_stats()
     for _ in range(args.warmup):
         losses = strat.train_step(batch)
     prof = None if args.no_gemm_profile else []
+    if strat.sharded.coll:
+        strat.sharded.wait_profile = []        # time every stall of the compute stream behind a reduce-scatter / all-gather event
     strat.synchronize()                        # flush the warm-up's deferred optimizer updates: the timed region owns exactly K of them
     sync()
     hip.GEMM_PROFILE = prof
@@ -255,6 +281,21 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     hip.GEMM_PROFILE = None
+    per_rank = None
+    if strat.sharded.coll:
+        # first-run diagnosis for N > 1 (VERDICT r3 #3d): every rank's own step time and how long ITS compute stream sat behind
+        # collectives -- rs_event = the backward's reduce-scatters not finished when clipping starts (exposed communication),
+        # gather_event = a layer's bf16 all-gather (issued behind AdamW) not finished when the next forward reaches the layer
+        waits = strat.sharded.wait_profile_ms()
+        mine = torch.tensor([elapsed / args.steps * 1e3, waits.get("rs_event", 0.0) / args.steps, waits.get("gather_event", 0.0) / args.steps],
+                            dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)] if world > 1 else [mine]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        rows = [[round(float(x), 3) for x in r.tolist()] for r in allr]
+        per_rank = {"step_ms": [r[0] for r in rows], "step_ms_min": min(r[0] for r in rows), "step_ms_max": max(r[0] for r in rows),
+                    "rs_event_wait_ms_per_step": [r[1] for r in rows], "gather_event_wait_ms_per_step": [r[2] for r in rows],
+                    "note": "main-stream stall behind the side-stream collectives, bracketed by HIP events around each wait_event"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,14 +325,22 @@ def main():
             traffic = None
             tprov = None
             hit = None
-            for tname in ("r3d_gemm256_hbm_traffic.json", "r3c_gemm256_hbm_traffic.json", "r3b_gemm256_hbm_traffic.json", "r3_gemm256_hbm_traffic.json", "r2_gemm256_hbm_traffic.json", "r1_gemm256_hbm_traffic.json"):
-                tpath = os.path.join(ROOT, "profiles", tname)
-                if os.path.exists(tpath) and args.config == 1 and not args.tiny:
+            stale = None
+            # newest record first (file names sort by round tag: r4b > r4 > r3d ...)
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm256_hbm_traffic.json")),
+                            key=lambda f: os.path.basename(f).split("_")[0], reverse=True)
+            for tpath in tfiles:
+                if args.config == 1 and not args.tiny:
                     with open(tpath) as fh:
                         tj = json.load(fh)
                     traffic = round(tj["hbm_bytes_per_launch"])
                     hit = tj.get("tcc_hit_rate")
-                    tprov = f"profiles/{tname} (collected {tj.get('collected', 'round 1')}; separate --pmc passes over this command, not this run)"
+                    # the counters describe the kernel they were collected on: a record without the library's gemm256 source id, or with
+                    # another one, is reported as stale instead of silently standing for the current kernel
+                    stale = tj.get("gemm_source_id") != hip.gemm_source_id()
+                    tprov = (f"profiles/{os.path.basename(tpath)} (collected {tj.get('collected', 'round 1')} on gemm256 source id "
+                             f"{tj.get('gemm_source_id', 'unrecorded')}, loaded library {hip.gemm_source_id()}; separate --pmc passes over this command, not this run)")
                     break
             if os.environ.get("MLA_BENCH_GEMM_SHAPES"):
                 by = {}
@@ -321,7 +370,7 @@ def main():
                                                        "achieved_gemm_flops_only": round(ach_fused, 1), "launches_per_step": len(fused) // args.steps}
                                                       if fused else None),
                     "all_gemm_launches_achieved": round(ach_all, 1),
-                    "traffic": traffic, "traffic_source": tprov,
+                    "traffic": traffic, "traffic_stale": stale, "traffic_source": tprov,
                     "traffic_unit": "HBM+MALL bytes per launch (fabric-side counters), avg over the plain gemm256_kernel<0,0,0> launches >= 0.1 TFLOP "
                                     "(the population of algorithmic_bytes_per_launch)",
                     "l2_hit_rate": (round(hit, 4) if hit is not None else None),
@@ -339,8 +388,10 @@ def main():
                                       + (" [TINY SMOKE MODEL - not the benchmark]" if args.tiny else ""),
                           "model": "mla-llama2-7b" if not args.tiny else "tiny", "global_batch": B_PER_GPU * world, "seq_len": S,
                           "parallelism": f"fsdp-rccl x{world}" if world > 1 else "single-gpu", "activation_save_level": args.save_level,
-                          **({"activation_policy": f"last {keep_layers} of 32 decoder layers keep activations (level {args.keep_level}), "
-                                                   f"{32 - keep_layers} checkpointed (level 0)"} if args.config == 4 and not args.tiny else {}),
+                          **({"activation_policy": ("every decoder layer checkpointed (the reference's policy, fsdp.py:211-223)" if keep_layers == 0 else
+                                                    f"MIXED (opt-in, not the reference's policy): last {keep_layers} of 32 decoder layers keep "
+                                                    f"activations (level {args.keep_level}), {32 - keep_layers} checkpointed (level 0)")}
+                             if args.config == 4 and not args.tiny else {}),
                           "optimizer": "fused AdamW + grad clip inside the timed region"},
                "model_tflop_per_sample": round(tot_fl / 1e12, 2),
                **({"heads_encoders_tflop_per_sample_from_gemm_launches": round(heads_fl / 1e12, 2)} if heads_fl else {}),
@@ -348,6 +399,8 @@ def main():
                "mfu_vs_2.5PF": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                "loss": {k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+        if per_rank:
+            out["per_rank"] = per_rank
         if roof:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
@@ -358,6 +411,9 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)                    # fd 1 is stdout again for whatever runs after main() in this process
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

@@ -29,6 +29,9 @@ typedef struct ihipStream_t* mla_stream_t; /* == hipStream_t */
 /* ---- library ---- */
 const char* mla_last_error(void);
 int mla_query(int what); /* 0: ABI version, 1: compiled gfx arch (950), 2: wavefront size (64), 3: 1 if the opt-in experiment kernels are compiled in */
+/* sha256[:16] over the gemm256 kernel family's sources, stamped at build time (build.sh): bench.py compares it with the id recorded
+ * next to the PMC traffic figures in profiles/ and reports roofline.traffic_stale when they differ */
+const char* mla_gemm_source_id(void);
 /* hardware-assumption self test (ds_read_b64_tr_b16 lane map, global_load_lds destination order) */
 int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_1k, mla_stream_t stream);
 

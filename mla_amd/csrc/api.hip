@@ -13,6 +13,14 @@ void mla_set_error(const char* fmt, ...) {
 
 extern "C" const char* mla_last_error(void) { return g_err; }
 
+// sha256[:16] over the sources of the gemm256 kernel family (gemm256.hip, its generated main-loop .inc files, gemm_args.h, common.h),
+// stamped by build.sh: profiles/*_hbm_traffic.json records the id of the kernel the counters were collected on, and bench.py flags
+// `traffic_stale` when the loaded library's id differs.
+#ifndef MLA_GEMM_SRC_ID
+#define MLA_GEMM_SRC_ID "unknown"
+#endif
+extern "C" const char* mla_gemm_source_id(void) { return MLA_GEMM_SRC_ID; }
+
 // what: 0 = ABI version, 1 = compiled gfx arch number (950), 2 = wavefront size the kernels assume, 3 = 1 when the opt-in experiment
 // kernels (assembly GEMM main loops, persistent GEMM walk) were compiled in (build.sh MLA_EXPERIMENTAL=1), else 0
 extern "C" int mla_query(int what) {

@@ -11,13 +11,17 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC ${MLA_EXTRA_FLAGS:-} -Wno-unus
 BUILD="$HERE/build"
 if [ "$EXP" = 1 ]; then FLAGS="$FLAGS -DMLA_EXPERIMENTAL_KERNELS"; BUILD="$HERE/build_exp"; fi
 mkdir -p "$BUILD"
+# identity of the gemm256 kernel family's sources -> mla_gemm_source_id() (api.hip); api.o is rebuilt when it changes
+GID=$(cat "$HERE/gemm256.hip" "$HERE/gemm256_kloop.inc" "$HERE/gemm256_kloop_half1.inc" "$HERE/gemm256_kloop_clobbers.inc" "$HERE/gemm_args.h" "$HERE/common.h" | sha256sum | cut -c1-16)
+if [ "$(cat "$BUILD/gemm_src_id.txt" 2>/dev/null)" != "$GID" ]; then echo "$GID" > "$BUILD/gemm_src_id.txt"; rm -f "$BUILD/api.o"; fi
 pids=()
 SRCS="api gemm gemm256 transpose elementwise attention loss pointcloud vision gen"
 [ "$EXP" = 1 ] && SRCS="$SRCS gemm_asm"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
   if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/common.h" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$BUILD/$f.o" ] || { [ "$f" = gemm256 ] && { [ "$HERE/gemm256_kloop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm256_kloop_half1.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_8w_clobbers.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_clobbers.inc" -nt "$BUILD/$f.o" ]; }; }; then
-    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
+    XF=""; [ "$f" = api ] && XF="-DMLA_GEMM_SRC_ID=\"$GID\""
+    $HIPCC $FLAGS $XF -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
     pids+=($!)
     if [ "$f" = gemm256 ]; then   # device assembly for tools/check_kloop_asm.py (below)
       $HIPCC $FLAGS --cuda-device-only -S "$HERE/$f.hip" -o "$BUILD/$f.s" &

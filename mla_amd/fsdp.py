@@ -228,9 +228,28 @@ class FlatUnit:
                 p._mg_touched = True
                 p.grad = None
 
-    def finish_backward(self):
+    def finish_backward(self, already_reduced: bool = False):
         """Parameters that received no gradient this step but hold a stale one from an earlier step are zeroed
-        (torch FSDP with use_orig_params presents zero gradients for them, and AdamW still applies to them)."""
+        (torch FSDP with use_orig_params presents zero gradients for them, and AdamW still applies to them).
+
+        ``already_reduced``: the unit's reduce-scatter was launched from its backward hook (decoder layers). With the in-place
+        collective the reduced SUM shard lives INSIDE grad32, so nothing may write main_grad any more -- a late autograd ``.grad``
+        or a stale gradient that would need zeroing is an error here, not something to patch up on top of (or racing with) the
+        collective's output (advisor, round 3). Only the dirty-flag bookkeeping runs."""
+        if already_reduced:
+            for n, p, _ in self.params:
+                if not p.requires_grad:
+                    continue
+                if p.grad is not None:
+                    raise RuntimeError(f"{self.name}: {n} received an autograd gradient after the unit's reduce-scatter was launched")
+                if not p._mg_touched and any(getattr(p, "_mg_regions", {}).values()):
+                    p._mg_touched = True
+                if not p._mg_touched and p._mg_dirty:
+                    raise RuntimeError(f"{self.name}: {n} holds a stale gradient that was reduced with this step's (untouched this step, "
+                                       "but the unit's reduce-scatter fired from its backward hook)")
+                if p._mg_touched:
+                    p._mg_dirty = True
+            return
         self.collect_autograd_grads()
         for _, p, _ in self.params:
             if p.requires_grad:
@@ -324,6 +343,7 @@ class ShardedModel:
         # forward reaching the layer in front, low stream priority, grid capped to 128..1024 workgroups -- never changed the step
         # time: the GEMMs slow down by exactly the AdamW time hidden (the chip is power-bound either way), so it stays inline.
         self.comm_stream = self.ops.stream(device) if self.coll else None
+        self.wait_profile = None      # list of (kind, event, event) when a caller wants the main stream's collective stalls timed
         # consumption: a unit's forward waits for ITS all-gather only, so later layers keep streaming in behind the forward pass
         # instead of being waited for up front. Units without a module (root: embeddings, heads, embedders) are waited for in
         # begin_step AND by a pre-hook on every module that directly owns one of their parameters, so an eval forward /
@@ -394,9 +414,32 @@ class ShardedModel:
             dist.all_gather(parts, shard.clone(), group=self.pg)
             region.copy_(torch.cat(parts))
 
+    def _timed_wait(self, kind: str, event) -> None:
+        """main stream waits for `event`; with ``wait_profile`` set (bench.py --gpus N) the stall is bracketed by two events on the
+        main stream, so the first multi-GPU run says how long the compute stream sat behind each kind of collective."""
+        cur = torch.cuda.current_stream(self.device)
+        prof = self.wait_profile
+        if prof is None:
+            cur.wait_event(event)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        cur.wait_event(event)
+        e1.record(cur)
+        prof.append((kind, e0, e1))
+
+    def wait_profile_ms(self) -> Dict[str, float]:
+        """Sum of the recorded stalls per kind (ms); clears the list. Call after a device synchronisation."""
+        out: Dict[str, float] = {}
+        for kind, e0, e1 in (self.wait_profile or []):
+            out[kind] = out.get(kind, 0.0) + e0.elapsed_time(e1)
+        if self.wait_profile is not None:
+            self.wait_profile = []
+        return out
+
     def wait_unit(self, u: FlatUnit):
         if u.gather_event is not None and u.gather_event is not True:
-            torch.cuda.current_stream(self.device).wait_event(u.gather_event)
+            self._timed_wait("gather_event", u.gather_event)
         u.gather_event = None
 
     def wait_all(self):
@@ -428,7 +471,7 @@ class ShardedModel:
             self.wait_all()   # normally long satisfied (every used unit waited in its forward)
         for u in self.units:
             if u.trainable:
-                u.finish_backward()
+                u.finish_backward(already_reduced=u.rs_event is not None)
         if self.coll:
             for u in self.units:
                 if u.trainable and u.rs_event is None:
@@ -437,7 +480,7 @@ class ShardedModel:
                 cur = torch.cuda.current_stream(self.device)
                 for u in self.units:
                     if u.trainable and u.rs_event is not None and u.rs_event is not True:
-                        cur.wait_event(u.rs_event)
+                        self._timed_wait("rs_event", u.rs_event)
 
     def grad_norm_and_clip(self, max_norm: Optional[float]):
         """Global L2 norm over the reduced gradient shards (+ scalar all-reduce), clip coefficient kept on device."""

@@ -93,7 +93,7 @@ _SIGNATURES = {
 
 def exported_symbols():
     """Names every build of libmla_hip.so must export (checked by the CPU test-suite)."""
-    return sorted(list(_SIGNATURES.keys()) + ["mla_last_error"] + list(_EXTRA_SIGNATURES.keys()))
+    return sorted(list(_SIGNATURES.keys()) + ["mla_last_error", "mla_gemm_source_id"] + list(_EXTRA_SIGNATURES.keys()))
 
 
 _EXTRA_SIGNATURES = {}  # filled by optional kernel groups (pointcloud / vision) below
@@ -120,6 +120,8 @@ def lib():
         L = ctypes.CDLL(_LIB_PATH)
         L.mla_last_error.restype = ctypes.c_char_p
         L.mla_last_error.argtypes = []
+        L.mla_gemm_source_id.restype = ctypes.c_char_p
+        L.mla_gemm_source_id.argtypes = []
         for name, argt in {**_SIGNATURES, **_EXTRA_SIGNATURES}.items():
             fn = getattr(L, name)
             fn.argtypes = argt
@@ -127,6 +129,11 @@ def lib():
         L.mla_attn_bwd_ws_bytes.restype = c_longlong
         _lib = L
     return _lib
+
+
+def gemm_source_id() -> str:
+    """sha256[:16] over the gemm256 kernel family's sources the loaded library was built from (build.sh stamps it)."""
+    return lib().mla_gemm_source_id().decode()
 
 
 def _stream():
@@ -691,6 +698,7 @@ def gather_rows(src2d, idx, out_rows=None, scatter=False):
     if scatter:
         out = torch.zeros((out_rows, H), dtype=torch.bfloat16, device=src2d.device)
     elif out_rows is not None and out_rows != n:
+        assert out_rows >= n, f"gather_rows: out_rows={out_rows} < len(idx)={n} (the kernel writes len(idx) rows)"
         out = torch.zeros((out_rows, H), dtype=torch.bfloat16, device=src2d.device)
     else:
         out = torch.empty((n, H), dtype=torch.bfloat16, device=src2d.device)

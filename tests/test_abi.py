@@ -85,10 +85,18 @@ def test_kloop_checker_flags_an_accumulator_touch_between_two_statements(tmp_pat
     always is."""
     import subprocess
     import sys
-    head = "_ZN1x14gemm256_kernelILi0ELi0ELi0ELb1EEEv8GemmArgs:\n\ts_load_dword s0, s[0:1], 0x0\nv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]\n"
-    cases = {"two_statements": (head + "\tv_accvgpr_write_b32 a5, v1\nv_accvgpr_read_b32 v4, a64\n\ts_endpgm\n.Lfunc_end0:\n", 1),
-             "one_statement": (head + "\tv_accvgpr_write_b32 a5, v1\n\ts_endpgm\n.Lfunc_end0:\n", 0),
-             "spill": (head + "\tscratch_store_dword off, v1, s0\n\ts_endpgm\n.Lfunc_end0:\n", 1)}
+    mfma = "v_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]\n"
+    def head(epi, n_mfma=128, indent=""):
+        return (f"_ZN1x14gemm256_kernelILi0ELi0ELi{epi}ELb1EEEv8GemmArgs:\n\ts_load_dword s0, s[0:1], 0x0\n" + (indent + mfma) * n_mfma)
+    tail = "\ts_endpgm\n.Lfunc_end0:\n"
+    cases = {"two_statements": (head(0) + "\tv_accvgpr_write_b32 a5, v1\nv_accvgpr_read_b32 v4, a64\n" + tail, 1),
+             "two_statements_clean": (head(0) + "\tv_mov_b32 v5, v1\nv_accvgpr_read_b32 v4, a64\n" + tail, 0),
+             "one_statement": (head(1) + "\tv_accvgpr_write_b32 a5, v1\n" + tail, 0),
+             "spill": (head(1) + "\tscratch_store_dword off, v1, s0\n" + tail, 1),
+             # advisor (round 3): the checks must not pass vacuously when the listing format hides the inline assembly
+             "plain_kernel_with_one_statement": (head(0) + "\tv_mov_b32 v5, v1\n" + tail, 1),
+             "indented_inline_asm": (head(1, indent="\t") + tail, 1),
+             "too_few_mfma_in_asm": (head(1, n_mfma=8) + tail, 1)}
     for name, (src, want) in cases.items():
         f = tmp_path / (name + ".s")
         f.write_text(src)

@@ -16,11 +16,22 @@ import sys
 def main(path):
     agpr = re.compile(r"(?<![\w.])a(\[\d+:\d+\]|\d+)\b|accvgpr")
     bad, seen = [], 0
-    fn, cand, statements, prev_asm = None, [], 0, False
+    fn, cand, statements, prev_asm, mfma_in_asm = None, [], 0, False, 0
+    # the generated main loop issues 64 MFMAs per K-tile and is unrolled over two K-tiles plus the peeled last pair: a detected asm
+    # region with fewer than this many v_mfma lines means the column-0 / tab heuristic below no longer tells the two apart
+    MIN_MFMA = 128
 
     def close():
-        if fn is not None and statements >= 2:
+        if fn is None:
+            return
+        if statements >= 2:
             bad.extend(cand)
+        # advisor (round 3): if a future hipcc indents inline asm, `statements` stays 0 and every check above passes vacuously
+        need = 2 if "Li0ELb1EEE" in fn else 1          # the plain kernel (EPI 0) has the second statement for the fp32 half
+        if statements < need:
+            bad.append((fn, 0, f"only {statements} inline-asm statement(s) detected, expected >= {need}: the assembly listing format changed?"))
+        if mfma_in_asm < MIN_MFMA:
+            bad.append((fn, 0, f"only {mfma_in_asm} v_mfma lines inside the detected inline-asm regions, expected >= {MIN_MFMA}"))
 
     for n, ln in enumerate(open(path), 1):
         m = re.match(r"^(_Z\w*gemm256_kernel\w*):", ln)
@@ -28,7 +39,7 @@ def main(path):
             close()
             fn = m.group(1) if "ELb1EEE" in m.group(1) else None
             seen += fn is not None
-            cand, statements, prev_asm = [], 0, False
+            cand, statements, prev_asm, mfma_in_asm = [], 0, False, 0
             continue
         if fn is None:
             continue
@@ -50,6 +61,7 @@ def main(path):
             if not prev_asm:
                 statements += 1
             prev_asm = True
+            mfma_in_asm += s.startswith("v_mfma")
     close()
     for f, n, s in bad:
         print(f"{path}:{n}: {f}: accumulator register / scratch access outside the inline assembly: {s}")

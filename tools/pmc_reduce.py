@@ -4,7 +4,9 @@ Population (round 3): launches of the PLAIN instantiation gemm256_kernel<0,0,0> 
 333 launches per step >= 0.1 TFLOP that bench.py's roofline object averages over and drops the 17 small ones).
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE is in KiB and reports half the bytes of wide coalesced reads on gfx950 -> x 1024 x 2;
 WRITE_SIZE x 1024 (uncalibrated). Both are fabric-side (L2 <-> Infinity Cache / HBM) counters: Infinity-Cache hits are included."""
-import csv, json, re, sys, datetime
+import csv, json, os, re, sys, datetime
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mla_amd import hip   # the library the counters were collected on (same tree, same call): its gemm256 source id goes into the record
 
 PLAIN = r"gemm256_kernel<0, ?0, ?0(, ?(true|false))?>"     # the plain instantiation only: the population bench.py's algorithmic_bytes_per_launch is over
 
@@ -31,6 +33,7 @@ if len(sys.argv) > 5:
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 1 --warmup 1`, gemm256_kernel<0,0,0> launches >= {min_us:.0f} us",
        "tcc_hit_rate": hit_rate,
        "collected": datetime.date.today().isoformat(),
+       "gemm_source_id": hip.gemm_source_id(),
        "corrections": "FETCH_SIZE x 1024 B x 2 (gfx950 counts 128-B requests as 64 B); WRITE_SIZE x 1024 B (uncalibrated)",
        "launches": nf, "avg_launch_us": fus, "fetch_size_kb_avg": fkb, "write_size_kb_avg": wkb,
        "hbm_read_bytes_per_launch": fkb * 1024 * 2, "hbm_write_bytes_per_launch": wkb * 1024,
