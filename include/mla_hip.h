@@ -213,9 +213,10 @@ int mla_colstats_bf16(const void* x, float* mean, float* var, long long rows, in
 int mla_bn_apply(const void* x, const float* mean, const float* var, const void* w, const void* b, const void* res, void* y,
                  long long rows, int C, float eps, int relu, mla_stream_t stream);
 int mla_maxpool_k(const void* x, void* out, long long groups, int K, int C, mla_stream_t stream);
-/* backward of the two (trainable point tokenizer, stage "pretrain" with use_pointcloud): feature gradient of lga_prep (fp32 atomics
- * into a zero-initialised [B, N, C] buffer) and of the max over the K neighbours (first maximum) */
-int mla_lga_prep_bwd(const void* drows, const long long* fps_idx, const int* knn, float* dfeats_zeroed, int B, int N, int G, int K, int C,
+/* backward of the two (trainable point tokenizer, stage "pretrain" with use_pointcloud): feature gradient of lga_prep -- a gather per
+ * target point with every sum in a fixed order (deterministic, no atomics; every element of dfeats [B, N, C] fp32 is written) -- and
+ * of the max over the K neighbours (first maximum). Reference: models/mla/pointcloud/backbone/Point_PN.py:115-158 (autograd of LGA). */
+int mla_lga_prep_bwd(const void* drows, const long long* fps_idx, const int* knn, float* dfeats, int B, int N, int G, int K, int C,
                      mla_stream_t stream);
 int mla_maxpool_k_bwd(const void* x, const void* dy, void* dx, long long groups, int K, int C, mla_stream_t stream);
 

@@ -231,23 +231,71 @@ __global__ __launch_bounds__(256) void lga_prep_vec_kernel(const float* __restri
 }
 
 // backward of lga_prep w.r.t. the point features (coordinates carry no gradient: the positional embedding is a constant):
-//   dfeats[b][knn[b,g,k]][c] += drows[(b,g,k)][c]        dfeats[b][centre(b,g)][c] += sum_k drows[(b,g,k)][C + c]
-// fp32 atomics into a zero-initialised [B, N, C] buffer (a point is the neighbour of many groups)
+//   dfeats[b][n][c] = sum over the groups g whose kNN list holds n (at position k)  drows[(b,g,k)][c]
+//                   + sum_k drows[(b,g,k)][C + c]   for the group g whose centre is n (FPS indices are distinct: at most one)
+// GATHER form, one workgroup per target point (round 4): every sum runs in a fixed order (ascending g, then ascending k), so the
+// gradient of the trainable point tower is bit-reproducible -- the round-1..3 kernel scattered with fp32 atomicAdd in arrival order.
+// All threads scan the batch's G*K indices coalesced (L2-resident, 166 KB at G = 512, K = 81) and set bit k of group g's 128-bit
+// hit mask (integer LDS atomics: order-independent); wave 0 compacts the groups with a hit, wave 1 the groups whose centre is n, in
+// ascending order; then every thread owns channels and adds the listed rows. Writes every element of dfeats (no zero-initialised
+// buffer needed). A true kNN list holds a point at most once per group; repeated indices are handled all the same. K <= 128.
 __global__ __launch_bounds__(256) void lga_prep_bwd_kernel(const bf16_t* __restrict__ drows, const long long* __restrict__ fps_idx,
                                                            const int* __restrict__ knn, float* __restrict__ dfeats, int N, int G, int K,
                                                            int C) {
-  const int bg = blockIdx.x, b = bg / G, tid = threadIdx.x;
-  const int ci = (int)fps_idx[bg];
+  extern __shared__ int lga_sh[];               // mask[4 G] | list[G] | clist[G] | counts[2]
+  unsigned* mask = (unsigned*)lga_sh;
+  int* list = lga_sh + 4 * G;
+  int* clist = lga_sh + 5 * G;
+  int* misc = lga_sh + 6 * G;
+  const int bn = blockIdx.x, b = bn / N, n = bn % N, tid = threadIdx.x;
   const int OD = 2 * C;
-  float* fb = dfeats + (size_t)b * N * C;
-  for (int e = tid; e < K * C; e += 256) {
-    const int kk = e / C, ch = e % C;
-    atomicAdd(fb + (size_t)knn[(size_t)bg * K + kk] * C + ch, bf2f(drows[((size_t)bg * K + kk) * OD + ch]));
+  for (int i = tid; i < 4 * G; i += 256) mask[i] = 0u;
+  __syncthreads();
+  const int* kb = knn + (size_t)b * G * K;
+  const int total = G * K;
+  for (int e = tid; e < total; e += 256)
+    if (kb[e] == n) {
+      const int g = e / K, k = e - g * K;
+      atomicOr(&mask[g * 4 + (k >> 5)], 1u << (k & 31));
+    }
+  __syncthreads();
+  if (tid < 128) {                              // ordered compaction, one wave each: groups with a neighbour hit, groups centred on n
+    const bool nb = tid < 64;
+    const int lane = tid & 63;
+    int cnt = 0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+      const int g = g0 + lane;
+      bool on = false;
+      if (g < G) on = nb ? ((mask[g * 4] | mask[g * 4 + 1] | mask[g * 4 + 2] | mask[g * 4 + 3]) != 0u) : ((int)fps_idx[(size_t)b * G + g] == n);
+      const unsigned long long m = __ballot(on);
+      if (on) (nb ? list : clist)[cnt + __popcll(m & ((1ull << lane) - 1ull))] = g;
+      cnt += __popcll(m);
+    }
+    if (lane == 0) misc[nb ? 0 : 1] = cnt;
   }
+  __syncthreads();
+  const int cnt = misc[0], ccnt = misc[1];
+  const bf16_t* db = drows + (size_t)b * G * K * OD;
   for (int ch = tid; ch < C; ch += 256) {
-    float s = 0.f;
-    for (int kk = 0; kk < K; ++kk) s += bf2f(drows[((size_t)bg * K + kk) * OD + C + ch]);
-    atomicAdd(fb + (size_t)ci * C + ch, s);
+    float acc = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+      const int g = list[i];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned m = mask[g * 4 + w];
+        while (m) {                              // ascending k; the order is part of the result
+          const int k = w * 32 + __ffs((int)m) - 1;
+          m &= m - 1;
+          acc += bf2f(db[((size_t)g * K + k) * OD + ch]);
+        }
+      }
+    }
+    for (int j = 0; j < ccnt; ++j) {
+      float s = 0.f;
+      for (int kk = 0; kk < K; ++kk) s += bf2f(db[((size_t)clist[j] * K + kk) * OD + C + ch]);
+      acc += s;
+    }
+    dfeats[((size_t)b * N + n) * C + ch] = acc;
   }
 }
 
@@ -486,10 +534,12 @@ extern "C" int mla_gather_rows_f32(const float* src, const long long* idx, float
 }
 
 // backward kernels of the point tokenizer (stage "pretrain" with use_pointcloud: Point_PN.py:115-158 LGA, :166-169 Pooling)
-extern "C" int mla_lga_prep_bwd(const void* drows, const long long* fps_idx, const int* knn, float* dfeats_zeroed, int B, int N, int G,
+extern "C" int mla_lga_prep_bwd(const void* drows, const long long* fps_idx, const int* knn, float* dfeats, int B, int N, int G,
                                 int K, int C, hipStream_t stream) {
-  MLA_CHECK_ARG(drows && fps_idx && knn && dfeats_zeroed, "mla_lga_prep_bwd: null pointer");
-  hipLaunchKernelGGL(lga_prep_bwd_kernel, dim3(B * G), dim3(256), 0, stream, (const bf16_t*)drows, fps_idx, knn, dfeats_zeroed, N, G, K, C);
+  MLA_CHECK_ARG(drows && fps_idx && knn && dfeats, "mla_lga_prep_bwd: null pointer");
+  MLA_CHECK_ARG(B > 0 && N > 0 && G > 0 && K > 0 && C > 0 && K <= 128 && (size_t)(6 * G + 2) * sizeof(int) <= 48 * 1024, "mla_lga_prep_bwd: bad shape (K <= 128, G <= 2047)");
+  hipLaunchKernelGGL(lga_prep_bwd_kernel, dim3(B * N), dim3(256), (6 * G + 2) * sizeof(int), stream, (const bf16_t*)drows, fps_idx, knn,
+                     dfeats, N, G, K, C);
   MLA_LAUNCH_CHECK();
 }
 extern "C" int mla_maxpool_k_bwd(const void* x, const void* dy, void* dx, long long groups, int K, int C, hipStream_t stream) {

@@ -1010,7 +1010,7 @@ def clip_preprocess(img_u8, bounds_h, coef_h, bounds_v, coef_v, OH, OW, mean, st
 
 def lga_prep_bwd(drows, fps_idx, knn_idx, B, N, C):
     G, K = knn_idx.shape[1], knn_idx.shape[2]
-    dfeats = torch.zeros((B, N, C), dtype=torch.float32, device=drows.device)
+    dfeats = torch.empty((B, N, C), dtype=torch.float32, device=drows.device)    # every element is written (gather form)
     call("mla_lga_prep_bwd", _p(drows), _p(fps_idx), _p(knn_idx), _p(dfeats), B, N, G, K, C)
     return dfeats
 

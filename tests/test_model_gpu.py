@@ -330,7 +330,8 @@ def test_mla_e2e_against_oracle_flash_semantics(dev):
 def test_full_size_step_is_deterministic_and_consistent(dev):
     """BASELINE configs[1] at full size (7B, 8 samples x 4 repeats x 548 tokens; what bench.py times): properties that need no CPU
     reference -- the WHOLE step is bit-reproducible (same batch, zero learning rate -> the same loss, the same gradient norm and
-    bit-equal fp32 gradient buffers: no atomics anywhere on the path; the contrastive row gather with repeated targets sums its
+    bit-equal fp32 gradient buffers: no floating-point atomics anywhere in the library (round 4: the point tower's lga_prep backward is a
+    fixed-order gather too, tests/test_pretrain_gpu.py::test_pretrain_point_tower_step_is_bit_reproducible); the contrastive row gather with repeated targets sums its
     duplicates in a fixed order, ops.GatherRowsSumFn), the global gradient norm equals the norm over the per-unit fp32 gradient buffers, the loss dict carries the reference's
     seven keys with `diff_loss` aliasing `total_loss`, and clipping scales the update (coefficient = 1 / norm for norm > 1)."""
     import math
