@@ -74,29 +74,97 @@ def _round_up(n, m):
     return ((n + m - 1) // m) * m
 
 
+def default_no_decay(n: str, p) -> bool:
+    """The reference's two AdamW parameter groups (training/strategies/fsdp.py:236-256): vectors and biases are not decayed."""
+    return p.ndim <= 1 or n.endswith(".bias")
+
+
+def plan_flat_layout(named_params: Sequence[Tuple[str, nn.Parameter]], world: int, no_decay: Callable = default_no_decay):
+    """Where every parameter of ONE sharding unit sits in the unit's flat buffers -- pure arithmetic on shapes and requires_grad (works
+    on meta-device modules): returns ``(params, n_decay, n_train, n_total)`` with ``params = [(name, parameter, element offset)]``.
+    Order: [trainable & decayed | trainable & not decayed | frozen], each in module order (keeps q|k|v and gate|up adjacent); every
+    tensor starts on an 8-element boundary (16 B in bf16, 32 B in fp32) and every region ends on a multiple of 8 x world, so that a
+    1/world shard of the trainable or of the frozen region starts 16-B aligned in bf16 on every rank."""
+    decay = [(n, p) for n, p in named_params if p.requires_grad and not no_decay(n, p)]
+    nodecay = [(n, p) for n, p in named_params if p.requires_grad and no_decay(n, p)]
+    frozen = [(n, p) for n, p in named_params if not p.requires_grad]
+    align = 8 * world
+    params: List[Tuple[str, nn.Parameter, int]] = []
+    off = 0
+    bounds = []
+    for group in (decay, nodecay, frozen):
+        for n, p in group:
+            params.append((n, p, off))
+            off += _round_up(p.numel(), 8)
+        off = _round_up(off, align)
+        bounds.append(off)
+    return params, bounds[0], bounds[1], bounds[2]
+
+
+def discover_units(model: nn.Module, unit_policy: Callable[[nn.Module], bool]):
+    """The sharding units of a model in the order ShardedModel creates them: ``[(unit name, module or None, [(param name, param)])]``.
+    Outermost matches of the policy are units; what no unit claims folds into the root unit; forward order = non-decoder units, root
+    (the embeddings are needed first), decoder layers."""
+    unit_mods: List[Tuple[str, nn.Module]] = []
+
+    def walk(prefix, mod):
+        for cn, child in mod.named_children():
+            full = f"{prefix}.{cn}" if prefix else cn
+            if unit_policy(child):
+                unit_mods.append((full, child))
+            else:
+                walk(full, child)
+    walk("", model)
+    claimed = set()
+    pending = []
+    for name, mod in unit_mods:
+        named = [(f"{name}.{n}", p) for n, p in mod.named_parameters() if id(p) not in claimed]
+        claimed.update(id(p) for _, p in named)
+        pending.append((name, mod, named))
+    root_named = [(n, p) for n, p in model.named_parameters() if id(p) not in claimed]
+    early = [x for x in pending if not hasattr(x[1], "self_attn")]
+    layers = [x for x in pending if hasattr(x[1], "self_attn")]
+    out = list(early)
+    if root_named:
+        out.append(("<root>", None, root_named))
+    out.extend(layers)
+    return [x for x in out if x[2]]
+
+
+def plan_sharded_layout(model: nn.Module, unit_policy: Callable[[nn.Module], bool], world: int, no_decay: Callable = default_no_decay,
+                        inplace_reduce: bool = True):
+    """Per-unit layout and per-rank memory of ``ShardedModel(model, unit_policy)`` at ``world`` ranks WITHOUT allocating anything (the
+    model may live on the meta device): the audit the 8-GPU run is planned with. Bytes per rank and unit:
+    bf16 replica (whole unit: the all-gathered weights stay resident), fp32 gradient buffer (whole trainable region: the in-place
+    reduce-scatter leaves the rank's shard inside it), fp32 master + two AdamW moments (1/world of the trainable region), fp32
+    master of the frozen region (1/world). ``inplace_reduce=False`` adds the separate fp32 gradient shard of the gloo / AVG path."""
+    units = []
+    for name, mod, named in discover_units(model, unit_policy):
+        params, n_decay, n_train, n_total = plan_flat_layout(named, world, no_decay)
+        shard_train, shard_frozen = n_train // world, (n_total - n_train) // world
+        ranges = []
+        for rank in range(world):
+            lo, hi = rank * shard_train, (rank + 1) * shard_train
+            ranges.append([(max(a, lo) - lo, min(b, hi) - lo, max(a, lo), dec) for a, b, dec in ((0, n_decay, True), (n_decay, n_train, False))
+                           if min(b, hi) > max(a, lo)])
+        units.append(dict(name=name, is_layer=mod is not None and hasattr(mod, "self_attn"), params=params, n_decay=n_decay, n_train=n_train,
+                          n_total=n_total, shard_train=shard_train, shard_frozen=shard_frozen, shard_ranges=ranges,
+                          bytes_bf16_replica=2 * n_total, bytes_grad32=4 * n_train,
+                          bytes_master=4 * (shard_train + shard_frozen), bytes_moments=8 * shard_train,
+                          bytes_grad_shard=0 if (inplace_reduce or world == 1) else 4 * shard_train))
+    return units
+
+
 class FlatUnit:
     """One sharding unit. Parameter order inside the flat buffers: [trainable & decayed | trainable & not decayed |
-    frozen], each in module order (keeps q|k|v and gate|up adjacent), every tensor padded to 8 elements."""
+    frozen], each in module order (keeps q|k|v and gate|up adjacent), every tensor padded to 8 elements (plan_flat_layout)."""
 
     def __init__(self, name: str, named_params: Sequence[Tuple[str, nn.Parameter]], device, world: int, rank: int, ops,
                  no_decay: Callable[[str, nn.Parameter], bool], process_group=None, sync_from_rank0: bool = True,
                  collectives: Optional[bool] = None, inplace_reduce: bool = False):
         self.name, self.world, self.rank, self.ops, self.device = name, world, rank, ops, device
         coll = (world > 1) if collectives is None else collectives   # separate shard buffers + real collectives
-        decay = [(n, p) for n, p in named_params if p.requires_grad and not no_decay(n, p)]
-        nodecay = [(n, p) for n, p in named_params if p.requires_grad and no_decay(n, p)]
-        frozen = [(n, p) for n, p in named_params if not p.requires_grad]
-        align = 8 * world
-        self.params: List[Tuple[str, nn.Parameter, int]] = []
-        off = 0
-        bounds = []
-        for group in (decay, nodecay, frozen):
-            for n, p in group:
-                self.params.append((n, p, off))
-                off += _round_up(p.numel(), 8)
-            off = _round_up(off, align)
-            bounds.append(off)
-        self.n_decay, self.n_train, self.n_total = bounds[0], bounds[1], bounds[2]
+        self.params, self.n_decay, self.n_train, self.n_total = plan_flat_layout(named_params, world, no_decay)
         self.shard_total = self.n_total // world
         self.shard_train = self.n_train // world
         self.trainable = self.n_train > 0
@@ -289,35 +357,12 @@ class ShardedModel:
         # (inplace_reduce=True with gloo is for the CPU tests: it runs the same SUM-shard bookkeeping over an in-place all-reduce)
         self.inplace_reduce = bool(self.coll and (dist.get_backend(process_group) == "nccl" if inplace_reduce is None else inplace_reduce))
         self.grad_div = float(self.world) if self.inplace_reduce else 1.0     # gshard holds grad_div x the mean gradient
-        no_decay = no_decay or (lambda n, p: p.ndim <= 1 or n.endswith(".bias"))   # fsdp.py:236-256
-        # ---- unit discovery (outermost matches of the policy; the remainder folds into the root unit)
-        unit_mods: List[Tuple[str, nn.Module]] = []
-
-        def walk(prefix, mod):
-            for cn, child in mod.named_children():
-                full = f"{prefix}.{cn}" if prefix else cn
-                if unit_policy(child):
-                    unit_mods.append((full, child))
-                else:
-                    walk(full, child)
-        walk("", model)
-        claimed = set()
+        no_decay = no_decay or default_no_decay   # fsdp.py:236-256
+        # ---- unit discovery (outermost matches of the policy; the remainder folds into the root unit); forward order: non-decoder
+        # units and the root first (embeddings are needed first), decoder layers after -- discover_units()
         self.units: List[FlatUnit] = []
         self.unit_of_module: Dict[int, FlatUnit] = {}
-        pending = []
-        for name, mod in unit_mods:
-            named = [(f"{name}.{n}", p) for n, p in mod.named_parameters() if id(p) not in claimed]
-            claimed.update(id(p) for _, p in named)
-            pending.append((name, mod, named))
-        root_named = [(n, p) for n, p in model.named_parameters() if id(p) not in claimed]
-        # forward order: non-decoder units and the root first (embeddings are needed first), decoder layers after
-        early = [x for x in pending if not hasattr(x[1], "self_attn")]
-        layers = [x for x in pending if hasattr(x[1], "self_attn")]
-        for name, mod, named in early:
-            self._add_unit(name, mod, named, no_decay)
-        if root_named:
-            self._add_unit("<root>", None, root_named, no_decay)
-        for name, mod, named in layers:
+        for name, mod, named in discover_units(model, unit_policy):
             self._add_unit(name, mod, named, no_decay)
         # buffers (BatchNorm statistics, ...) just move to the device in fp32 (FSDP buffer_dtype fp32)
         for b in model.buffers():
