@@ -210,8 +210,11 @@ def main():
     dev_index = local_rank if local_rank < ndev else 0      # one-visible-device-per-rank launchers: every rank's device is index 0
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    coll_knobs = {}
     if world > 1 or "RANK" in os.environ:       # launched through torch.distributed.run (also with --gpus 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from mla_amd.fsdp import apply_rccl_env
+        coll_knobs = apply_rccl_env()           # MLA_RCCL_MAX_CHANNELS / MLA_GEMM_CUS / MLA_FSDP_INPLACE_RS
         dist.init_process_group("nccl", device_id=device)
 
     from mla_amd import hip
@@ -401,6 +404,7 @@ def main():
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
         if per_rank:
             out["per_rank"] = per_rank
+            out["collective_knobs"] = {**coll_knobs, "inplace_reduce_scatter": bool(strat.sharded.inplace_reduce), "gemm_planned_cus": hip.gemm_cus() or "device"}
         if roof:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:

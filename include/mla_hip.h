@@ -59,6 +59,11 @@ int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes);   /* partial
  * only queries. Returns the mode in force. Results are bit-identical either way -- the switch exists for A/B measurements and tests.
  * Environment MLA_GEMM_KLOOP=0 sets the initial mode. */
 int mla_gemm_kloop(int mode);
+/* CUs the GEMM launches plan their rounds for (split-K tail of the last, partially filled round): n >= 8 and a multiple of 8 = plan
+ * for n CUs (multi-GPU runs: the CUs RCCL's kernels leave free), 0 = the device's count (default; also MLA_GEMM_CUS in the
+ * environment), n < 0 = query. Returns the setting in force, -1 for a bad argument. It only changes which tiles are split along K:
+ * results agree to fp32 rounding across settings and are deterministic for a given one (K-slices are summed in a fixed order). */
+int mla_gemm_cus(int n);
 int mla_gemm_bf16_ws_sq(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
                         float alpha, float* workspace, size_t workspace_bytes, float* sq_out, int sq_capacity, int* sq_slots,
                         mla_stream_t stream);
@@ -288,6 +293,12 @@ int mla_imgroi_bwd(const void* delta_raw, int ld, const void* a_raw, int lda, co
                    float* doff_raw, int B, int CT_curr, int CT_next, int HW, int ps, float clip, float shift, mla_stream_t stream);
 int mla_imgloss_bwd(const void* delta_raw, int ld, const void* curr, const void* next, int img_fp32, const float* gscale,
                     void* ddelta_raw, int B, int CT_curr, int CT_next, int HW, int ps, float clip, mla_stream_t stream);
+
+/* ---- multi-GPU rehearsal (no reference counterpart): stand-in for a collective's kernel on a side stream -- `blocks` resident
+ * 1024-thread workgroups stream out = a + b over n fp32 (n % 4 == 0), sleeping `sleep_ticks` x 8128 clocks after every 64 KiB chunk; lds_bytes =
+ * 163840 makes each workgroup the only resident of its CU (the CU is taken from a gemm256 workgroup), 0 lets it share the CU.
+ * tools/contention_rehearsal.py measures the training step's sensitivity to it (profiles/r4_contention.txt). */
+int mla_side_traffic(const float* a, const float* b, float* out, long long n, int blocks, int lds_bytes, int sleep_ticks, mla_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1182,6 +1182,19 @@ inline int choose_split(int tiles, int ncu, int nt, size_t ws_bytes, int* full_o
   return best;
 }
 
+// Number of CUs the launches plan their rounds for (split-K tail: tiles of the last, partially filled round of `ncu` workgroups).
+// Default = the device's CU count; mla_gemm_cus(n) / MLA_GEMM_CUS=n plan for n (a multiple of 8) instead -- the knob for the multi-GPU
+// run, where RCCL's kernels hold some CUs for most of the backward and a "round" is what is actually free.
+int g_ncu_plan = -1;
+int planned_cus(int device_cus) {
+  if (g_ncu_plan < 0) {
+    const char* e = getenv("MLA_GEMM_CUS");
+    const int v = e ? atoi(e) : 0;
+    g_ncu_plan = (v >= 8 && v % 8 == 0) ? v : 0;
+  }
+  return (g_ncu_plan > 0 && g_ncu_plan < device_cus) ? g_ncu_plan : device_cus;
+}
+
 // Main loop of the k-contiguous instantiations: 1 = hand-scheduled assembly (default), 0 = compiler-scheduled. Both give the same bits;
 // MLA_GEMM_KLOOP=0 in the environment or mla_gemm_kloop(0) select the compiler's (A/B measurements, tests).
 int g_kloop = -1;
@@ -1362,6 +1375,17 @@ extern "C" int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const vo
 // instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.
 // number of sum-of-squares partials a k-contiguous fp32-output launch of this shape writes (whole tiles + 64 per split tile): lets the
 // caller reserve exactly that many floats in a shared buffer and sum the whole buffer in one launch afterwards
+// n >= 8 (a multiple of 8): plan the split-K tails for n CUs; n == 0: back to the device's CU count; n < 0: query. Returns the value in
+// force (0 = device count), -1 for a bad argument. Set it before the work starts (not synchronised with concurrent launches).
+extern "C" int mla_gemm_cus(int n) {
+  if (n >= 0) {
+    if (n != 0 && (n < 8 || n % 8 != 0 || n > 1024)) return -1;
+    g_ncu_plan = n;
+  } else if (g_ncu_plan < 0) {
+    (void)planned_cus(1 << 20);
+  }
+  return g_ncu_plan;
+}
 extern "C" int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes) {
   if (M < 256 || N < 256 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return -1;
   int ncu = 0, dev = 0;
@@ -1371,7 +1395,7 @@ extern "C" int mla_gemm_sq_slots(int M, int N, int K, size_t workspace_bytes) {
   const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
   if (workspace_bytes) {
     int full = 0;
-    const int s = choose_split(tiles, ncu, K / 64, workspace_bytes, &full);
+    const int s = choose_split(tiles, planned_cus(ncu), K / 64, workspace_bytes, &full);
     if (s > 1 && full % 8 == 0) return full + (tiles - full) * 64;
   }
   return tiles;
@@ -1420,7 +1444,7 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   }
   if (p.sk_ws && ws_bytes) {
     int full = 0;
-    const int s = choose_split(tiles, ncu, p.K / 64, ws_bytes, &full);
+    const int s = choose_split(tiles, planned_cus(ncu), p.K / 64, ws_bytes, &full);
     if (s > 1 && full % 8 == 0) { p.sk_split = s; p.sk_full = full; }
   }
   // persistent walk when there is more than one round of tiles and the operands fit 31-bit byte offsets (buffer addressing)

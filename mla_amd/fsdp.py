@@ -74,6 +74,26 @@ def _round_up(n, m):
     return ((n + m - 1) // m) * m
 
 
+def apply_rccl_env(environ=None) -> Dict[str, str]:
+    """Knobs for the collectives' footprint on the chip, to be applied BEFORE the process group is created (bench.py does; a training
+    script would call it next to its init_process_group). RCCL's kernels run on the side stream underneath the backward GEMMs, which
+    launch one 512-thread workgroup per CU: every CU a channel occupies is a CU the GEMM rounds do not get.
+      MLA_RCCL_MAX_CHANNELS=n  -> NCCL_MAX_NCHANNELS=n (RCCL honours the NCCL_* names): caps the workgroups per collective kernel;
+      MLA_GEMM_CUS=n           -> read by libmla_hip.so itself: the GEMMs plan their split-K tails for n CUs instead of all of them.
+    Returns what was set (for the bench line)."""
+    import os as _os
+    env = _os.environ if environ is None else environ
+    done = {}
+    v = env.get("MLA_RCCL_MAX_CHANNELS")
+    if v:
+        env["NCCL_MAX_NCHANNELS"] = str(int(v))
+        done["NCCL_MAX_NCHANNELS"] = env["NCCL_MAX_NCHANNELS"]
+    for k in ("MLA_GEMM_CUS", "MLA_FSDP_INPLACE_RS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
+        if env.get(k) is not None:
+            done[k] = env[k]
+    return done
+
+
 def default_no_decay(n: str, p) -> bool:
     """The reference's two AdamW parameter groups (training/strategies/fsdp.py:236-256): vectors and biases are not decayed."""
     return p.ndim <= 1 or n.endswith(".bias")
@@ -355,6 +375,10 @@ class ShardedModel:
         self.ops = ops if ops is not None else HipLocalOps()
         # RCCL: in-place SUM reduce-scatter, mean folded into the scales (see FlatUnit). gloo (CPU tests) keeps separate mean shards.
         # (inplace_reduce=True with gloo is for the CPU tests: it runs the same SUM-shard bookkeeping over an in-place all-reduce)
+        # MLA_FSDP_INPLACE_RS=0: back to the out-of-place AVG reduce-scatter into separate shard buffers (the round-2 form) -- a pre-wired
+        # fallback for the first multi-GPU run, should RCCL's in-place SUM form misbehave on the node
+        if inplace_reduce is None and os.environ.get("MLA_FSDP_INPLACE_RS") == "0":
+            inplace_reduce = False
         self.inplace_reduce = bool(self.coll and (dist.get_backend(process_group) == "nccl" if inplace_reduce is None else inplace_reduce))
         self.grad_div = float(self.world) if self.inplace_reduce else 1.0     # gshard holds grad_div x the mean gradient
         no_decay = no_decay or default_no_decay   # fsdp.py:236-256

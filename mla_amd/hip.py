@@ -40,6 +40,8 @@ _SIGNATURES = {
     "mla_sum_partials": [c_void_p, c_int, c_void_p, c_int, c_void_p],
     "mla_gemm_sq_slots": [c_int, c_int, c_int, c_size_t],
     "mla_gemm_kloop": [c_int],
+    "mla_gemm_cus": [c_int],
+    "mla_side_traffic": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p],
     "mla_gemm_gateup_swiglu": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
                                c_void_p],
     "mla_gemm_dact_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
@@ -129,6 +131,16 @@ def lib():
         L.mla_attn_bwd_ws_bytes.restype = c_longlong
         _lib = L
     return _lib
+
+
+def gemm_cus(n: int = -1) -> int:
+    """CUs the GEMM launches plan their split-K tails for (mla_gemm_cus): n >= 8 (multiple of 8) sets, 0 = device count, < 0 queries."""
+    return lib().mla_gemm_cus(n)
+
+
+def side_traffic(a32, b32, out32, blocks: int, lds_bytes: int = 0, sleep_ticks: int = 0):
+    """Stand-in for a collective's kernel on the CURRENT stream (mla_side_traffic): out = a + b streamed by `blocks` workgroups."""
+    call("mla_side_traffic", _p(a32), _p(b32), _p(out32), a32.numel(), blocks, lds_bytes, sleep_ticks)
 
 
 def gemm_source_id() -> str:
