@@ -696,30 +696,54 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // same update, 4 elements per lane per trip (16-B accesses on the seven fp32 streams, 8-B on the bf16 copy): the update is
-// element-wise, so the results are bit-identical to adamw_kernel; n4 = number of whole float4 groups
+// element-wise, so the results are bit-identical to adamw_kernel; n4 = number of whole float4 groups.
+// UNR = float4 groups per lane and trip (all their loads issued before the first use); NT = non-temporal accesses.
+template <int UNR, bool NT>
 __global__ __launch_bounds__(256) void adamw_vec4_kernel(f32x4_t* __restrict__ p, const f32x4_t* __restrict__ g, f32x4_t* __restrict__ m,
                                                          f32x4_t* __restrict__ v, u32x2_t* __restrict__ p16, long long n4, float lr,
                                                          float beta1, float beta2, float eps, float wd, float bc1, float bc2,
                                                          const float* __restrict__ grad_scale, long long n4_decay) {
   const float gs = grad_scale ? *grad_scale : 1.f;
   const float step = lr / bc1, isq = 1.f / sqrtf(bc2), decay_on = 1.f - lr * wd;
-  MLA_CHUNK_LOOP(i, n4) {
-    const float decay = i < n4_decay ? decay_on : 1.f;     // groups [0, n4_decay) are weight-decayed, the rest (norms, biases) not
-    const f32x4_t g4 = __builtin_nontemporal_load(g + i);
-    f32x4_t p4 = __builtin_nontemporal_load(p + i), m4 = __builtin_nontemporal_load(m + i), v4 = __builtin_nontemporal_load(v + i);
+  const long long chunk = ((((n4) + gridDim.x - 1) / gridDim.x) + 256 * UNR - 1) / (256 * UNR) * (256 * UNR);
+  const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
+  for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * UNR) {
+    f32x4_t g4[UNR], p4[UNR], m4[UNR], v4[UNR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float pp = p4[r], mm = m4[r], vv = v4[r];
-      adamw_elem(pp, g4[r], mm, vv, gs, decay, beta1, beta2, step, isq, eps);
-      p4[r] = pp; m4[r] = mm; v4[r] = vv;
+    for (int u = 0; u < UNR; ++u) {
+      const long long i = i0 + u * 256;
+      if (i < hi) {
+        if (NT) {
+          g4[u] = __builtin_nontemporal_load(g + i); p4[u] = __builtin_nontemporal_load(p + i);
+          m4[u] = __builtin_nontemporal_load(m + i); v4[u] = __builtin_nontemporal_load(v + i);
+        } else {
+          g4[u] = g[i]; p4[u] = p[i]; m4[u] = m[i]; v4[u] = v[i];
+        }
+      }
     }
-    // every stream is touched exactly once per step: non-temporal loads and stores (+3 % stand-alone, tools/bench_adamw.py)
-    __builtin_nontemporal_store(p4, p + i); __builtin_nontemporal_store(m4, m + i); __builtin_nontemporal_store(v4, v + i);
-    if (p16) {
-      u32x2_t o;
-      o[0] = pack2bf(p4[0], p4[1]);
-      o[1] = pack2bf(p4[2], p4[3]);
-      __builtin_nontemporal_store(o, p16 + i);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long long i = i0 + u * 256;
+      if (i >= hi) continue;
+      const float decay = i < n4_decay ? decay_on : 1.f;     // groups [0, n4_decay) are weight-decayed, the rest (norms, biases) not
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pp = p4[u][r], mm = m4[u][r], vv = v4[u][r];
+        adamw_elem(pp, g4[u][r], mm, vv, gs, decay, beta1, beta2, step, isq, eps);
+        p4[u][r] = pp; m4[u][r] = mm; v4[u][r] = vv;
+      }
+      // every stream is touched exactly once per step: non-temporal loads and stores (+3 % stand-alone, tools/bench_adamw.py)
+      if (NT) {
+        __builtin_nontemporal_store(p4[u], p + i); __builtin_nontemporal_store(m4[u], m + i); __builtin_nontemporal_store(v4[u], v + i);
+      } else {
+        p[i] = p4[u]; m[i] = m4[u]; v[i] = v4[u];
+      }
+      if (p16) {
+        u32x2_t o;
+        o[0] = pack2bf(p4[u][0], p4[u][1]);
+        o[1] = pack2bf(p4[u][2], p4[u][3]);
+        if (NT) __builtin_nontemporal_store(o, p16 + i); else p16[i] = o;
+      }
     }
   }
 }
@@ -985,9 +1009,20 @@ static int adamw_impl(float* p, const float* g, float* m, float* v, void* p16, l
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   // (the decay boundary must not cut a 16-B group: otherwise everything goes through the scalar kernel)
   const long long n4 = (AL16(p) && AL16(g) && AL16(m) && AL16(v) && (p16 == nullptr || ((uintptr_t)p16 & 7) == 0) && (n_decay & 3) == 0) ? n / 4 : 0;
-  if (n4)
-    hipLaunchKernelGGL(adamw_vec4_kernel, dim3(grid_for(n4, adamw_grid_cap())), dim3(256), 0, stream, (f32x4_t*)p, (const f32x4_t*)g, (f32x4_t*)m,
-                       (f32x4_t*)v, (u32x2_t*)p16, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, n_decay / 4);
+  if (n4) {
+    static const int variant = getenv("MLA_ADAMW_VARIANT") ? atoi(getenv("MLA_ADAMW_VARIANT")) : 0;   // A/B only (tools/bench_adamw.py)
+    const dim3 grid(grid_for(n4, adamw_grid_cap()));
+#define ADAMW_LAUNCH(U, N) hipLaunchKernelGGL((adamw_vec4_kernel<U, N>), grid, dim3(256), 0, stream, (f32x4_t*)p, (const f32x4_t*)g, (f32x4_t*)m, \
+                       (f32x4_t*)v, (u32x2_t*)p16, n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, n_decay / 4)
+    // default: four float4 groups per lane and trip, non-temporal (stand-alone 6.20-6.29 TB/s vs 5.99-6.15 with one group, same box,
+    // alternating; plain accesses 5.9-6.0) -- tools/ab_adamw.sh
+    if (variant == 1) ADAMW_LAUNCH(2, true);
+    else if (variant == 9) ADAMW_LAUNCH(1, true);     // rounds 2-3
+    else if (variant == 3) ADAMW_LAUNCH(1, false);
+    else if (variant == 4) ADAMW_LAUNCH(2, false);
+    else ADAMW_LAUNCH(4, true);
+#undef ADAMW_LAUNCH
+  }
   const long long done = n4 * 4;
   if (done < n)
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n - done, 8192)), dim3(256), 0, stream, p + done, g + done, m + done, v + done,
