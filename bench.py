@@ -268,6 +268,8 @@ def main():
         print(f"# mixed activation policy: base peak {base / 2**30:.1f} GiB, device {total / 2**30:.1f} GiB, {per_layer / 2**30:.2f} GiB per kept "
               f"layer -> keep {keep_layers}", file=sys.stderr)
         mla.vlm.llm_backbone.set_activation_policy(keep_layers, keep_level=args.keep_level, rest_level=0)
+        losses = None
+        torch.cuda.empty_cache()                 # the probe step's cached blocks have the all-checkpointed step's shapes
         torch.cuda.reset_peak_memory_stats()
     for _ in range(args.warmup):
         losses = strat.train_step(batch)
