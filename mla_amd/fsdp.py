@@ -175,14 +175,48 @@ def plan_sharded_layout(model: nn.Module, unit_policy: Callable[[nn.Module], boo
     return units
 
 
+class _Arenas:
+    """One allocation per KIND of buffer for all units of a model (bf16 replicas, fp32 gradient buffers, masters, the two AdamW moments,
+    separate gradient shards): a unit's buffers are consecutive slices of them. Measured on MI355X (tools/exp_adamw_placement.py): the
+    fused AdamW streams five buffers of a unit at once, and with the units' buffers allocated one by one in unit order (the five of a
+    unit adjacent in the address space) it runs at 5.5 TB/s; with one arena per kind (the five streams of a unit several GB apart, as
+    in the kernel's stand-alone benchmark) at 6.0 TB/s -- the in-step optimizer was the slow case in rounds 1-3."""
+
+    ALIGN_BYTES = 2 << 20      # every slice starts on a 2 MiB boundary, like a separate allocation would: a weight matrix whose rows do
+    #                            not start on 128-B lines costs the GEMMs' 1-KiB LDS-DMA reads an extra line each (measured: -3 % on the step)
+
+    def __init__(self, sizes: Dict[str, int], device, slices: int = 0):
+        dt = {"flat16": torch.bfloat16}
+        pad = {k: slices * (self.ALIGN_BYTES // (2 if k == "flat16" else 4)) for k in sizes}
+        self.buf = {k: torch.zeros(max(n + pad[k], 1), dtype=dt.get(k, torch.float32), device=device) for k, n in sizes.items() if n > 0}
+        self.used = {k: 0 for k in self.buf}
+
+    def has(self, kind: str) -> bool:
+        return kind in self.buf
+
+    def take(self, kind: str, n: int):
+        if n == 0:
+            return torch.zeros(0, dtype=torch.bfloat16 if kind == "flat16" else torch.float32, device=next(iter(self.buf.values())).device)
+        gran = self.ALIGN_BYTES // self.buf[kind].element_size()
+        o = (self.used[kind] + gran - 1) // gran * gran
+        assert o + n <= self.buf[kind].numel(), f"arena {kind}: {o} + {n} > {self.buf[kind].numel()}"
+        self.used[kind] = o + n
+        return self.buf[kind][o:o + n]
+
+
 class FlatUnit:
     """One sharding unit. Parameter order inside the flat buffers: [trainable & decayed | trainable & not decayed |
     frozen], each in module order (keeps q|k|v and gate|up adjacent), every tensor padded to 8 elements (plan_flat_layout)."""
 
     def __init__(self, name: str, named_params: Sequence[Tuple[str, nn.Parameter]], device, world: int, rank: int, ops,
                  no_decay: Callable[[str, nn.Parameter], bool], process_group=None, sync_from_rank0: bool = True,
-                 collectives: Optional[bool] = None, inplace_reduce: bool = False):
+                 collectives: Optional[bool] = None, inplace_reduce: bool = False, arenas: Optional["_Arenas"] = None):
         self.name, self.world, self.rank, self.ops, self.device = name, world, rank, ops, device
+        # buffers come from per-kind arenas when the owner provides them (ShardedModel), else from torch one by one
+        def take(kind, n, dtype):
+            if arenas is not None and arenas.has(kind):
+                return arenas.take(kind, n)
+            return torch.zeros(n, dtype=dtype, device=device)
         coll = (world > 1) if collectives is None else collectives   # separate shard buffers + real collectives
         self.params, self.n_decay, self.n_train, self.n_total = plan_flat_layout(named_params, world, no_decay)
         self.shard_total = self.n_total // world
@@ -195,18 +229,22 @@ class FlatUnit:
             full32[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
         if coll and sync_from_rank0:
             dist.broadcast(full32, src=0, group=process_group)      # every rank starts from rank 0's weights (FSDP sync_module_states)
-        self.flat16 = torch.zeros(self.n_total, dtype=torch.bfloat16, device=device)
+        self.flat16 = take("flat16", self.n_total, torch.bfloat16)
         ops.cast_to_bf16(full32, self.flat16)
         # fp32 master weights: the trainable region and the frozen region are each sharded 1/world, so that the weights,
         # gradient shard and AdamW moments of one element always live on the same rank
         nf = (self.n_total - self.n_train) // world
-        if not coll:
+        if not coll and not (arenas is not None and arenas.has("master")):
             self.master_train, self.master_frozen = full32[:self.n_train], full32[self.n_train:]
         else:
-            self.master_train = full32[rank * self.shard_train:(rank + 1) * self.shard_train].clone()
-            self.master_frozen = full32[self.n_train + rank * nf:self.n_train + (rank + 1) * nf].clone()
+            r = rank if coll else 0
+            st, sf = (self.shard_train, nf) if coll else (self.n_train, self.n_total - self.n_train)
+            self.master_train = take("master", st, torch.float32)
+            self.master_frozen = take("master", sf, torch.float32)
+            self.master_train.copy_(full32[r * st:(r + 1) * st])
+            self.master_frozen.copy_(full32[self.n_train + r * sf:self.n_train + (r + 1) * sf])
         del full32
-        self.grad32 = torch.zeros(self.n_train, dtype=torch.float32, device=device) if self.trainable else None
+        self.grad32 = take("grad32", self.n_train, torch.float32) if self.trainable else None
         # inplace_reduce (RCCL): the reduce-scatter writes this rank's shard INTO its own slice of the gradient buffer (NCCL's in-place
         # form, recvbuff == sendbuff + rank * count) as a SUM; the 1 / world of the mean is folded into the norm and into AdamW's
         # gradient scale (ShardedModel.grad_div). No separate shard buffer (27 GB / world at 7B), no copy when world == 1.
@@ -217,9 +255,9 @@ class FlatUnit:
             elif self.inplace_reduce:
                 self.gshard = self.grad32[rank * self.shard_train:(rank + 1) * self.shard_train]
             else:
-                self.gshard = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
-            self.exp_avg = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
-            self.exp_avg_sq = torch.zeros(self.shard_train, dtype=torch.float32, device=device)
+                self.gshard = take("gshard", self.shard_train, torch.float32)
+            self.exp_avg = take("exp_avg", self.shard_train, torch.float32)
+            self.exp_avg_sq = take("exp_avg_sq", self.shard_train, torch.float32)
         # ---- re-point the module parameters at the bf16 compute storage; install fp32 main_grad views
         # gradient-norm partials delivered by the wgrad GEMM epilogues (ops._gemm_into_main_grad): offset -> (numel, partials, count).
         # Only without collectives: under FSDP the norm is taken over the REDUCED shards, which no local epilogue has seen.
@@ -386,7 +424,25 @@ class ShardedModel:
         # units and the root first (embeddings are needed first), decoder layers after -- discover_units()
         self.units: List[FlatUnit] = []
         self.unit_of_module: Dict[int, FlatUnit] = {}
-        for name, mod, named in discover_units(model, unit_policy):
+        found = discover_units(model, unit_policy)
+        # one arena per kind of buffer, sized from the layout plan (see _Arenas: +10 % AdamW bandwidth against per-unit allocations);
+        # MLA_FSDP_ARENAS=0 = the per-unit allocations of rounds 1-3 (A/B switch)
+        self._arenas = None
+        kinds = [k for k in os.environ.get("MLA_FSDP_ARENAS", "master,exp_avg,exp_avg_sq").split(",") if k and k != "0"]
+        if kinds:
+            sizes = dict(flat16=0, grad32=0, master=0, exp_avg=0, exp_avg_sq=0, gshard=0)
+            for name, mod, named in found:
+                _, n_decay, n_train, n_total = plan_flat_layout(named, self.world, no_decay)
+                w = self.world if self.coll else 1
+                sizes["flat16"] += n_total
+                sizes["grad32"] += n_train
+                sizes["master"] += n_total // w
+                sizes["exp_avg"] += n_train // self.world
+                sizes["exp_avg_sq"] += n_train // self.world
+                if self.coll and not self.inplace_reduce:
+                    sizes["gshard"] += n_train // self.world
+            self._arenas = _Arenas({k: v for k, v in sizes.items() if k in kinds}, device, slices=2 * len(found))
+        for name, mod, named in found:
             self._add_unit(name, mod, named, no_decay)
         # buffers (BatchNorm statistics, ...) just move to the device in fp32 (FSDP buffer_dtype fp32)
         for b in model.buffers():
@@ -437,7 +493,7 @@ class ShardedModel:
         if not named:
             return
         u = FlatUnit(name, named, self.device, self.world, self.rank, self.ops, no_decay, self.pg, collectives=self.coll,
-                     inplace_reduce=self.inplace_reduce)
+                     inplace_reduce=self.inplace_reduce, arenas=self._arenas)
         u.module = mod
         self.units.append(u)
 
