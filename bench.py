@@ -417,8 +417,16 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
+    # fd 1 is stdout again for whatever runs after main() in this process -- but only after the C library's buffered stdout (RCCL's
+    # version banner sits there until exit when fd 1 is a pipe or a file) has been flushed to where fd 1 points NOW (stderr):
+    # restored without the flush, the banner landed behind the JSON line on the real stdout
     sys.stdout.flush()
-    os.dup2(real_stdout, 1)                    # fd 1 is stdout again for whatever runs after main() in this process
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.dup2(real_stdout, 1)
     os.close(real_stdout)
 
 
