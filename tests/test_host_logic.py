@@ -478,3 +478,26 @@ def test_run_vla_training_and_get_train_strategy_surface(tmp_path):
     assert len(ck) == 1 and ck[0].name.startswith("step-000003-epoch-01-loss=")          # end of epoch 1, save_interval 1
     with pytest.warns(UserWarning, match="Optimizer checkpoint not found"):
         strat.load_optimizer_and_scheduler(ck[0])
+
+
+def test_collective_knobs_and_buffer_arenas():
+    """Round 4 plumbing around the sharded path (no GPU, no process group): the environment knobs bench.py applies before creating the
+    RCCL communicator, and the per-kind buffer arenas (2 MiB-aligned slices, exact capacity accounting)."""
+    import torch
+    from mla_amd.fsdp import _Arenas, apply_rccl_env
+    env = {"MLA_RCCL_MAX_CHANNELS": "8", "MLA_GEMM_CUS": "240", "MLA_FSDP_INPLACE_RS": "0", "UNRELATED": "1"}
+    done = apply_rccl_env(env)
+    assert env["NCCL_MAX_NCHANNELS"] == "8" and done == {"NCCL_MAX_NCHANNELS": "8", "MLA_GEMM_CUS": "240", "MLA_FSDP_INPLACE_RS": "0"}
+    assert apply_rccl_env({}) == {}
+    ar = _Arenas({"master": 1000, "exp_avg": 24, "gshard": 0}, torch.device("cpu"), slices=3)
+    assert ar.has("master") and ar.has("exp_avg") and not ar.has("gshard") and not ar.has("flat16")
+    a, b, c = ar.take("master", 400), ar.take("master", 600), ar.take("master", 0)
+    assert a.numel() == 400 and b.numel() == 600 and c.numel() == 0
+    assert a.data_ptr() % 16 == 0 and (b.data_ptr() - a.data_ptr()) % _Arenas.ALIGN_BYTES == 0 and b.data_ptr() > a.data_ptr()
+    a.fill_(1.0)
+    b.fill_(2.0)
+    assert float(a.sum()) == 400.0 and float(b.sum()) == 1200.0            # disjoint
+    import pytest
+    with pytest.raises(AssertionError):
+        for _ in range(8):
+            ar.take("master", 600)                                          # beyond the planned capacity: loud, never silent overlap
