@@ -30,3 +30,6 @@ done
 python $R/tools/pmc_table.py /tmp/pmc_1.csv /tmp/pmc_2.csv /tmp/pmc_3.csv /tmp/pmc_4.csv > $O/${TAG}_pmc_table.txt
 python $R/tools/pmc_reduce.py /tmp/pmc_3.csv /tmp/pmc_4.csv $O/${TAG}_gemm256_hbm_traffic.json 150 /tmp/pmc_2.csv
 cat $O/${TAG}_power_trace.txt | tail -12; cat $O/${TAG}_pmc_table.txt; head -40 $O/${TAG}_roofline_table.txt
+# second argument "all": the secondary configurations from the same command (bench lines of configs[3] / [4] with their own `roofline`
+# objects, kernel stats, step breakdowns; configs[4] with the reference's policy and with the opt-in mixed policy)
+if [ "$2" = "all" ]; then bash $R/tools/collect_configs34.sh $TAG; fi
