@@ -335,7 +335,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
   qb = nqb - 1 - qb;                               // heaviest (most key tiles) first
   const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
   const int row_lim = seqlen < p.S ? seqlen : p.S;  // rows at / beyond it are padding: zero output, no work
-  const int q0 = qb * BQ;
+  // Row blocks are shifted towards the END of the sequence (round 4): block qb covers rows [qb * BQ - shift, + BQ) with shift = the
+  // whole 64-row key tiles that fit into the padding of the last block ((-S) mod BQ, rounded down to 64), so the emptier block is the
+  // FIRST (rows < 0 do not exist), which needs a single key tile, instead of the LAST, which needs all of them (S = 548: 128-row
+  // blocks with 64 and 100 useful rows through 1 and 9 key tiles, 25 tile passes per head; aligned to the start 36 useful rows went
+  // through 9 tiles, 29 passes). Multiples of 64 only: a shift that moves the 16-row groups off the key-tile grid makes every fourth
+  // group straddle two diagonal tiles (+5 % MFMA / LDS work: measured, no gain). Every row still sees exactly its key tiles
+  // 0 .. q / 64 in order, so the results are bit-identical.
+  const int q0 = qb * BQ - (((BQ - p.S % BQ) % BQ) & ~63);
   const int g = lane >> 4;
   int myq[RB], grow0[RB];
 #pragma unroll
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
   if (nkt <= 0 || q0 >= row_lim) {  // whole block is padding
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
-      if (myq[rb] < p.S) {
+      if (myq[rb] >= 0 && myq[rb] < p.S) {
         bf16_t* orow = p.o + ((long long)b * p.S + myq[rb]) * p.ld_o + h * D;
 #pragma unroll
         for (int fd = 0; fd < 8; ++fd) *(u32x2_t*)(orow + fd * 16 + g * 4) = u32x2_t{0u, 0u};
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
   float m[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    load_row_frags(qb_ + (long long)(myq[rb] < p.S ? myq[rb] : p.S - 1) * p.ld, lane, qf[rb]);
+    load_row_frags(qb_ + (long long)(myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1) * p.ld, lane, qf[rb]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) ot[rb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     m[rb] = -INFINITY;
@@ -416,8 +423,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
   __syncthreads();
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const bool valid = myq[rb] < p.S;
-    const bool pad = myq[rb] >= seqlen;
+    const bool valid = myq[rb] >= 0 && myq[rb] < p.S;
+    const bool pad = myq[rb] >= seqlen || myq[rb] < 0;
     const float lsum = l[rb][0];                  // all four entries hold the row sum
     const float inv = (pad || lsum == 0.f) ? 0.f : 1.f / lsum;
     const int row = row_group<RB>(wave, rb) * 16 + (lane & 15);
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
 #pragma unroll
     for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
       const int r = ps * (NT / 16) + (threadIdx.x >> 4);
-      if (q0 + r < p.S)
+      if (q0 + r >= 0 && q0 + r < p.S)
         *(u32x4_t*)(p.o + ((long long)b * p.S + q0 + r) * p.ld_o + h * D + j * 8) =
             *(const u32x4_t*)(smem + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
     }
@@ -458,7 +465,7 @@ __device__ __forceinline__ void dq_pad_block(const AttnArgs& p, const int (&myq)
   const int g = lane >> 4;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
-    if (myq[rb] < p.S) {
+    if (myq[rb] >= 0 && myq[rb] < p.S) {
       bf16_t* dqrow = p.dq + ((long long)b * p.S + myq[rb]) * p.ld + h * D;
 #pragma unroll
       for (int fd = 0; fd < 8; ++fd) *(u32x2_t*)(dqrow + fd * 16 + g * 4) = u32x2_t{0u, 0u};
@@ -489,7 +496,7 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
   __syncthreads();
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const bool valid = myq[rb] < p.S;
+    const bool valid = myq[rb] >= 0 && myq[rb] < p.S;
     const float sc = padq[rb] ? 0.f : p.scale;
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) dqt[rb][fd] *= sc;
@@ -515,14 +522,14 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
 #pragma unroll
     for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
       const int r = ps * (NT / 16) + (threadIdx.x >> 4);
-      if (q0 + r < p.S)
+      if (q0 + r >= 0 && q0 + r < p.S)
         *(u32x4_t*)(p.dq + ((long long)b * p.S + q0 + r) * p.ld + h * D + j * 8) =
             *(const u32x4_t*)(smem + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
     }
   }
   if (tr) {
-    const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3
-    const bool jv = q0 + j * 4 < p.S;
+    const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3 (q0 and S are multiples of 4)
+    const bool jv = q0 + j * 4 >= 0 && q0 + j * 4 < p.S;
     const long long tok = (long long)b * p.S + q0 + j * 4;
 #pragma unroll
     for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
@@ -534,7 +541,7 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
     for (int rb = 0; rb < RB; ++rb) {
       const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
       bf16x8_t of[4];
-      load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
+      load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         union { bf16x8_t v; uint32_t u[4]; } f;
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   qb = nqb - 1 - qb;                               // heaviest (most key tiles) first
   const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
   const int row_lim = seqlen < p.S ? seqlen : p.S;
-  const int q0 = qb * BQ;
+  const int q0 = qb * BQ - (((BQ - p.S % BQ) % BQ) & ~63);      // row blocks shifted towards the end of the sequence, see the forward kernel
   const int g = lane >> 4;
   int myq[RB], grow0[RB];
 #pragma unroll
@@ -651,10 +658,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   bool padq[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const int qc = myq[rb] < p.S ? myq[rb] : p.S - 1;
+    const int qc = myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1;
     load_row_frags(qb_ + (long long)qc * p.ld, lane, qf[rb]);
     load_row_frags(p.dout + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, dof[rb]);
-    padq[rb] = (myq[rb] >= seqlen) || (myq[rb] >= p.S);
+    padq[rb] = (myq[rb] >= seqlen) || (myq[rb] >= p.S) || (myq[rb] < 0);
     lse2[rb] = padq[rb] ? INFINITY : p.lse[((long long)b * p.H + h) * p.S + qc] * LOG2E;
     if (p.o) {
       // delta = rowsum(O * dO) formed here (the four lanes of a row hold all 128 channels of dO already) and published for the
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
         for (int j = 0; j < 4; ++j) acc += bflo(a.w[j]) * bflo(d.w[j]) + bfhi(a.w[j]) * bfhi(d.w[j]);
       }
       dlt[rb] = group_sum(acc);
-      if (g == 0 && myq[rb] < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myq[rb]] = dlt[rb];
+      if (g == 0 && myq[rb] >= 0 && myq[rb] < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myq[rb]] = dlt[rb];
     } else {
       dlt[rb] = p.delta[((long long)b * p.H + h) * p.S + qc];
     }
