@@ -25,7 +25,9 @@
     __builtin_amdgcn_s_waitcnt(0x0F70);    \
     asm volatile("" ::: "memory");         \
   } while (0)
-#if MLA_ATTN_GLDS_ASM
+#if defined(MLA_ATTN_NOSTAGE)            // TIMING-ONLY ablation (tools/build_attn_abl.sh): no global -> LDS copies at all
+#define ATTN_GLDS(src, dst) ((void)(src), (void)(dst))
+#elif MLA_ATTN_GLDS_ASM
 #define ATTN_GLDS glds16_untracked
 #else
 #define ATTN_GLDS glds16
@@ -81,6 +83,12 @@ template <int NW = 4>
 __device__ __forceinline__ void stage_fast(const bf16_t* __restrict__ tile_base, const unsigned* off, char* tile, int wave) {
 #pragma unroll
   for (int it = 0; it < 16 / NW; ++it) ATTN_GLDS(tile_base + off[it], tile + (wave * (16 / NW) + it) * 1024);
+}
+
+template <int NW = 4>
+__device__ __forceinline__ void stage_fast_b(const bf16_t* __restrict__ tile_base, const unsigned* off_bytes, char* tile, int wave) {
+#pragma unroll
+  for (int it = 0; it < 16 / NW; ++it) ATTN_GLDS((const char*)tile_base + off_bytes[it], tile + (wave * (16 / NW) + it) * 1024);
 }
 
 // A/B fragment of 16 tile rows (rb) x 32 d (ks): lane (i = lane&15 -> row, g = lane>>4 -> d group of 8)
@@ -457,21 +465,34 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
   }
 }
 
-// ------------------------------------------------------------------------------------------------ forward, 32 query rows per wave, assembly tile body (round 4)
-// The 16-row forward above is co-bound by the LDS pipe (every K / V^T fragment read feeds ONE 16x16x32 MFMA) and its waves run their
-// phases in lockstep; with 32 rows per wave on v_mfma_f32_32x32x16_bf16 the same fragment bytes feed twice the flops. The compiler
-// cannot hold that kernel's live set (it ping-pongs the 64 accumulators between two register sets, serialises ds_read -> wait -> MFMA
-// and spills once fragments are batched: HISTORY.md "Round 4"), so the per-tile body is ONE generated inline-asm statement
-// (attn_fwd32_tile.inc, tools/gen_attn_asm.py): scores, softmax and P V of a 64-key tile on physical registers, the output
-// accumulators in a[0:63] for the whole kernel, fragments in counted batches. Layout (verified by the compiler version):
+// ------------------------------------------------------------------------------------------------ forward, 32 rows per wave, cross-tile software pipeline
+// OPT-IN (MLA_ATTN_FWD=1; round 4). The 16-row forward above reads every K / V^T fragment from LDS for ONE 16x16x32 MFMA; with 32 rows
+// per wave on v_mfma_f32_32x32x16_bf16 the same fragment bytes feed twice the flops. The compiler cannot hold that kernel's live set
+// (it ping-pongs the 64 accumulators between two register sets, serialises ds_read -> wait -> MFMA and spills once fragments are
+// batched: HISTORY.md "Round 4"), so the body of an iteration is ONE generated inline-asm statement on physical registers
+// (attn_fwd32p_tile*.inc, tools/gen_attn_asm.py): softmax + P V of tile k and Q K^T of tile k + 1, with the softmax VALU in the MFMA
+// gaps. Layout (verified by the round-4 compiler version of the same kernel):
 //   S^T[key][q] = K Q^T : A = K rows by ds_read_b128 (m = key), B = Q^T straight from global (n = q = lane & 31)
 //                         C: lane (q, kh = lane >> 5), register r <-> key kb*32 + (r >> 2)*8 + kh*4 + (r & 3)
 //   O^T[d][q]  += V^T P^T: B = registers 8 (t & 1) .. + 7 of block t >> 1 packed to bf16 (k-slot <-> key map permuted to match),
 //                         A = V^T by ds_read_b64_tr_b16 under the same permutation (V staged with swizzle 2)
-// C++ keeps the tile loop, the LDS-DMA staging (double-buffered 64-key K / V tiles), the barriers, Q load and the epilogue.
-// Between the statements nothing but the assembly may touch a[0:63] (build.sh checks the device assembly: tools/check_kloop_asm.py).
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_fwd32a_kernel(AttnArgs p) {
+// LDS: three K stages + two V stages of 16 KiB (K of tile k + 2 and V of tile k + 1 are staged during iteration k); iterations
+// k = -1 (prologue: Q K^T of tile 0 only) .. nkt - 1. C++ keeps the loop, the barriers, Q load and the epilogue. The output accumulators
+// (a[0:63]), Q (a[96:127]) and the scores of tile k + 1 (v[64:127]) live in physical registers BETWEEN statements: build.sh checks
+// from the device assembly that the compiler's own code touches none of them inside the loop (tools/check_attn_asm.py).
+// Measured (HISTORY.md "Round 4"): S = 2048 405-427 us vs 452-471 us of the default kernel, S = 548 189-193 vs 173-179 us -> opt-in.
+constexpr int FWD32P_LDS = 5 * TILE_BYTES;
+#ifdef MLA_ATTN_TRACE      // experiment build (tools/build_attn_flags.sh): per-iteration cycle stamps of block 0's waves -> mla_attn_trace()
+__device__ unsigned long long g_attn_trace[4 * 64 * 8];
+#define ATTN_TR(pt)                                                                                   \
+  do {                                                                                                \
+    if (blockIdx.x == MLA_ATTN_TRACE && lane == 0 && k + 1 < 64) g_attn_trace[(wave * 64 + k + 1) * 8 + (pt)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define ATTN_TR(pt) ((void)0)
+#endif
+__global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(AttnArgs p) {
+  constexpr int NW = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BQ = 32 * NW;
   constexpr int NST = 16 / NW;
@@ -541,58 +562,100 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32a_kernel(AttnArgs p) {
 #undef Z4
       ::
       :
-#include "attn_fwd32_clobbers.inc"
+#include "attn_fwd32p_clobbers.inc"
   );
   // LDS byte addresses (low 32 bits of the generic pointer = offset in the workgroup's LDS) of this lane's operand gathers in stage 0
   const unsigned lds0 = (unsigned)(unsigned long long)smem;
   const int kr = lane & 31;
   const unsigned kaddr0 = lds0 + kr * 256 + ((kh ^ (lane & 15)) << 4);
   const int i16 = lane & 15, a4 = lane >> 4;
-  const unsigned vaddr0 = lds0 + TILE_BYTES + (((a4 >> 1) * 4 + (i16 >> 2)) * 256) + (((i16 >> 2) & 3) << 6) + (((a4 & 1) * 2 + ((i16 & 3) >> 1)) << 4) +
+  const unsigned vaddr0 = lds0 + 3 * TILE_BYTES + (((a4 >> 1) * 4 + (i16 >> 2)) * 256) + (((i16 >> 2) & 3) << 6) + (((a4 & 1) * 2 + ((i16 & 3) >> 1)) << 4) +
                           (i16 & 1) * 8;
 
   unsigned koff[NST], voff[NST];
   stage_offs<0, NW>(p.ld, wave, lane, koff);
   stage_offs<2, NW>(p.ld, wave, lane, voff);
+#pragma unroll
+  for (int i = 0; i < NST; ++i) { koff[i] *= 2; voff[i] *= 2; }       // byte offsets (the assembly's global_load_lds takes bytes)
+  char* const vring = smem + 3 * TILE_BYTES;
   stage_rows64<0, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
-  stage_rows64<2, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
-  for (int kt = 0; kt < nkt; ++kt) {
+  const bool wave_on = grow0 < row_lim && grow0 + 31 >= 0;
+  int last = (grow0 + 31) >> 6;                      // last key tile with an unmasked pair for this wave
+  if (last > nkt - 1) last = nkt - 1;
+  float mx = -INFINITY;
+  int k3 = 0;                                        // (k + 1) % 3 : K stage of tile k + 1
+  for (int k = -1; k < nkt; ++k) {
+    ATTN_TR(0);
     ATTN_WAIT_VM0();
+    ATTN_TR(1);
     __syncthreads();
-    // wave-uniform: any unmasked, non-padding (row, key) pair of this wave in this tile? Then the tile body runs, and -- when the next
-    // tile lies inside the sequence -- issues the next tile's eight LDS-DMA copies itself, between its QK^T MFMAs; otherwise they are
-    // issued here in one burst
-    const bool active = grow0 < row_lim && kt * 64 <= grow0 + 31;
-    const bool stage_next = kt + 1 < nkt;
-    const bool inside = (kt + 2) * 64 <= p.S;
-    const bf16_t* kn = kb_ + (long long)(kt + 1) * 64 * p.ld;
-    const bf16_t* vn = vb_ + (long long)(kt + 1) * 64 * p.ld;
-    char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-    if (stage_next && !(active && inside && NST == 4)) {
-      if (inside) {
-        stage_fast<NW>(kn, koff, nx, wave);
-        stage_fast<NW>(vn, voff, nx + TILE_BYTES, wave);
-      } else {
-        stage_rows64<0, NW>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
-        stage_rows64<2, NW>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
+    ATTN_TR(2);
+    const bool do_cur = wave_on && k >= 0 && k <= last;
+    const bool do_next = wave_on && k + 1 <= last;
+    const bool need_k = k + 2 < nkt, need_v = k + 1 < nkt;
+    const bool in_asm = do_next && need_k && (k + 3) * 64 <= p.S;
+    const int k3n = k3 == 2 ? 0 : k3 + 1;            // (k + 2) % 3
+    const bf16_t* kn = kb_ + (long long)(k + 2) * 64 * p.ld;
+    const bf16_t* vn = vb_ + (long long)(k + 1) * 64 * p.ld;
+    char* kdst = smem + k3n * TILE_BYTES;
+    char* vdst = vring + ((k + 1) & 1) * TILE_BYTES;
+    if (!in_asm) {
+      if (need_k) {
+        if ((k + 3) * 64 <= p.S) stage_fast_b<NW>(kn, koff, kdst, wave);
+        else stage_rows64<0, NW>(kb_, p.ld, (k + 2) * 64, p.S, kdst, wave, lane);
+      }
+      if (need_v) {
+        if ((k + 2) * 64 <= p.S) stage_fast_b<NW>(vn, voff, vdst, wave);
+        else stage_rows64<2, NW>(vb_, p.ld, (k + 1) * 64, p.S, vdst, wave, lane);
       }
     }
-    if (active) {
-      const unsigned stage = (unsigned)(kt & 1) * (2 * TILE_BYTES);
-      const unsigned kaddr = kaddr0 + stage, vaddr = vaddr0 + stage;
-      const int thr = myq - kt * 64 - kh * 4;
-      const int flags = __builtin_amdgcn_readfirstlane((kt * 64 + 63 > grow0 ? 1 : 0) | (kt * 64 + 32 <= grow0 + 31 ? 2 : 0) |
-                                                       ((stage_next && inside && NST == 4) ? 4 : 0));
-      const unsigned ldsdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((kt + 1) & 1) * (2 * TILE_BYTES) + (unsigned)wave * NST * 1024);
-      asm volatile(
-#include "attn_fwd32_tile.inc"
-          : "+v"(m), "+v"(lpart)
-          : "v"(kaddr), "v"(vaddr), "v"(sc2), "v"(thr), "s"(flags), "v"(koff[0] * 2), "v"(koff[1 % NST] * 2), "v"(koff[2 % NST] * 2),
-            "v"(koff[3 % NST] * 2), "v"(voff[0] * 2), "v"(voff[1 % NST] * 2), "v"(voff[2 % NST] * 2), "v"(voff[3 % NST] * 2), "s"(kn), "s"(vn), "s"(ldsdst)
+    ATTN_TR(3);
+    if (do_cur || do_next) {
+      const unsigned kaddr = kaddr0 + (unsigned)k3 * TILE_BYTES, vaddr = vaddr0 + (unsigned)(k & 1) * TILE_BYTES;
+      const int thr = myq - (k + 1) * 64 - kh * 4;
+      const int flags = __builtin_amdgcn_readfirstlane(((do_next && (k + 1) * 64 + 63 > grow0) ? 1 : 0) | ((do_next && (k + 1) * 64 + 32 <= grow0 + 31) ? 2 : 0) |
+                                                       (in_asm ? 4 : 0) | (do_next ? 8 : 0) | (do_cur ? 16 : 0) |
+                                                       ((do_cur && k * 64 + 32 <= grow0 + 31) ? 32 : 0));
+      const unsigned ldsk = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)k3n * TILE_BYTES + (unsigned)wave * NST * 1024);
+      const unsigned ldsv = __builtin_amdgcn_readfirstlane(lds0 + (3u + ((unsigned)(k + 1) & 1u)) * TILE_BYTES + (unsigned)wave * NST * 1024);
+#define FWD32P_OPERANDS                                                                                                       \
+          : "+v"(m), "+v"(lpart), "+v"(mx)                                                                                       \
+          : "v"(kaddr), "v"(vaddr), "v"(sc2), "v"(thr), "s"(flags), "v"(koff[0]), "v"(koff[1]), "v"(koff[2]), "v"(koff[3]),      \
+            "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(kn), "s"(vn), "s"(ldsk), "s"(ldsv)                       \
           :
-#include "attn_fwd32_clobbers.inc"
-      );
+      // flags == 62: this tile and the next both lie below the diagonal and the copies are issued from the assembly -- the body with
+      // every flag test resolved (no scalar branches); everything else takes the generic body
+      if (flags == 62) {
+        if (k & 1) {
+          asm volatile(
+#include "attn_fwd32p_tile1c.inc"
+              FWD32P_OPERANDS
+#include "attn_fwd32p_clobbers.inc"
+          );
+        } else {
+          asm volatile(
+#include "attn_fwd32p_tile0c.inc"
+              FWD32P_OPERANDS
+#include "attn_fwd32p_clobbers.inc"
+          );
+        }
+      } else if (k & 1) {
+        asm volatile(
+#include "attn_fwd32p_tile1.inc"
+            FWD32P_OPERANDS
+#include "attn_fwd32p_clobbers.inc"
+        );
+      } else {
+        asm volatile(
+#include "attn_fwd32p_tile0.inc"
+            FWD32P_OPERANDS
+#include "attn_fwd32p_clobbers.inc"
+        );
+      }
+#undef FWD32P_OPERANDS
     }
+    ATTN_TR(4);
+    k3 = k3n;
   }
   // ---- epilogue: export the accumulators 16 at a time, normalise, stage O through LDS (the K / V ring is free now) as whole 256-B rows
   __syncthreads();
@@ -1293,6 +1356,10 @@ int check_common(const AttnArgs& p, const char* who) {
 
 #define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 
+#ifdef MLA_ATTN_TRACE
+extern "C" int mla_attn_trace(void* host, int bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_trace), bytes); }
+#endif
+
 extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
                             int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, hipStream_t stream) {
   MLA_CHECK_ARG(q && k && v && o && lse, "mla_attn_fwd: null pointer");
@@ -1304,22 +1371,18 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
   if (check_common(p, "mla_attn_fwd")) return -1;
   static bool attr = false;
   constexpr int BQ = 16 * FWD_NW * FWD_RB;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_RB, FWD_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); attr = true; }
-  static const int variant = getenv("MLA_ATTN_FWD") ? atoi(getenv("MLA_ATTN_FWD")) : 0;   // 0 = 8 waves x 16 rows; 1 / 2 = 4 / 8 waves x 32 rows, assembly tile body
-  if (variant == 1 || variant == 2) {
-    static bool attr2 = false;
-    if (!attr2) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd32a_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-      (void)hipFuncSetAttribute((const void*)attn_fwd32a_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-      attr2 = true;
-    }
-    static const int lds_extra = getenv("MLA_ATTN_LDS_EXTRA") ? atoi(getenv("MLA_ATTN_LDS_EXTRA")) : 0;   // experiment: force one block per CU
-    if (lds_extra) (void)hipFuncSetAttribute((const void*)attn_fwd32a_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + lds_extra);
-    if (variant == 1) hipLaunchKernelGGL((attn_fwd32a_kernel<4>), dim3(grid_blocks((S + 127) / 128, H, B)), dim3(256), 4 * TILE_BYTES + lds_extra, stream, p);
-    else hipLaunchKernelGGL((attn_fwd32a_kernel<8>), dim3(grid_blocks((S + 255) / 256, H, B)), dim3(512), 4 * TILE_BYTES, stream, p);
+  constexpr int FWD_LDS = 4 * TILE_BYTES;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_RB, FWD_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS); attr = true; }
+  // MLA_ATTN_FWD=1: the 32-rows-per-wave forward with the generated assembly tile body (opt-in, see attn_fwd32p_kernel)
+  static const int variant = getenv("MLA_ATTN_FWD") ? atoi(getenv("MLA_ATTN_FWD")) : 0;
+  if (variant == 1) {
+    static bool attr3 = false;
+    static const int lds_extra = getenv("MLA_ATTN_LDS_EXTRA") ? atoi(getenv("MLA_ATTN_LDS_EXTRA")) : 0;   // experiment (tools/exp_attn_trace.py): one block per CU
+    if (!attr3) { (void)hipFuncSetAttribute((const void*)attn_fwd32p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD32P_LDS + lds_extra); attr3 = true; }
+    hipLaunchKernelGGL(attn_fwd32p_kernel, dim3(grid_blocks((S + 127) / 128, H, B)), dim3(256), FWD32P_LDS + lds_extra, stream, p);
     MLA_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL((attn_fwd_kernel<FWD_RB, FWD_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * FWD_NW), 4 * TILE_BYTES, stream, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<FWD_RB, FWD_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * FWD_NW), FWD_LDS, stream, p);
   MLA_LAUNCH_CHECK();
 }
 

@@ -19,11 +19,11 @@ SRCS="api gemm gemm256 transpose elementwise attention loss pointcloud vision ge
 [ "$EXP" = 1 ] && SRCS="$SRCS gemm_asm"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/common.h" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$BUILD/$f.o" ] || { [ "$f" = gemm256 ] && { [ "$HERE/gemm256_kloop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm256_kloop_half1.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_8w_clobbers.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_clobbers.inc" -nt "$BUILD/$f.o" ]; }; }; then
+  if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/common.h" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$BUILD/$f.o" ] || { [ "$f" = gemm256 ] && { [ "$HERE/gemm256_kloop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm256_kloop_half1.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = attention ] && { [ "$HERE/attn_fwd32p_tile0.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile1.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile0c.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile1c.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_clobbers.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_8w_clobbers.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_clobbers.inc" -nt "$BUILD/$f.o" ]; }; }; then
     XF=""; [ "$f" = api ] && XF="-DMLA_GEMM_SRC_ID=\"$GID\""
     $HIPCC $FLAGS $XF -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
     pids+=($!)
-    if [ "$f" = gemm256 ]; then   # device assembly for tools/check_kloop_asm.py (below)
+    if [ "$f" = gemm256 ] || [ "$f" = attention ]; then   # device assembly for tools/check_kloop_asm.py / check_attn_asm.py (below)
       $HIPCC $FLAGS --cuda-device-only -S "$HERE/$f.hip" -o "$BUILD/$f.s" &
       pids+=($!)
     fi
@@ -33,6 +33,8 @@ for p in "${pids[@]}"; do wait $p; done
 # gemm256's assembly-loop kernels keep their accumulators in a0..a127 across two inline-asm statements: prove from the device assembly
 # that the compiler touches no accumulation register (and spills nothing) outside the assembly
 python3 "$HERE/../../tools/check_kloop_asm.py" "$BUILD/gemm256.s"
+# the opt-in assembly attention forward keeps accumulators, Q and the next tile's scores in physical registers between its statements
+python3 "$HERE/../../tools/check_attn_asm.py" "$BUILD/attention.s"
 # explicit object list: a stale build/<removed source>.o must not be linked
 OBJS=()
 for f in $SRCS; do [ -f "$HERE/$f.hip" ] && OBJS+=("$BUILD/$f.o"); done

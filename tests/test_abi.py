@@ -102,3 +102,48 @@ def test_kloop_checker_flags_an_accumulator_touch_between_two_statements(tmp_pat
         f.write_text(src)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kloop_asm.py"), str(f)], capture_output=True, text=True)
         assert r.returncode == want, (name, r.stdout)
+
+
+def test_attention_assembly_is_what_the_generator_writes(tmp_path):
+    """The committed iteration bodies of the opt-in assembly attention forward (attn_fwd32p_*.inc) are exactly what tools/gen_attn_asm.py
+    emits; the common-case body has no scalar branch on the flags and the same MFMA count as one path of the generic body."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GEN_OUT_DIR=str(tmp_path))
+    env.pop("GEN_ATTN_ABL", None)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_attn_asm.py")], check=True, env=env, capture_output=True)
+    names = ["attn_fwd32p_tile0.inc", "attn_fwd32p_tile1.inc", "attn_fwd32p_tile0c.inc", "attn_fwd32p_tile1c.inc", "attn_fwd32p_clobbers.inc"]
+    for n in names:
+        new, old = open(tmp_path / n).read(), open(os.path.join(ROOT, "mla_amd", "csrc", n)).read()
+        assert new == old, f"{n} differs from the generator's output: run python tools/gen_attn_asm.py"
+    for par in (0, 1):
+        body = [ln.strip('"\\n \n') for ln in open(tmp_path / f"attn_fwd32p_tile{par}c.inc") if ln.startswith('"')]
+        assert sum(ln.startswith("v_mfma_f32_32x32x16_bf16") for ln in body) == 32          # 16 Q K^T + 16 P V
+        assert not any(ln.startswith(("s_bitcmp", "s_cbranch_scc", "s_branch")) for ln in body)
+        assert sum(ln.startswith("s_cbranch_vccz") for ln in body) == 2                     # the running-max decision (data-dependent)
+        assert sum(ln.startswith("global_load_lds_dwordx4") for ln in body) == 8            # K of tile k + 2, V of tile k + 1
+        # the score buffers alternate: parity p accumulates Q K^T into the OTHER buffer than the one its softmax reads
+        qk = [ln for ln in body if ln.startswith("v_mfma") and ln.split()[1].startswith("v[")]
+        assert all(ln.split()[1].startswith("v[96:" if par == 0 else "v[64:") or ln.split()[1].startswith("v[112:" if par == 0 else "v[80:") for ln in qk), qk[:2]
+
+
+def test_attention_asm_checker_flags_persistent_registers_and_vacuous_input(tmp_path):
+    """tools/check_attn_asm.py (run by build.sh): compiler code between the tile statements that names v64.. or an AGPR is a finding;
+    statement-local temporaries (v40..63) are not; a listing without the kernel or without its tile statements is a failure, not a pass."""
+    import subprocess
+    import sys
+    stmt = ";;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 a[0:15], a[64:67], v[64:67], a[0:15]\n;;#ASMEND\n"
+    def kern(between):
+        return ("_ZN12_GLOBAL__N_118attn_fwd32p_kernelENS_8AttnArgsE:\n\ts_load_dword s0, s[0:1], 0x0\n" + stmt + between + stmt +
+                "\tv_accvgpr_read_b32 v70, a3\n\ts_endpgm\n.end_amdhsa_kernel\n")
+    cases = {"clean": (kern("\tv_add_u32_e32 v41, v3, v5\n\ts_barrier\n"), 0),
+             "score_register": (kern("\tv_mov_b32_e32 v64, v1\n"), 1),
+             "score_tuple": (kern("\tglobal_load_dwordx4 v[60:63], v[2:3], off\n\tglobal_load_dwordx4 v[62:65], v[2:3], off\n"), 1),
+             "agpr": (kern("\tv_accvgpr_write_b32 a5, v1\n"), 1),
+             "one_statement_only": ("_ZN12_GLOBAL__N_118attn_fwd32p_kernelENS_8AttnArgsE:\n" + stmt + "\ts_endpgm\n.end_amdhsa_kernel\n", 1),
+             "kernel_missing": ("_Z5otherv:\n\ts_endpgm\n.end_amdhsa_kernel\n", 1)}
+    for name, (src, want) in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(src)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_attn_asm.py"), str(f)], capture_output=True, text=True)
+        assert r.returncode == want, (name, r.stdout)

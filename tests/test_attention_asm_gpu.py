@@ -1,0 +1,64 @@
+"""The opt-in 32-rows-per-wave attention forward with the generated assembly iteration body (MLA_ATTN_FWD=1, attn_fwd32p_kernel,
+tools/gen_attn_asm.py) against the same oracle and tolerances as the default kernel. The variant is read once per process, so the
+parity cases of tests/test_kernels_gpu.py (forward AND the backward that consumes this forward's o / lse; ragged lengths, padding-only
+blocks, S = 2048) run in a child process with the variable set; a second child proves the variable really selects another kernel
+(same results within bf16 rounding, not the same bits).
+Reference: transformers modeling_llama.py:371-380 (scaled causal softmax attention of LlamaAttention.forward)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DUMP = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from mla_amd import hip
+dev = torch.device("cuda:0")
+out = {}
+for S, B, lens in ((548, 3, None), (548, 3, [548, 17, 300]), (1024, 2, [1024, 700]), (132, 2, None), (36, 2, None)):
+    H, D = 3, 128
+    g = torch.Generator().manual_seed(S + B)
+    qkv = (torch.randn(B * S, 3 * H * D, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    o, lse = hip.attn_fwd(qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:], B, S, H, D, 3 * H * D, sl, D ** -0.5)
+    out[f"{S}_{B}_{'ragged' if lens else 'full'}"] = (o.cpu(), lse.cpu())
+torch.save(out, sys.argv[1])
+"""
+
+
+def _child(env_extra, args, timeout=900):
+    env = dict(os.environ, **env_extra)
+    return subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_assembly_forward_passes_the_attention_parity_cases(dev):
+    r = _child({"MLA_ATTN_FWD": "1"}, ["-m", "pytest", os.path.join("tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+                                       "test_attention_fwd_bwd or test_attention_full_size_config4_properties or test_attention_bwd_five_product"])
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert " passed" in tail and "failed" not in tail, tail
+
+
+def test_the_variable_selects_another_kernel_with_the_same_results(dev, tmp_path):
+    outs = {}
+    for variant in ("0", "1"):
+        f = tmp_path / f"v{variant}.pt"
+        r = _child({"MLA_ATTN_FWD": variant}, ["-c", DUMP, str(f), ROOT])
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        outs[variant] = torch.load(f)
+    differ = 0
+    for key, (o0, l0) in outs["0"].items():
+        o1, l1 = outs["1"][key]
+        assert torch.equal(torch.isfinite(l0), torch.isfinite(l1)), key                    # padded rows: lse = +inf in both
+        fin = torch.isfinite(l0)
+        assert float((l0[fin] - l1[fin]).abs().max()) < 5e-3, key                           # log-sum-exp: fp32 either way
+        rel = float((o0.float() - o1.float()).norm() / o0.float().norm())
+        assert rel < 3e-3, (key, rel)                                                       # measured 1.3e-3 .. 2.0e-3: two bf16 roundings
+        assert torch.equal(o0 == 0, o1 == 0) or float(((o0 == 0) != (o1 == 0)).float().mean()) < 1e-3, key
+        differ += int(not torch.equal(o0, o1))
+    assert differ > 0, "MLA_ATTN_FWD=1 produced the default kernel's bits: the assembly forward did not run"

@@ -1,30 +1,34 @@
-"""Cycle stamps inside the attention forward loop (experiment build build_tr/: attention.hip patched to write s_memtime-style cycle
-counters of one block -- batch 5, head 0, second-heaviest row block -- into the buffer passed as `delta`)."""
-import os, sys, ctypes
+"""Per-iteration cycle stamps of one block of the pipelined attention forward (experiment build with -DMLA_ATTN_TRACE=<block>,
+tools/build_attn_flags.sh): where a wave's iteration goes -- wait for the staged tile (vmcnt), barrier, C++ glue, tile statement.
+Usage: MLA_HIP_LIB=mla_amd/csrc/build_tr/lib_trace.so MLA_ATTN_FWD=3 python tools/exp_attn_trace.py [S] [B]"""
+import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from mla_amd import hip
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 548
-B, H, D = 32, 32, 128
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+H, D = 32, 128
 dev = torch.device("cuda:0")
 qkv = (torch.randn(B * S, 3 * H * D, device=dev) * 0.5).to(torch.bfloat16)
 q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
-o = torch.empty(B * S, H * D, dtype=torch.bfloat16, device=dev)
-lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-ts = torch.zeros(8 * 256, dtype=torch.int64, device=dev)
-L = hip.lib()
-from ctypes import c_void_p, c_int, c_longlong, c_float
-L.mla_attn_fwd_trace.argtypes = [c_void_p] * 6 + [c_int] * 4 + [c_longlong, c_longlong, c_float, c_void_p, c_void_p]
-for it in range(3):
-    ts.zero_()
-    L.mla_attn_fwd_trace(hip._p(q), hip._p(k), hip._p(v), hip._p(o), hip._p(lse), None, B, S, H, D, 3 * H * D, H * D, D ** -0.5, hip._p(ts), hip._stream())
-    torch.cuda.synchronize()
-t = ts.cpu().view(8, 256)
-for w in (0, 3, 7):
-    r = t[w]
-    print(f"wave {w}: block start->loop end {int(r[251] - r[250])} cycles")
-    for kt in range(12):
-        x = r[kt * 8:kt * 8 + 8]
-        if int(x[0]) == 0:
-            break
-        print(f"   kt {kt}: vmcnt wait {int(x[6]-x[5]):6d} | barrier {int(x[0]-x[6]):6d} | stage-issue+QK {int(x[2]-x[0]):6d} | softmax {int(x[3]-x[2]):6d} | PV {int(x[4]-x[3]):6d} | total {int(x[4]-x[5]):6d}")
+for _ in range(3):
+    hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, None, D ** -0.5)
+torch.cuda.synchronize()
+buf = np.zeros(4 * 64 * 8, dtype=np.uint64)
+lib = ctypes.CDLL(os.environ.get("MLA_HIP_LIB") or os.path.join(os.path.dirname(hip.__file__), "libmla_hip.so"))
+rc = lib.mla_attn_trace(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
+assert rc == 0, rc
+t = buf.reshape(4, 64, 8).astype(np.int64)
+n = int((t[3, :, 0] > 0).sum())
+print(f"S={S} B={B}: {n} iterations traced (block {os.environ.get('TRACE_BLOCK', '?')}); cycles per iteration: wait-vm | barrier | glue | statement | total")
+for w in range(4):
+    tw = t[w, :n]
+    wait, bar, glue, stmt = tw[:, 1] - tw[:, 0], tw[:, 2] - tw[:, 1], tw[:, 3] - tw[:, 2], tw[:, 4] - tw[:, 3]
+    tot = np.diff(tw[:, 0])
+    print(f"wave {w}: mean wait {wait[1:].mean():7.0f} barrier {bar[1:].mean():7.0f} glue {glue[1:].mean():6.0f} statement {stmt[1:].mean():7.0f} | iteration {tot.mean():7.0f}")
+    if w == 3:
+        for i in range(min(n, 40)):
+            print(f"   it {i - 1:3d}: wait {wait[i]:6d} bar {bar[i]:6d} glue {glue[i]:5d} stmt {stmt[i]:6d}")
+print("whole block, wave 3:", int(t[3, n - 1, 4] - t[3, 0, 0]), "cycles")

@@ -1,44 +1,23 @@
 #!/usr/bin/env python
-"""Generates the hand-scheduled key-tile body of the 32-rows-per-wave attention forward (mla_amd/csrc/attn_fwd32_tile.inc): ONE inline-asm
-statement per (wave, 64-key tile) on v_mfma_f32_32x32x16_bf16, with the output accumulators in a[0:63] (owned by the assembly for the
-whole kernel), the operand fragments and Q in a[64:127], and 64 physical VGPRs v[64:127] as statement-local temporaries. Why assembly: HISTORY.md "Round 4" -- at 32 rows per wave
-the compiler keeps two copies of the 64 accumulators, serialises ds_read -> s_waitcnt -> v_mfma with one fragment in flight and spills
-as soon as fragments are batched by hand; the layout below is the one verified by the round-4 compiler version.
-
-Per statement (operands, see attention.hip):
-  %0 m (running max, log2 domain)  %1 lpart (this lane's half of the row sum)   [Q fragments: a[96 + 4 kd : 99 + 4 kd], written once]
-  %2 kaddr  = LDS byte address of this lane's K row (lane & 31) + ((kh ^ (lane & 15)) << 4); d-step kd is at kaddr ^ (kd << 5),
-               32-key block kb at + 8192
-  %3 vaddr  = LDS byte address of this lane's V^T gather for d-block 0; d-block db is at vaddr ^ (db << 6), 16-key step t at
-               + 4096 t, its second key quad at + 2048
-  %4 sc2 = scale * log2(e)   %5 thr = myq - 64 kt - 4 kh (causal threshold of this lane relative to the tile)
-  %6 flags (SGPR): bit 0 = the tile touches the diagonal (apply the mask), bit 1 = the upper 32 keys hold unmasked pairs,
-     bit 2 = stage the NEXT tile from inside this statement: eight LDS-DMA copies spread between the QK^T MFMAs
-  %7..%10 / %11..%14 byte offsets of this wave's four K / V copies, %15 / %16 SGPR-pair bases of the next K / V tile, %17 LDS
-     destination of this wave's first K copy (V copies at + 16 KiB)
-Register map: S0 = v[64:79], S1 = v[80:95] scores of key block 0 / 1 (register r <-> key kb*32 + (r >> 2)*8 + kh*4 + (r & 3));
-FA = a[64:79], FB = a[80:95] two batches of four operand fragments (K rows by ds_read_b128, V^T by ds_read_b64_tr_b16);
-PF = v[96:111] P^T packed to bf16 (fragment t = registers 4t..4t+3 = the B operand of key step t); v[112:119] addresses;
-v120.. scalars of the softmax. a[16 db : 16 db + 15] = O^T accumulator of d-block db.
-Schedule: K fragments in batches of four, two batches in flight (counted lgkmcnt), the next tile's eight LDS-DMA copies behind QK^T
-MFMAs, the V^T fragments of key steps 0 / 1 requested right behind QK^T and landing during the softmax, steps 2 / 3 requested under the
-P V MFMAs of steps 0 / 1. Measured and NOT kept (HISTORY.md "Round 4"): a sub-tile pipeline with the softmax VALU of one key block in
-the MFMA gaps of the other -- 4 cheap VALU per 32-cycle MFMA gap are free (tools/micro/mfma_fillers.hip), 8 cost 17 cycles, a v_exp_f32
-~10: the tile's ~140 VALU only hide under MFMAs of ANOTHER tile (cross-tile software pipeline: the next step).
-Hazards padded by hand (cdna_hip_programming.md 5.7 item 2): MFMA D -> VALU 12+ states, VALU -> MFMA operand 2, VALU -> permlane 2.
-Usage: python tools/gen_attn_asm.py   (writes the .inc; tests/test_abi.py checks it is in sync)"""
+"""Generates the hand-scheduled iteration bodies of the 32-rows-per-wave attention forward (attn_fwd32p_kernel, mla_amd/csrc/attention.hip,
+opt-in via MLA_ATTN_FWD=1): ONE inline-asm statement per (wave, iteration) on v_mfma_f32_32x32x16_bf16 with the output accumulators in
+a[0:63] (owned by the assembly for the whole kernel), the operand fragments and Q in a[64:127] and the two score buffers in v[64:127].
+Why assembly: HISTORY.md "Round 4" -- at 32 rows per wave the compiler keeps two copies of the 64 accumulators, serialises
+ds_read -> s_waitcnt -> v_mfma with one fragment in flight and spills as soon as fragments are batched by hand.
+Outputs: attn_fwd32p_tile{0,1}.inc (generic body, score-buffer parity 0 / 1: every case by flag tests), attn_fwd32p_tile{0,1}c.inc (the
+same body with the flag tests resolved for the common case: no scalar branches), attn_fwd32p_clobbers.inc.
+Hazards padded by hand (cdna_hip_programming.md 5.7 item 2): MFMA D -> VALU 12+ states, VALU -> MFMA operand 2, VALU -> permlane 2,
+v_exp_f32 -> non-trans VALU 1.
+GEN_ATTN_ABL=nosm,nomfma,nok,nov,nold strips an instruction class for TIMING-ONLY builds (tools/build_attn_abl.sh).
+Usage: python tools/gen_attn_asm.py   (tests/test_abi.py checks the committed .inc files are in sync)"""
 import os
 
 CSRC = os.environ.get("GEN_OUT_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mla_amd", "csrc")
 # With AGPRs in use at two waves per SIMD hipcc splits the unified file 128 arch VGPRs + 128 AGPRs (arch registers >= v128 are
 # reserved), so everything only the matrix pipe and the LDS touch lives in AGPRs: the output accumulators, both fragment buffers
 # (ds_read_* can target AGPRs, MFMA A / B operands may be AGPRs) and the Q fragments.
-S0, S1, PF, TA = 64, 80, 96, 112                     # arch VGPRs: scores, packed P^T, K addresses (8)
-MX, T1, MSAFE, ALPHA, LS0, LS1, NINF, TMP = 120, 121, 122, 123, 124, 125, 126, 127
-AO, FA, FB, AQ = 0, 64, 80, 96                        # AGPRs: O^T accumulators, fragment batches A / B, Q fragments
-OP_M, OP_L, OP_KADDR, OP_VADDR, OP_SC2, OP_THR, OP_FLAGS = 0, 1, 2, 3, 4, 5, 6
-OP_KOFF, OP_VOFF, OP_KBASE, OP_VBASE, OP_LDSDST = 7, 11, 15, 16, 17       # staging: 4 + 4 VGPR byte offsets, two SGPR-pair bases, LDS destination
-NST = 4                                                                    # LDS-DMA copies per wave and operand (4 waves x 4 x 1 KiB = one 16 KiB tile)
+AO, FA, FB, AQ = 0, 64, 80, 96                        # AGPRs: O^T accumulators, fragment buffers A / B, Q fragments
+NST = 4                                               # LDS-DMA copies per wave and operand (4 waves x 4 x 1 KiB = one 16 KiB tile)
 THR = "0x41000000"          # 8.0: the running max moves only when a tile's max exceeds it by more than 2^8
 
 
@@ -50,205 +29,351 @@ def ar(base, n=1):
     return f"a{base}" if n == 1 else f"a[{base}:{base + n - 1}]"
 
 
-def s_reg(i):          # score register i of 32 (S0 ++ S1)
-    return S0 + i
+# ================================================================================================ cross-tile pipelined body (round 4, variant 3)
+# One statement per (wave, iteration k): softmax + P V of tile k (scores already in registers, computed by the previous statement) and
+# Q K^T of tile k + 1, with the softmax VALU of tile k in the MFMA gaps of Q K^T (k + 1) / P V (k). What hides where follows
+# tools/micro/mfma_fillers.hip: a 32x32x16 MFMA occupies the matrix pipe for 32 cycles; ~4 plain VALU or 1 v_exp_f32 + 2-3 plain
+# VALU issue under it for free, more stretch the gap.
+#   region A: 16 (8) Q K^T MFMAs of tile k+1 -> S_next   | fillers: key block 0 of tile k: fma, exp2, row-sum, pack (56 VALU)
+#   region B: 16 (8) P V MFMAs of tile k                 | fillers: key block 1 of tile k (56 VALU, must precede P V steps 2 / 3),
+#                                                        |          then the running row maximum of S_next (20 VALU)
+# The two score buffers swap roles every iteration (two generated bodies, parity 0 / 1); packed P^T overwrites the first 16 registers
+# of the current score buffer in place. The running-max decision (deferred maximum, threshold 2^8) is taken at the top of the statement
+# from the maximum the previous statement left in %2.
+# Operands: %0 m  %1 l (this lane's half of the row sum)  %2 mx (row max of the scores in S_cur, x sc2)  %3 kaddr (tile k+1)
+#   %4 vaddr (tile k)  %5 sc2  %6 thr of tile k+1  %7 flags (SGPR): bit 0 tile k+1 touches the diagonal, bit 1 tile k+1 has two key
+#   blocks for this wave, bit 2 issue the staging copies (K of tile k+2, V of tile k+1) from here, bit 3 tile k+1 exists for this wave,
+#   bit 4 tile k exists (false in the prologue iteration k = -1), bit 5 tile k has two key blocks
+#   %8..%11 / %12..%15 byte offsets of this wave's K / V copies, %16 / %17 SGPR-pair bases of K tile k+2 / V tile k+1,
+#   %18 / %19 LDS destinations of this wave's first K / V copy
+# Registers: v40..47 scalars, v48..55 K addresses, v56..59 V^T addresses, v[64:95] / v[96:127] the two score buffers;
+#   a[0:63] O^T, a[64:79] ring of four K fragments / V^T fragments of odd key steps, a[80:95] V^T fragments of even key steps, a[96:127] Q.
+PB_MX, PB_T1, PB_MSAFE, PB_ALPHA, PB_LS0, PB_LS1, PB_NINF, PB_TMP = 40, 41, 42, 43, 44, 45, 46, 47
+PB_KA, PB_VA, PB_SC2P, PB_MSP = 48, 56, 60, 62      # K / V^T addresses; (sc2, sc2) and (msafe, msafe) pairs of the packed-fp32 instructions
+PB_S = (64, 96)
+PO_M, PO_L, PO_MX, PO_KADDR, PO_VADDR, PO_SC2, PO_THR, PO_FLAGS, PO_KOFF, PO_VOFF, PO_KBASE, PO_VBASE, PO_LDSK, PO_LDSV = 0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 17, 18, 19
+PF_NDIAG, PF_NTWO, PF_STAGE, PF_NEXT, PF_CUR, PF_CTWO = 0, 1, 2, 3, 4, 5
 
 
-def gen():
+def spread(groups, fillers, first=0, last=None):
+    """groups: list of instruction lists (each starts with its MFMA); fillers spread evenly over the gaps behind groups first..last"""
+    last = len(groups) - 1 if last is None else last
+    n = last - first + 1
+    per = -(-len(fillers) // n) if fillers else 0
+    out, pos = [], 0
+    for g, grp in enumerate(groups):
+        out.extend(grp)
+        if first <= g <= last:
+            out.extend(fillers[pos:pos + per])
+            pos += per
+    assert pos >= len(fillers)
+    return out
+
+
+def gen_pipe(par):
+    SC, SN = PB_S[par], PB_S[1 - par]
     L = []
     A = L.append
+    lab = [100 + 100 * par]
 
-    def kread(buf, kb, kd0):
-        return [f"ds_read_b128 {ar(buf + 4 * i, 4)}, v{TA + kd0 + i} offset:{kb * 8192}" for i in range(4)]
+    def label():
+        lab[0] += 1
+        return str(lab[0])
 
-    def vread(buf, t):      # V^T fragments of key step t, d-blocks 0..3 (addresses v[112:115] by then)
+    def bit(b, target):            # branch to target when flag bit b is clear
+        A(f"s_bitcmp1_b32 %{PO_FLAGS}, {b}")
+        A(f"s_cbranch_scc0 {target}f")
+
+    def vread(buf, t):
         out = []
         for db in range(4):
-            out.append(f"ds_read_b64_tr_b16 {ar(buf + 4 * db, 2)}, v{TA + db} offset:{t * 4096}")
-            out.append(f"ds_read_b64_tr_b16 {ar(buf + 4 * db + 2, 2)}, v{TA + db} offset:{t * 4096 + 2048}")
+            out.append(f"ds_read_b64_tr_b16 {ar(buf + 4 * db, 2)}, v{PB_VA + db} offset:{t * 4096}")
+            out.append(f"ds_read_b64_tr_b16 {ar(buf + 4 * db + 2, 2)}, v{PB_VA + db} offset:{t * 4096 + 2048}")
         return out
-
-    def pv(buf, t):
-        return [f"v_mfma_f32_32x32x16_bf16 {ar(AO + 16 * db, 16)}, {ar(buf + 4 * db, 4)}, {vr(PF + 4 * t, 4)}, {ar(AO + 16 * db, 16)}"
-                for db in range(4)]
 
     def stage(i):
-        """i-th staging copy of the NEXT tile (0..3 K, 4..7 V), issued behind an MFMA when flags bit 2 is set: ~60 cycles of issue
-        each that would otherwise sit in a burst at the top of the iteration (all waves of the CU at once)"""
         isv, q = divmod(i, NST)
-        off = f"%{(OP_VOFF if isv else OP_KOFF) + q}"
-        base = f"%{OP_VBASE if isv else OP_KBASE}"
-        lab = f"8{i}"
-        return [f"s_bitcmp1_b32 %{OP_FLAGS}, 2", f"s_cbranch_scc0 {lab}f", f"s_add_u32 m0, %{OP_LDSDST}, {isv * 16384 + q * 1024}", "s_nop 0",
-                f"global_load_lds_dwordx4 {off}, {base}", f"{lab}:"]
+        off = f"%{(PO_VOFF if isv else PO_KOFF) + q}"
+        base = f"%{PO_VBASE if isv else PO_KBASE}"
+        dst = f"%{PO_LDSV if isv else PO_LDSK}"
+        lb = label()
+        return [f"s_bitcmp1_b32 %{PO_FLAGS}, {PF_STAGE}", f"s_cbranch_scc0 {lb}f", f"s_add_u32 m0, {dst}, {q * 1024}", "s_nop 0",
+                f"global_load_lds_dwordx4 {off}, {base}", f"{lb}:"]
 
-    A("; ---- addresses: K d-step kd -> v[112 + kd]")
-    A(f"v_mov_b32 v{TA}, %{OP_KADDR}")
-    for kd in range(1, 8):
-        A(f"v_xor_b32 v{TA + kd}, {kd << 5}, %{OP_KADDR}")
-    A(f"v_mov_b32 v{NINF}, 0xff800000")
-    A(f"s_bitcmp1_b32 %{OP_FLAGS}, 1")
-    A("s_cbranch_scc0 10f")
-    # ---------------- two key blocks; fragments in batches of four, two batches in flight; the next tile's eight copies behind MFMAs
-    A("; ---- QK^T, key blocks 0 and 1")
-    order = [(kb, kd) for kd in range(8) for kb in (0, 1)]                # fragment f -> (kb, kd)
-
-    def kread2(buf, b):
-        return [f"ds_read_b128 {ar(buf + 4 * i, 4)}, v{TA + order[4 * b + i][1]} offset:{order[4 * b + i][0] * 8192}" for i in range(4)]
-
-    def qk2(buf, b):
+    def softmax_fillers(e0, e1):
+        """scale-and-subtract / exp2 / row-sum / pack of score registers e0..e1-1 of the current tile, two registers per packed-fp32
+        instruction where one exists (v_pk_fma_f32, v_pk_add_f32: 80 instead of 112 VALU instructions per 32 scores), as a software
+        pipeline: no result is consumed by the next instruction (and a v_exp_f32 result needs one wait state before a non-trans VALU
+        reads it)"""
         out = []
-        for i in range(4):
-            kb, kd = order[4 * b + i]
-            sreg = S0 if kb == 0 else S1
-            c = "0" if kd == 0 else vr(sreg, 16)
-            out.append(f"v_mfma_f32_32x32x16_bf16 {vr(sreg, 16)}, {ar(buf + 4 * i, 4)}, {ar(AQ + 4 * kd, 4)}, {c}")
+        pairs = list(range(e0, e1, 2))
+        for t in range(len(pairs) + 3):
+            if t < len(pairs):
+                e = pairs[t]
+                out.append(f"v_pk_fma_f32 v[{SC + e}:{SC + e + 1}], v[{SC + e}:{SC + e + 1}], v[{PB_SC2P}:{PB_SC2P + 1}], v[{PB_MSP}:{PB_MSP + 1}] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+            if 0 <= t - 1 < len(pairs):
+                e = pairs[t - 1]
+                out.append(f"v_exp_f32 v{SC + e}, v{SC + e}")
+                out.append(f"v_exp_f32 v{SC + e + 1}, v{SC + e + 1}")
+            if 0 <= t - 2 < len(pairs):
+                e = pairs[t - 2]
+                out.append(f"v_pk_add_f32 v[{PB_LS0}:{PB_LS1}], v[{PB_LS0}:{PB_LS1}], v[{SC + e}:{SC + e + 1}]")
+            if 0 <= t - 3 < len(pairs):
+                e = pairs[t - 3]
+                out.append(f"v_cvt_pk_bf16_f32 v{SC + e // 2}, v{SC + e}, v{SC + e + 1}")
         return out
-    L.extend(kread2(FA, 0))
-    L.extend(kread2(FB, 1))
-    for b in range(4):
-        buf = FA if b % 2 == 0 else FB
-        A("s_waitcnt lgkmcnt(4)" if b < 3 else "s_waitcnt lgkmcnt(0)")
-        m = qk2(buf, b)
-        L.extend([m[0]] + stage(2 * b) + [m[1], m[2]] + stage(2 * b + 1) + [m[3]])
-        if b + 2 < 4:
-            L.extend(kread2(buf, b + 2))
-    A("s_branch 11f")
-    A("10:")
-    # ---------------- upper 32 keys fully masked for this wave: one key block; scores of block 1 = -inf
-    L.extend(kread(FA, 0, 0))
-    L.extend(kread(FB, 0, 4))
-    A("s_waitcnt lgkmcnt(4)")
 
-    def qk1(buf, kd0):
-        return [f"v_mfma_f32_32x32x16_bf16 {vr(S0, 16)}, {ar(buf + 4 * i, 4)}, {ar(AQ + 4 * (kd0 + i), 4)}, {'0' if kd0 + i == 0 else vr(S0, 16)}"
-                for i in range(4)]
-    m = qk1(FA, 0)
-    L.extend([m[0]] + stage(0) + [m[1]] + stage(1) + [m[2]] + stage(2) + [m[3]] + stage(3))
-    A("s_waitcnt lgkmcnt(0)")
-    m = qk1(FB, 4)
-    L.extend([m[0]] + stage(4) + [m[1]] + stage(5) + [m[2]] + stage(6) + [m[3]] + stage(7))
-    for r in range(16):
-        A(f"v_mov_b32 v{S1 + r}, v{NINF}")
-    A("11:")
-    # V^T addresses (the K addresses are dead) and the fragments of key steps 0 / 1: in flight during the softmax.
-    # FA was last read >= 4 MFMAs ago; FB by the four MFMAs issued last -- by the time these reads can return (LDS latency + the
-    # eight reads in front of them) those MFMAs have fetched their operands. lgkmcnt is a 4-bit counter: never 16 outstanding.
-    A(f"v_mov_b32 v{TA}, %{OP_VADDR}")
-    for db in range(1, 4):
-        A(f"v_xor_b32 v{TA + db}, {db << 6}, %{OP_VADDR}")
-    A("s_nop 1")
-    L.extend(vread(FA, 0))
-    r1 = vread(FB, 1)
-    L.extend(r1[:7])
-    A("s_waitcnt lgkmcnt(14)")
-    L.extend(r1[7:])
-    A("; ---- softmax over 32 scores per lane (MFMA D -> VALU: 8-pass XDL needs 12 wait states; 16 given)")
-    A("s_nop 15")
-    A(f"s_bitcmp1_b32 %{OP_FLAGS}, 0")
-    A("s_cbranch_scc0 20f")
-    for i in range(32):
-        kb, r = divmod(i, 16)
-        c = kb * 32 + (r >> 2) * 8 + (r & 3)
-        A(f"v_cmp_gt_i32_e32 vcc, {c}, %{OP_THR}")
-        A(f"v_cndmask_b32_e32 v{s_reg(i)}, v{s_reg(i)}, v{NINF}, vcc")
-    A("20:")
-    A(f"v_max3_f32 v{MX}, v{s_reg(0)}, v{s_reg(1)}, v{s_reg(2)}")
-    i = 3
-    while i < 32:
-        b = i + 1 if i + 1 < 32 else i
-        A(f"v_max3_f32 v{MX}, v{MX}, v{s_reg(i)}, v{s_reg(b)}")
-        i += 2
-    A(f"v_mov_b32 v{T1}, v{MX}")
-    A("s_nop 1")
-    A(f"v_permlane32_swap_b32 v{MX}, v{T1}")
-    A(f"v_max_f32 v{MX}, v{MX}, v{T1}")
-    A(f"v_mul_f32 v{MX}, v{MX}, %{OP_SC2}")                    # max of the raw scores x positive scale
-    # Deferred maximum (cdna_hip_programming.md T13): the running max moves -- and the 64 accumulators are rescaled, 192 instructions
-    # through v_accvgpr_read / write -- only when some lane's tile maximum exceeds its running max by more than THR (log2 units);
-    # otherwise the old max stays and p = exp2(s - m_old) <= 2^THR (bf16 keeps its 8 bits of precision at any magnitude; sums in
-    # fp32). -inf - -inf = NaN compares false: no update. (Measured: the step time does not depend on it -- the tile is not VALU-bound.)
-    A(f"v_sub_f32 v{T1}, v{MX}, %{OP_M}")
-    A(f"v_mov_b32 v{ALPHA}, 1.0")
-    A(f"v_cmp_lt_f32_e32 vcc, {THR}, v{T1}")
-    A("s_cbranch_vccz 31f")
-    A(f"v_max_f32 v{T1}, %{OP_M}, v{MX}")                      # new running max (lanes below the threshold move too: harmless)
-    A(f"v_cmp_eq_f32_e32 vcc, v{NINF}, v{T1}")
-    A(f"v_cndmask_b32_e64 v{MSAFE}, v{T1}, 0, vcc")
-    A(f"v_sub_f32 v{ALPHA}, %{OP_M}, v{MSAFE}")
-    A(f"v_exp_f32 v{ALPHA}, v{ALPHA}")
-    A(f"v_mov_b32 %{OP_M}, v{T1}")
-    for base in range(0, 64, 8):      # eight registers per group through v[116:123]... the K-address registers v[116:119] + v[124:127]
-        tmp = [TA + 4, TA + 5, TA + 6, TA + 7, LS0, LS1, TMP, MSAFE]
+    def max_fillers():
+        out = [f"v_max3_f32 v{PB_MX}, v{SN}, v{SN + 1}, v{SN + 2}"]
+        i = 3
+        while i < 32:
+            b = i + 1 if i + 1 < 32 else i
+            out.append(f"v_max3_f32 v{PB_MX}, v{PB_MX}, v{SN + i}, v{SN + b}")
+            i += 2
+        return out
+
+    def max_finish():
+        return [f"v_mov_b32 v{PB_T1}, v{PB_MX}", "s_nop 1", f"v_permlane32_swap_b32 v{PB_MX}, v{PB_T1}", f"v_max_f32 v{PB_MX}, v{PB_MX}, v{PB_T1}",
+                f"v_mul_f32 %{PO_MX}, v{PB_MX}, %{PO_SC2}"]
+
+    def region_a(nblk, fill):
+        """Q K^T of tile k+1 into S_next: fragments through a ring of four slots in a[64:79] (the read of fragment f + 4 goes out right behind
+        MFMA f, which fetched slot f % 4 in its first cycles; LDS data return in order, so lgkmcnt counts the reads still wanted)"""
+        frs = [(kb, kd) for kb in range(nblk) for kd in range(8)]
+        n = len(frs)
+
+        def rd(f):
+            kb, kd = frs[f]
+            return f"ds_read_b128 {ar(FA + 4 * (f % 4), 4)}, v{PB_KA + kd} offset:{kb * 8192}"
+        out = [rd(f) for f in range(4)]
+        groups = []
+        for f, (kb, kd) in enumerate(frs):
+            g = [f"s_waitcnt lgkmcnt({min(3, n - 1 - f)})"]
+            c = "0" if kd == 0 else vr(SN + 16 * kb, 16)
+            g.append(f"v_mfma_f32_32x32x16_bf16 {vr(SN + 16 * kb, 16)}, {ar(FA + 4 * (f % 4), 4)}, {ar(AQ + 4 * kd, 4)}, {c}")
+            if f + 4 < n:
+                g.append(rd(f + 4))
+            si = f - 1 if n == 16 else f
+            if 0 <= si < 8:
+                g.extend(stage(si))
+            groups.append(g)
+        out.extend(spread(groups, softmax_fillers(0, 16) if fill else []))
+        if nblk == 1:
+            out.extend(f"v_mov_b32 v{SN + 16 + r}, v{PB_NINF}" for r in range(16))
+        return out
+
+    def region_b(T, with_max):
+        """P V of tile k: V^T fragments of key step 0 are in a[80:95] (requested at the top of the statement), of step 1 in a[64:79]
+        (requested behind the last Q K^T MFMA); steps 2 / 3 are requested behind the MFMAs of steps 0 / 1."""
+        groups = []
+        for t in range(T):
+            buf = FB if t % 2 == 0 else FA
+            for db in range(4):
+                g = []
+                if db == 0:
+                    g.append(f"s_waitcnt lgkmcnt({8 if t + 1 < T else 0})")
+                g.append(f"v_mfma_f32_32x32x16_bf16 {ar(AO + 16 * db, 16)}, {ar(buf + 4 * db, 4)}, {vr(SC + 4 * t, 4)}, {ar(AO + 16 * db, 16)}")
+                if db == 3 and t + 2 < T:
+                    if t == 1:
+                        g.append("s_waitcnt lgkmcnt(7)")          # never 16 outstanding (4-bit counter)
+                    g.extend(vread(buf, t + 2))
+                groups.append(g)
+        if T == 4:
+            f1 = softmax_fillers(16, 32)
+            per = 5
+            seq = spread(groups[:10], f1 + [""] * (per * 10 - len(f1)))
+            seq = [x for x in seq if x]
+            # every packed register must be written (and two wait states old) before the P V MFMA that reads it as its B operand
+            written = {}
+            for i, ln in enumerate(seq):
+                if ln.startswith("v_cvt_pk"):
+                    written[int(ln.split()[1].strip(",")[1:])] = i
+                if ln.startswith("v_mfma"):
+                    t = (int(ln.split("v[")[1].split(":")[0]) - SC) // 4
+                    for r in range(SC + 4 * t, SC + 4 * t + 4):
+                        assert r < SC + 8 or (r in written and written[r] < i - 2), (r, i, written)
+            rest = groups[10:]
+            tail = spread(rest, max_fillers() if with_max else [])
+            out = seq + tail
+        else:
+            out = spread(groups, max_fillers() if with_max else [], first=2)   # S_next: >= 2 MFMAs (64 cycles) behind the last Q K^T MFMA
+        out.append(f"v_add_f32 v{PB_LS0}, v{PB_LS0}, v{PB_LS1}")
+        out.append(f"v_add_f32 %{PO_L}, %{PO_L}, v{PB_LS0}")
+        if with_max:
+            out.extend(max_finish())
+        return out
+
+    # ---------------------------------------------------------------- top: running-max decision for tile k
+    A(f"v_mov_b32 v{PB_NINF}, 0xff800000")
+    nodec, nomove = label(), label()
+    bit(PF_CUR, nodec)
+    A(f"v_sub_f32 v{PB_T1}, %{PO_MX}, %{PO_M}")                 # -inf - -inf = NaN compares false: no update
+    A(f"v_cmp_lt_f32_e32 vcc, {THR}, v{PB_T1}")
+    A(f"s_cbranch_vccz {nomove}f")
+    A(f"v_max_f32 v{PB_T1}, %{PO_M}, %{PO_MX}")                 # new running max (lanes below the threshold move too: harmless)
+    A(f"v_cmp_eq_f32_e32 vcc, v{PB_NINF}, v{PB_T1}")
+    A(f"v_cndmask_b32_e64 v{PB_MSAFE}, v{PB_T1}, 0, vcc")
+    A(f"v_sub_f32 v{PB_ALPHA}, %{PO_M}, v{PB_MSAFE}")
+    A(f"v_exp_f32 v{PB_ALPHA}, v{PB_ALPHA}")
+    A(f"v_cmp_neq_f32_e32 vcc, v{PB_NINF}, %{PO_M}")            # any lane with a finite old max? (none at the first tile: O is still zero)
+    A(f"v_mov_b32 %{PO_M}, v{PB_T1}")
+    A(f"v_mul_f32 %{PO_L}, %{PO_L}, v{PB_ALPHA}")
+    A(f"s_cbranch_vccz {nomove}f")
+    for base in range(0, 64, 8):
+        tmp = [PB_KA + k for k in range(8)]
         for k in range(8):
             A(f"v_accvgpr_read_b32 v{tmp[k]}, a{base + k}")
         A("s_nop 0")
         for k in range(8):
-            A(f"v_mul_f32 v{tmp[k]}, v{tmp[k]}, v{ALPHA}")
+            A(f"v_mul_f32 v{tmp[k]}, v{tmp[k]}, v{PB_ALPHA}")
         for k in range(8):
             A(f"v_accvgpr_write_b32 a{base + k}, v{tmp[k]}")
-    A("31:")
-    A(f"v_cmp_eq_f32_e32 vcc, v{NINF}, %{OP_M}")
-    A(f"v_cndmask_b32_e64 v{MSAFE}, %{OP_M}, 0, vcc")          # a row with nothing unmasked yet: subtract 0, not -inf
-    for i in range(32):
-        A(f"v_fma_f32 v{s_reg(i)}, v{s_reg(i)}, %{OP_SC2}, -v{MSAFE}")
-    for i in range(32):
-        A(f"v_exp_f32 v{s_reg(i)}, v{s_reg(i)}")
-    A(f"v_add_f32 v{LS0}, v{s_reg(0)}, v{s_reg(1)}")
-    A(f"v_add_f32 v{LS1}, v{s_reg(2)}, v{s_reg(3)}")
-    for i in range(4, 32, 2):
-        A(f"v_add_f32 v{LS0}, v{LS0}, v{s_reg(i)}")
-        A(f"v_add_f32 v{LS1}, v{LS1}, v{s_reg(i + 1)}")
-    A(f"v_add_f32 v{LS0}, v{LS0}, v{LS1}")
-    A(f"v_fma_f32 %{OP_L}, %{OP_L}, v{ALPHA}, v{LS0}")
-    for j in range(16):
-        A(f"v_cvt_pk_bf16_f32 v{PF + j}, v{s_reg(2 * j)}, v{s_reg(2 * j + 1)}")
-    A("; ---- P V")
-    A("s_waitcnt lgkmcnt(8)")
+    A(f"{nomove}:")
+    A(f"v_cmp_eq_f32_e32 vcc, v{PB_NINF}, %{PO_M}")
+    A(f"v_cndmask_b32_e64 v{PB_MSAFE}, %{PO_M}, 0, vcc")        # a row with nothing unmasked yet: subtract 0, not -inf
+    A(f"v_mov_b32 v{PB_LS0}, 0")
+    A(f"v_mov_b32 v{PB_LS1}, 0")
+    A(f"v_mov_b32 v{PB_MSP}, v{PB_MSAFE}")
+    A(f"v_mov_b32 v{PB_MSP + 1}, v{PB_MSAFE}")
+    A(f"v_mov_b32 v{PB_SC2P}, %{PO_SC2}")
+    A(f"v_mov_b32 v{PB_SC2P + 1}, %{PO_SC2}")
+    A(f"{nodec}:")
+    # ---------------------------------------------------------------- addresses; V^T fragments of key step 0 of tile k
+    A(f"v_mov_b32 v{PB_KA}, %{PO_KADDR}")
+    for kd in range(1, 8):
+        A(f"v_xor_b32 v{PB_KA + kd}, {kd << 5}, %{PO_KADDR}")
+    A(f"v_mov_b32 v{PB_VA}, %{PO_VADDR}")
+    for db in range(1, 4):
+        A(f"v_xor_b32 v{PB_VA + db}, {db << 6}, %{PO_VADDR}")
     A("s_nop 1")
-    L.extend(pv(FA, 0))
-    A(f"s_bitcmp1_b32 %{OP_FLAGS}, 1")
-    A("s_cbranch_scc0 40f")
-    L.extend(vread(FA, 2))
-    A("s_waitcnt lgkmcnt(8)")
-    L.extend(pv(FB, 1))
-    L.extend(vread(FB, 3))
-    A("s_waitcnt lgkmcnt(8)")
-    L.extend(pv(FA, 2))
-    A("s_waitcnt lgkmcnt(0)")
-    L.extend(pv(FB, 3))
-    A("s_branch 41f")
-    A("40:")
-    A("s_waitcnt lgkmcnt(0)")
-    L.extend(pv(FB, 1))
-    A("41:")
+    nov0 = label()
+    bit(PF_CUR, nov0)
+    L.extend(vread(FB, 0))
+    A(f"{nov0}:")
+    # ---------------------------------------------------------------- region A
+    a3, a2, a1one, a2one, aend = label(), label(), label(), label(), label()
+    bit(PF_NEXT, a3)
+    bit(PF_CUR, a2)
+    bit(PF_NTWO, a1one)
+    L.extend(region_a(2, True))
+    A(f"s_branch {aend}f")
+    A(f"{a1one}:")
+    L.extend(region_a(1, True))
+    A(f"s_branch {aend}f")
+    A(f"{a2}:")
+    bit(PF_NTWO, a2one)
+    L.extend(region_a(2, False))
+    A(f"s_branch {aend}f")
+    A(f"{a2one}:")
+    L.extend(region_a(1, False))
+    A(f"s_branch {aend}f")
+    A(f"{a3}:")
+    L.extend(softmax_fillers(0, 16))
+    A(f"{aend}:")
+    # ---------------------------------------------------------------- V^T fragments of key step 1 (the K ring is free); causal mask of S_next
+    nov1 = label()
+    bit(PF_CUR, nov1)
+    L.extend(vread(FA, 1))
+    A(f"{nov1}:")
+    nomask = label()
+    bit(PF_NDIAG, nomask)
+    A("s_nop 15")                                               # MFMA D -> VALU
+    for i in range(32):
+        kb, r = divmod(i, 16)
+        c = kb * 32 + (r >> 2) * 8 + (r & 3)
+        A(f"v_cmp_gt_i32_e32 vcc, {c}, %{PO_THR}")
+        A(f"v_cndmask_b32_e32 v{SN + i}, v{SN + i}, v{PB_NINF}, vcc")
+    A(f"{nomask}:")
+    # ---------------------------------------------------------------- region B
+    bnocur, bone, b2n, b1n, bend = label(), label(), label(), label(), label()
+    bit(PF_CUR, bnocur)
+    bit(PF_CTWO, bone)
+    bit(PF_NEXT, b2n)
+    L.extend(region_b(4, True))
+    A(f"s_branch {bend}f")
+    A(f"{b2n}:")
+    L.extend(region_b(4, False))
+    A(f"s_branch {bend}f")
+    A(f"{bone}:")
+    bit(PF_NEXT, b1n)
+    L.extend(region_b(2, True))
+    A(f"s_branch {bend}f")
+    A(f"{b1n}:")
+    L.extend(region_b(2, False))
+    A(f"s_branch {bend}f")
+    A(f"{bnocur}:")
+    A("s_nop 15")
+    L.extend(max_fillers())
+    L.extend(max_finish())
+    A(f"{bend}:")
     return L
 
 
+def specialise(lines, flags):
+    """The generic body with every flag test resolved for one value of %7: s_bitcmp1 / s_cbranch_scc0 / s_branch disappear (a taken
+    or not-taken scalar branch costs a wave tens of cycles, and the generic body executes 18 of them per tile); the data-dependent
+    s_cbranch_vccz of the running-max decision stays."""
+    import re
+    where = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(\d+):$", ln)
+        if m:
+            where.setdefault(m.group(1), []).append(i)
+    out, pc, scc = [], 0, 0
+    while pc < len(lines):
+        ln = lines[pc]
+        op = ln.split()[0]
+        if op == "s_bitcmp1_b32":
+            assert ln.split()[1] == f"%{PO_FLAGS},", ln
+            scc = (flags >> int(ln.split(",")[1])) & 1
+        elif (op == "s_cbranch_scc0" and scc == 0) or op == "s_branch":
+            t = ln.split()[1][:-1]
+            pc = min(x for x in where[t] if x > pc)
+            continue
+        elif op == "s_cbranch_scc0":
+            pass
+        else:
+            out.append(ln)
+        pc += 1
+    return out
+
+
+PIPE_COMMON = (1 << PF_NTWO) | (1 << PF_STAGE) | (1 << PF_NEXT) | (1 << PF_CUR) | (1 << PF_CTWO)    # a tile below the diagonal, next one too
+
+
+def write_inc(name, lines):
+    with open(os.path.join(CSRC, name), "w") as f:
+        f.write("// generated by tools/gen_attn_asm.py -- do not edit\n")
+        for ln in lines:
+            f.write('"' + ln + '\\n"\n')
+
+
 def main():
-    lines = gen()
-    abl = set(os.environ.get("GEN_ATTN_ABL", "").split(","))     # TIMING-ONLY ablations (wrong results): nov, nok, nosm, nomfma
+    abl = set(os.environ.get("GEN_ATTN_ABL", "").split(","))     # TIMING-ONLY ablations (wrong results)
+
     def keep(ln):
         if "nov" in abl and ln.startswith("ds_read_b64_tr"):
             return False
         if "nok" in abl and ln.startswith("ds_read_b128"):
             return False
+        if "nold" in abl and ln.startswith("global_load_lds"):
+            return False
         if "nomfma" in abl and ln.startswith("v_mfma"):
             return False
-        if "nosm" in abl and ln.startswith(("v_exp_f32", "v_fma_f32 v", "v_add_f32", "v_max3", "v_cvt_pk")):
+        if "nosm" in abl and ln.startswith(("v_exp_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_add_f32", "v_max3", "v_cvt_pk")):
             return False
         return True
-    lines = [ln for ln in lines if keep(ln)]
-    with open(os.path.join(CSRC, "attn_fwd32_tile.inc"), "w") as f:
-        f.write("// generated by tools/gen_attn_asm.py -- do not edit\n")
-        for ln in lines:
-            f.write('"' + ln + '\\n"\n')
-    clob = [f'"v{i}"' for i in range(64, 128)] + [f'"a{i}"' for i in range(128)] + ['"vcc"', '"scc"', '"memory"']
-    with open(os.path.join(CSRC, "attn_fwd32_clobbers.inc"), "w") as f:
+    for par in (0, 1):
+        pl = [ln for ln in gen_pipe(par) if keep(ln)]
+        write_inc(f"attn_fwd32p_tile{par}.inc", pl)
+        print(f"attn_fwd32p_tile{par}.inc: {len(pl)} lines, {sum(ln.startswith('v_mfma') for ln in pl)} MFMAs (all paths)")
+        sp = specialise(pl, PIPE_COMMON)
+        write_inc(f"attn_fwd32p_tile{par}c.inc", sp)
+        print(f"attn_fwd32p_tile{par}c.inc: {len(sp)} lines, {sum(ln.startswith('v_mfma') for ln in sp)} MFMAs (flags == {PIPE_COMMON})")
+    clob = [f'"v{i}"' for i in range(40, 128)] + [f'"a{i}"' for i in range(128)] + ['"vcc"', '"scc"', '"memory"']
+    with open(os.path.join(CSRC, "attn_fwd32p_clobbers.inc"), "w") as f:
         f.write("// generated by tools/gen_attn_asm.py -- do not edit\n")
         f.write(", ".join(clob) + "\n")
-    n_mfma = sum(ln.startswith("v_mfma") for ln in lines)
-    print(f"attn_fwd32_tile.inc: {len(lines)} lines, {n_mfma} MFMAs (both paths)")
 
 
 if __name__ == "__main__":
