@@ -1,7 +1,7 @@
 #!/bin/bash
 # TIMING-ONLY ablation builds of the assembly attention forward (wrong results): libmla_hip with the generated tile bodies stripped of one
 # instruction class (GEN_ATTN_ABL: nosm = no softmax VALU, nomfma, nok / nov = no K / V^T fragment reads, nold = no global -> LDS staging copies). Usage: build_attn_abl.sh nosm nomfma ...
-# Output: mla_amd/csrc/build_tr/libabl_<name>.so (git-ignored); run with MLA_HIP_LIB=<that> MLA_ATTN_FWD=3 python tools/bench_attn.py
+# Output: mla_amd/csrc/build_tr/libabl_<name>.so (git-ignored); run with MLA_HIP_LIB=<that> MLA_ATTN_FWD=1 python tools/bench_attn.py
 set -e
 HERE="$(cd "$(dirname "$0")/.." && pwd)"; C="$HERE/mla_amd/csrc"; mkdir -p "$C/build_tr"
 [ -f "$C/build/api.o" ] || bash "$C/build.sh" >/dev/null

@@ -7,7 +7,7 @@ C=$(cd "$(dirname "$0")/../mla_amd/csrc" && pwd)
 mkdir -p $C/build_exp/$TAG
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result $EXTRA -c $C/$SRC -o $C/build_exp/$TAG/attention.o
 OBJS=""
-for f in api gemm gemm256 transpose elementwise loss pointcloud vision gen; do OBJS="$OBJS $C/build/$f.o"; done
+for o in $C/build/*.o; do [ "$(basename $o)" = attention.o ] || OBJS="$OBJS $o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $C/build_exp/$TAG/libmla_hip.so $OBJS $C/build_exp/$TAG/attention.o
 rm -f $C/build_exp/$TAG/attention.o
 echo "built $C/build_exp/$TAG/libmla_hip.so"

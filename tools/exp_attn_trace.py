@@ -1,6 +1,9 @@
-"""Per-iteration cycle stamps of one block of the pipelined attention forward (experiment build with -DMLA_ATTN_TRACE=<block>,
-tools/build_attn_flags.sh): where a wave's iteration goes -- wait for the staged tile (vmcnt), barrier, C++ glue, tile statement.
-Usage: MLA_HIP_LIB=mla_amd/csrc/build_tr/lib_trace.so MLA_ATTN_FWD=3 python tools/exp_attn_trace.py [S] [B]"""
+"""Per-iteration cycle stamps of one block of the assembly attention forward: where a wave's iteration goes -- wait for the staged
+tile (vmcnt), barrier, C++ glue, tile statement. Needs an experiment build that records them:
+    bash tools/build_attn_variant.sh trace "-DMLA_ATTN_TRACE=0"          (block 0 = the heaviest row block of the first (batch, head))
+    MLA_HIP_LIB=mla_amd/csrc/build_exp/trace/libmla_hip.so MLA_ATTN_FWD=1 [MLA_ATTN_LDS_EXTRA=16384] python tools/exp_attn_trace.py [S] [B]
+MLA_ATTN_LDS_EXTRA=16384 leaves one block per CU (one wave per SIMD: the statement's time without a competing wave). Each stamp
+(s_memtime + a global store) costs the interval it closes ~300 cycles. Numbers: HISTORY.md "Round 4"."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
