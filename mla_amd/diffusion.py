@@ -224,10 +224,16 @@ class TimestepEmbedder(nn.Module):  # models.py:28-65
                                  Linear(hidden_size, hidden_size, bias=True))
         self.frequency_embedding_size = frequency_embedding_size
 
+    _freqs = {}      # (half, max_period, device) -> the frequency table on that device (same values: computed on the host in fp32 once)
+
     @staticmethod
     def timestep_embedding(t, dim, max_period=10000):
         half = dim // 2
-        freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(device=t.device)
+        key = (half, max_period, str(t.device))
+        freqs = TimestepEmbedder._freqs.get(key)
+        if freqs is None:
+            freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(device=t.device)
+            TimestepEmbedder._freqs[key] = freqs
         args = t[:, None].float() * freqs[None]
         return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
