@@ -186,6 +186,11 @@ def main():
         # the parent (plain `python bench.py --gpus N`): never a silent smaller job, N ranks need N devices (one RCCL rank per GPU)
         if ndev < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible")
+    elif os.environ.get("MLA_BENCH_REHEARSAL") == "1":
+        # rehearsal of the N-rank control flow on ONE GPU (tools/rehearse_bench_ranks.sh): every rank uses device 0 and the collectives
+        # go through gloo. Only with --tiny (N replicas of the 7B model do not fit one GPU); the numbers mean nothing, the JSON line says so
+        if not args.tiny:
+            raise SystemExit("MLA_BENCH_REHEARSAL=1 needs --tiny")
     elif local_rank >= max(ndev, 1) and ndev != 1:
         # a launcher's worker: launchers that bind ONE visible device per rank (per-rank HIP_VISIBLE_DEVICES, SLURM --gpus-per-task=1)
         # show ndev == 1 with WORLD_SIZE == --gpus, which is fine; what must not happen is a rank without a device of its own
@@ -207,7 +212,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    dev_index = local_rank if local_rank < ndev else 0      # one-visible-device-per-rank launchers: every rank's device is index 0
+    rehearsal = os.environ.get("MLA_BENCH_REHEARSAL") == "1" and "RANK" in os.environ
+    dev_index = local_rank if (local_rank < ndev and not rehearsal) else 0      # one-visible-device-per-rank launchers: every rank's device is index 0
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     coll_knobs = {}
@@ -215,7 +221,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from mla_amd.fsdp import apply_rccl_env
         coll_knobs = apply_rccl_env()           # MLA_RCCL_MAX_CHANNELS / MLA_GEMM_CUS / MLA_FSDP_INPLACE_RS
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from mla_amd import hip
     from mla_amd.strategy import FSDPStrategy
@@ -404,6 +413,9 @@ def main():
                "mfu_vs_2.5PF": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                "loss": {k: float(v) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1},
                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+        if rehearsal:
+            out["rehearsal"] = "MLA_BENCH_REHEARSAL=1: all ranks on ONE GPU over gloo, tiny model -- control flow only, not a measurement"
+            out["config"]["parallelism"] = f"fsdp-gloo x{world} on one device (rehearsal)"
         if per_rank:
             out["per_rank"] = per_rank
             out["collective_knobs"] = {**coll_knobs, "inplace_reduce_scatter": bool(strat.sharded.inplace_reduce), "gemm_planned_cus": hip.gemm_cus() or "device"}
