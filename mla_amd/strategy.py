@@ -43,6 +43,15 @@ class FSDPStrategy:
         if sharding_strategy not in ("full-shard", "shard-grad-op"):
             raise ValueError(f"FSDP Sharding Strategy {sharding_strategy} is not supported!")
         self.worker_init_fn, self.sharding_strategy = worker_init_fn, sharding_strategy
+        # One layout for both names (deviation 12): torch FSDP's FULL_SHARD frees the gathered parameters after
+        # each unit's forward / backward, SHARD_GRAD_OP keeps them until the backward is over; here the full bf16 replica (12.9 GiB at 7B)
+        # and the full fp32 gradient buffer (25.8 GiB) stay resident on every rank and only masters + AdamW moments + the reduced
+        # gradient shard are 1/world. Results are identical; say so once instead of silently treating the names as synonyms.
+        import logging
+        logging.getLogger(__name__).info(
+            "FSDPStrategy(sharding_strategy=%r): 'full-shard' and 'shard-grad-op' select the SAME layout in this build -- bf16 weights "
+            "replicated and resident, fp32 gradients reduced into 1/world shards, fp32 masters and AdamW moments sharded 1/world",
+            sharding_strategy)
         self.last_lr = learning_rate
         self.vlm, self.stage = vlm, stage
         self.device = torch.device("cuda", device_id) if isinstance(device_id, int) else torch.device(device_id)
@@ -260,7 +269,10 @@ def get_train_strategy(train_strategy: str, vlm, device_id: int, stage: str, epo
                        worker_init_fn=None, requires_cliploss: bool = False) -> FSDPStrategy:
     """Same signature, defaults and error as training/materialize.py:22-68. NB the factory's default
     `reduce_in_full_precision=False` meets the strategy's fp32-only reduction: scripts/train.py always passes the VLAConfig value
-    (True, conf/vla.py:55); a caller relying on the bf16-reduction default gets the NotImplementedError of FSDPStrategy."""
+    (True, conf/vla.py:55); a caller relying on the bf16-reduction default gets the NotImplementedError of FSDPStrategy.
+    "fsdp-shard-grad-op" and "fsdp-full-shard" (training/strategies/fsdp.py:88-93) both resolve to the one layout this build has:
+    resident bf16 replica + full fp32 gradient buffer per rank, masters / moments / reduced gradients sharded 1/world (38.8 GiB of
+    un-sharded state per rank at every world size, DESIGN.md section 4 table and section 7 #12) -- the strategy logs that at INFO."""
     if train_strategy not in TRAIN_STRATEGIES:
         raise ValueError(f"Train Strategy `{train_strategy}` is not supported!")
     cfg = TRAIN_STRATEGIES[train_strategy]

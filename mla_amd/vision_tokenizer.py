@@ -151,15 +151,17 @@ class VisionTokenizer(nn.Module):
     def device(self):
         return self.patch_embedding.weight.device
 
-    def tokens(self, pixel_values: torch.Tensor) -> torch.Tensor:
-        """[B, 4, 672, 672] (RGB + mask channel, fp32 or bf16) -> [B, 256, C] bf16 tokens (before the projector)."""
+    def tokens(self, pixel_values: torch.Tensor, check_mask: bool = True) -> torch.Tensor:
+        """[B, 4, Hi, Wi] (RGB + mask channel, fp32 or bf16; 672 x 672 on the training path) -> [B, (Hi/42) * (Wi/42), C] bf16 tokens
+        (before the projector). The mask channel is NOT applied here: this is the whole-grid dataflow."""
         B, CT, Hi, Wi = pixel_values.shape
         P, cs, C = self.patch_stride, self.conv_stride, self.hidden_size
         gh, gw = Hi // P, Wi // P
-        # only the all-ones pixel mask is supported; the verdict is read back by assert_masks_ok() -- called by the owner at its next
+        # the batched path is the all-ones-mask dataflow; the verdict is read back by assert_masks_ok() -- called by the owner at its next
         # host synchronisation point (PrismaticVLM.forward, right after the contrastive index) so that the check does not stall an
-        # empty launch queue at the very start of the step
-        self._mask_ok = (pixel_values[:, -1] == 1).all()
+        # empty launch queue at the very start of the step. Cropped masks go through forward(..., allow_crop=True) / crop_boxes().
+        if check_mask:
+            self._mask_ok = (pixel_values[:, -1] == 1).all()
         kreal = 3 * P * P
         kpad = ((kreal + 31) // 32) * 32
         la = self.local_attention
@@ -193,14 +195,50 @@ class VisionTokenizer(nn.Module):
         if ok is not None:
             self._mask_ok = None
             if not bool(ok):
-                raise NotImplementedError("cropped pixel masks: only the all-ones mask yields the 256 tokens the reference's "
-                                          "N_img = 256 layout needs (models/vlm/prismatic.py:932-933)")
+                raise NotImplementedError("cropped pixel masks inside PrismaticVLM: only the all-ones mask yields the 256 tokens the "
+                                          "reference's N_img = 256 layout needs (models/vlm/prismatic.py:932-933); the tokenizer itself "
+                                          "handles them: VisionTokenizer.forward(pixel_values, projector, allow_crop=True)")
 
-    def forward(self, pixel_values, modules, repeat: int = 1):
-        """Reference signature (pixel_values, projector) -> (list of [256, token_size] tokens, list of [h, w]).
+    def crop_boxes(self, pixel_values: torch.Tensor):
+        """Per-sample patch rectangles of the reference's crop (models/mla/image/vision_tokenizer.py:124-137): the pixel mask pooled to
+        the patch grid must consist of whole patches (:127); an all-zero mask keeps the top-left 16 x 16 patches (:131-132), any other
+        the rectangle spanned by its first and last non-zero patch in row-major order (:134-137). Host-side (one device read):
+        returns [(h1, h2, w1, w2)] inclusive, or None when every mask is all ones (the batched path applies)."""
+        P = self.patch_stride
+        pm = F.avg_pool2d(pixel_values[:, -1:].float(), kernel_size=P, stride=P)[:, 0]
+        if bool((pm == 1).all()):
+            return None
+        pm = pm.cpu()
+        if bool((pm % 1 != 0).any()):
+            raise ValueError("pixel mask is not made of whole 14 x 14 patches (the reference asserts this, vision_tokenizer.py:127)")
+        boxes = []
+        for m in pm:
+            if float(m.sum()) == 0:
+                boxes.append((0, 15, 0, 15))
+            else:
+                nz = torch.nonzero(m, as_tuple=False)
+                boxes.append((int(nz[0, 0]), int(nz[-1, 0]), int(nz[0, 1]), int(nz[-1, 1])))
+        return boxes
+
+    def forward(self, pixel_values, modules, repeat: int = 1, allow_crop: bool = False):
+        """Reference signature (pixel_values, projector) -> (list of [h * w, token_size] tokens, list of [h, w]).
         ``repeat``: the batch is ``repeat`` tiled copies of its first B/repeat samples (MLA.forward tiles every input
-        R times, models/mla/model_mla.py:159-169); the frozen, deterministic tower then runs once per distinct image."""
+        R times, models/mla/model_mla.py:159-169); the frozen, deterministic tower then runs once per distinct image.
+        ``allow_crop``: honour cropped pixel masks like the reference's per-sample loop (:129-150) -- one host read of the pooled
+        masks, then every cropped sample runs the same kernels on its own patch rectangle (floor(H/3) x floor(W/3) tokens; the
+        average pool and the window unfold both drop the remainder rows / columns, so the rectangle is cut to multiples of 3).
+        PrismaticVLM never sets it: its N_img = 256 layout (prismatic.py:932-933) only fits the all-ones mask."""
         B = pixel_values.shape[0]
+        boxes = self.crop_boxes(pixel_values) if allow_crop else None
+        if boxes is not None:
+            P, cs = self.patch_stride, self.conv_stride
+            outs, hws = [], []
+            for i, (h1, h2, w1, w2) in enumerate(boxes):
+                h, w = (h2 - h1 + 1) // cs, (w2 - w1 + 1) // cs
+                sub = pixel_values[i:i + 1, :, h1 * P:(h1 + h * cs) * P, w1 * P:(w1 + w * cs) * P]
+                outs.append(modules(self.tokens(sub, check_mask=False))[0])
+                hws.append(torch.tensor([h, w], dtype=torch.long, device=pixel_values.device))
+            return outs, hws
         if repeat > 1:
             tok = self.tokens(pixel_values[: B // repeat]).repeat(repeat, 1, 1)
         else:

@@ -328,6 +328,30 @@ def vision_tokenizer(pixel_values, w: dict, proj: dict, patch: int = 14):
     return mlp_projector(toks, proj["w0"], proj["b0"], proj["w2"], proj["b2"])
 
 
+def vision_tokenizer_cropped(pixel_values, w: dict, proj: dict, patch: int = 14, conv_stride: int = 3):
+    """VisionTokenizer.forward vision_tokenizer.py:119-150 INCLUDING the per-sample crop (:124-137): the pixel mask (last channel) is
+    average-pooled to the patch grid; a sample whose patch mask is all zero keeps the top-left 16 x 16 patches (:131-132), any other keeps
+    the rectangle spanned by the first and the last non-zero patch in row-major order (:134-137). Local attention then runs on that
+    sub-grid (floor(H/3) x floor(W/3) tokens). Returns (list of [h*w, token] tensors, list of [h, w]) like the reference."""
+    rgb, mask = pixel_values[:, :-1], pixel_values[:, -1:]
+    pe = F.conv2d(rgb, w["patch_w"], stride=patch)
+    pm = F.avg_pool2d(mask, kernel_size=patch, stride=patch)
+    assert len(torch.where(pm % 1)[0]) == 0          # :127 patch masks are whole patches
+    toks, hws = [], []
+    for i in range(pe.shape[0]):
+        if pm[i, 0].sum() == 0:
+            sub = pe[i, :, :16, :16]
+        else:
+            nz = torch.nonzero(pm[i, 0], as_tuple=False)
+            (h1, w1), (h2, w2) = nz[0], nz[-1]
+            sub = pe[i, :, h1:h2 + 1, w1:w2 + 1]
+        Hs, Ws = sub.shape[1:]
+        t = local_attention(sub.unsqueeze(0), w, conv_stride)[0]
+        toks.append(mlp_projector(t, proj["w0"], proj["b0"], proj["w2"], proj["b2"]))
+        hws.append(torch.tensor([Hs // conv_stride, Ws // conv_stride]))
+    return toks, hws
+
+
 # ------------------------------------------------------------------------------------------------- point tokenizer
 def furthest_point_sample(xyz: torch.Tensor, npoint: int, start: torch.Tensor) -> torch.Tensor:
     """models/mla/pointcloud/backbone/Point_PN.py:6-21 with the random start index made an explicit input."""

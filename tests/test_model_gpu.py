@@ -100,6 +100,38 @@ def test_vision_tokenizer_tokens(dev, comp):
     assert torch.equal(torch.stack(toks2)[:2], torch.stack(toks)) and torch.equal(torch.stack(toks2)[2:], torch.stack(toks))
 
 
+@pytest.mark.parametrize("case", ["rect_div", "rect_rem", "all_zero", "full"])
+def test_vision_tokenizer_cropped_mask_matches_reference(dev, case):
+    """a5, the cropped pixel-mask path (models/mla/image/vision_tokenizer.py:124-137) against the reference's own output at B = 1
+    (tests/golden/vision_crop.npz from oracle/capture_golden_crop.py): token count [h, w] exact, tokens at the bf16 level of the
+    all-ones case above."""
+    from mla_amd.vision_tokenizer import MLP_GELU, VisionTokenizer
+    from oracle.capture_golden_crop import make_pixels
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vision_crop.npz"))
+    vt = VisionTokenizer(1024)
+    vt.load_state_dict({k: recipe.det_weight("vlm.vision_tower_2d." + k, v.shape) for k, v in vt.state_dict().items()})
+    proj = MLP_GELU(1024, recipe.TOKEN_SIZE, 2)
+    proj.load_state_dict({k: recipe.det_weight("vlm.projector_2d." + k, v.shape) for k, v in proj.state_dict().items()})
+    vt.requires_grad_(False).to(dev)
+    proj.to(dev)
+    for p in list(vt.parameters()) + list(proj.parameters()):
+        p.data = p.data.to(BF)
+    px = make_pixels(case).to(dev)
+    toks, hw = vt(px, proj, allow_crop=True)
+    assert len(toks) == 1 and hw[0].tolist() == g[f"{case}_hw"].tolist()
+    want = torch.from_numpy(g[f"{case}_tokens_slice"])
+    assert toks[0].shape[0] == want.shape[0]
+    assert fro_rel(toks[0][:, :64], want) < 2e-2
+    if case != "full":       # without allow_crop the batched path runs and the owner's deferred check rejects the mask
+        vt(px, proj)
+        with pytest.raises(NotImplementedError):
+            vt.assert_masks_ok()
+    # a mixed batch: every sample takes its own rectangle
+    both = torch.cat([px, make_pixels("rect_div").to(dev)])
+    toks2, hw2 = vt(both, proj, allow_crop=True)
+    assert hw2[1].tolist() == [12, 12] and torch.equal(toks2[0], toks[0])
+
+
 @pytest.mark.parametrize("save_level", [2, 1, 0])
 @pytest.mark.parametrize("lens", [None, [100, 37], "odd"])
 def test_decoder_layer_fwd_bwd(dev, save_level, lens):

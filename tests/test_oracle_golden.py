@@ -373,3 +373,20 @@ def test_clip_preprocess_oracle_bit_exact_vs_pil_and_vendored_processor():
     ref_h = O.pil_bicubic_resize_u8(np.ascontiguousarray(img), 672)      # full result; compare through a vertical identity is not possible,
     assert col.shape == (224, 3) and ref_h.shape == (672, 672, 3)        # so check the tables' invariants instead:
     assert np.all(c.sum(1) >= (1 << 22) - 4) and np.all(c.sum(1) <= (1 << 22) + 4)   # taps sum to 1.0 in fixed point (rounding slack)
+
+
+@pytest.mark.parametrize("case", ["rect_div", "rect_rem", "all_zero", "full"])
+def test_vision_tokenizer_cropped_mask(case):
+    """the cropped pixel-mask path (vision_tokenizer.py:124-137) against the reference at B = 1
+    (tests/golden/vision_crop.npz, oracle/capture_golden_crop.py)."""
+    from tests_shapes import MLA_TINY_SHAPES
+    from oracle.capture_golden_crop import make_pixels
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vision_crop.npz"))
+    sd = recipe.make_state_dict({k: v for k, v in MLA_TINY_SHAPES.items()
+                                 if k.startswith("vlm.vision_tower_2d.") or k.startswith("vlm.projector_2d.")})
+    P = "vlm.projector_2d.mlp."
+    with torch.no_grad():
+        toks, hw = O.vision_tokenizer_cropped(make_pixels(case), mla_oracle.vision_weights(sd),
+                                              dict(w0=sd[P + "0.weight"], b0=sd[P + "0.bias"], w2=sd[P + "2.weight"], b2=sd[P + "2.bias"]))
+    assert hw[0].tolist() == g[f"{case}_hw"].tolist()
+    assert np.allclose(toks[0][:, :64].numpy(), g[f"{case}_tokens_slice"], rtol=2e-4, atol=2e-4)
