@@ -105,7 +105,9 @@ def capture_heads():
     print("  params without gradient:", list(res["no_grad_names"]))
 
 
-def capture_e2e_gen(R=2):
+def _run_e2e_gen(mode, R=2):
+    """mode "A": fp32 module, fp32 inputs (the plain import); "C": model.to(bf16) + autocast(cpu, bf16) with bf16 float inputs -- what
+    FSDP mixed precision feeds the reference on the GPU (SURVEY Appendix A #20); same recipe as capture_golden.run_reference."""
     g = recipe.GEN_TINY
     mla = ref_import.build_reference_mla(recipe.TINY_LLAMA | {"vocab_size": recipe.TINY_LLAMA["vocab_size"] + 1}, recipe.TOKEN_SIZE,
                                          generation=dict(use_generation=True, gen_image=True, use_roi=False, gen_pointcloud=True,
@@ -124,23 +126,39 @@ def capture_e2e_gen(R=2):
     _print = builtins.print
     builtins.print = lambda *a, **k: None
     try:
-        up = lambda m, a: tuple(x.float() if torch.is_tensor(x) and x.is_floating_point() else x for x in a)  # noqa: E731
-        mla.vlm.proprio_embedder.register_forward_pre_hook(up)
-        mla.vlm.x_embedder.register_forward_pre_hook(up)
-        with _Draws(draws, 2 * R):
-            loss_dict, out = mla(**kw)
+        if mode == "A":
+            up = lambda m, a: tuple(x.float() if torch.is_tensor(x) and x.is_floating_point() else x for x in a)  # noqa: E731
+            mla.vlm.proprio_embedder.register_forward_pre_hook(up)
+            mla.vlm.x_embedder.register_forward_pre_hook(up)
+            with _Draws(draws, 2 * R):
+                loss_dict, out = mla(**kw)
+        else:
+            mla.to(torch.bfloat16)
+            kw["images"] = {k: v.to(torch.bfloat16) for k, v in kw["images"].items()}
+            for k in ("point_cloud", "actions", "proprio", "next_images", "next_point_cloud"):
+                kw[k] = kw[k].to(torch.bfloat16)
+            with _Draws(draws, 2 * R), torch.autocast("cpu", dtype=torch.bfloat16):
+                loss_dict, out = mla(**kw)
         loss_dict["total_loss"].float().backward()
     finally:
         builtins.print = _print
     grads = {k: p.grad for k, p in mla.named_parameters() if p.grad is not None}
+    return shapes, loss_dict, grads
+
+
+def capture_e2e_gen(R=2):
+    res = {}
     f = lambda t: t.detach().float().numpy()  # noqa: E731
-    res = {f"A_{k}": f(v) for k, v in loss_dict.items()}
-    res["A_gradnorms"] = np.array([float(grads[k].float().norm()) for k in sorted(grads)], dtype=np.float64)
-    res["grad_names"] = np.array(sorted(grads))
-    res["param_names"] = np.array(sorted(shapes))
-    res["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
+    for mode in ("A", "C"):
+        shapes, loss_dict, grads = _run_e2e_gen(mode, R)
+        res.update({f"{mode}_{k}": f(v) for k, v in loss_dict.items()})
+        if mode == "A":
+            res["grad_names"] = np.array(sorted(grads))
+            res["param_names"] = np.array(sorted(shapes))
+            res["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
+        res[f"{mode}_gradnorms"] = np.array([float(grads[k].float().norm()) if k in grads else 0.0 for k in res["grad_names"]], dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "mla_tiny_e2e_gen.npz"), **res)
-    print("mla_tiny_e2e_gen.npz:", {k: float(v) for k, v in res.items() if k.startswith("A_") and np.ndim(v) == 0})
+    print("mla_tiny_e2e_gen.npz:", {k: float(v) for k, v in res.items() if k[:2] in ("A_", "C_") and np.ndim(v) == 0})
 
 
 if __name__ == "__main__":

@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""profiles/rNN_parity_table.txt: the measured end-to-end parity numbers behind the bounds of tests/test_model_gpu.py::
+test_mla_e2e_against_reference_golden and tests/test_generation_gpu.py::test_mla_e2e_post_training.
+
+For every compared tensor: err(hip, A) and the yardstick err(C, A), where A = the reference in fp32 and C = the reference in its own
+GPU arithmetic (model.to(bf16) + bf16 autocast), both captured from the imported reference (tests/golden/mla_tiny_e2e*.npz).
+err = Frobenius-relative for tensors, |x - A| / A for gradient norms. Run on the GPU box:
+    python tools/parity_table.py > gpurun_out/parity_table.txt
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def err(a, ref):
+    return float(np.linalg.norm(a - ref) / (np.linalg.norm(ref) + 1e-30))
+
+
+def sft(dev):
+    import test_model_gpu as T
+    e2e = np.load(os.path.join(G, "mla_tiny_e2e.npz"), allow_pickle=True)
+    m, ld, out = T._run_hip_e2e(dev)
+    print("== tiny MLA SFT step (BASELINE configs[0] shapes) vs reference golden: hip | mode C | ratio hip / C")
+    for k, got, a, c in (("total_loss", ld["total_loss"], "A_total_loss", "C_total_loss"),
+                         ("img_pc_contrastive_loss", ld["img_pc_contrastive_loss"], "A_contrastive", "C_contrastive"),
+                         ("llm_loss", out.loss, "A_llm_loss", "C_llm_loss")):
+        A, C = float(e2e[a]), float(e2e[c])
+        print(f"loss {k:<28} |hip - A| {abs(float(got) - A):.2e} | |C - A| {abs(C - A):.2e}   (A = {A:.6f})")
+    for name, got in (("hidden8_slice", out.hidden_states[8][:, 250:270, :32]), ("last_hidden_slice", out.hidden_states[-1][:, -8:, :32]),
+                      ("logits_slice", out.logits[:, -8:, :64])):
+        A, C = e2e["A_" + name], e2e["C_" + name]
+        g = got.detach().float().cpu().numpy()
+        if name != "hidden8_slice":
+            keep = np.ones(A.shape[:2], dtype=bool)
+            keep[1, -3:] = keep[3, -3:] = False
+            A, C, g = A[keep], C[keep], g[keep]
+        print(f"act  {name:<28} {err(g, A):.2e} | {err(C, A):.2e} | {err(g, A) / err(C, A):.2f}")
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    for key in e2e.files:
+        if key.startswith("A_grad::"):
+            n = key[len("A_grad::"):]
+            A, C = e2e[key], e2e["C_grad::" + n]
+            g = grads[n].float().cpu()
+            g = (g if tuple(g.shape) == A.shape else g[:16, :64]).numpy()
+            print(f"grad {n:<95} {err(g, A):.2e} | {err(C, A):.2e} | {err(g, A) / err(C, A):.2f}")
+    names = [str(n) for n in e2e["grad_names"]]
+    gn = np.array([float(grads[k].float().norm()) for k in names])
+    A, C = e2e["A_gradnorms"], e2e["C_gradnorms"]
+    relA, relC = np.abs(gn - A) / (A + 1e-12), np.abs(C - A) / (A + 1e-12)
+    print(f"gradient norms over {len(names)} parameters: median rel hip {np.median(relA):.2e} | mode C {np.median(relC):.2e}; "
+          f"max hip {relA.max():.2e} | max C {relC.max():.2e}")
+    print("parameters with rel(hip) > 2 x rel(C) (norm A, rel hip, rel C):")
+    for n, a, ra, rc in sorted(zip(names, A, relA, relC), key=lambda t: -t[2]):
+        if ra > 2 * rc:
+            print(f"   {n:<100} |A| {a:.3e}  hip {ra:.2e}  C {rc:.2e}")
+
+
+def gen(dev):
+    import test_generation_gpu as T
+    m, gold = T.build_tiny_mla_gen(dev)
+    from oracle import recipe
+    batch, draws = recipe.make_batch(R=2, with_next=True)
+    m.vlm.vision_tower_3d.fps_starts_override = [draws["fps_start0"], draws["fps_start1"]]
+    to = lambda v: v.to(dev)  # noqa: E731
+    BF = torch.bfloat16
+    ld, out = m(input_ids=to(batch["input_ids"]), attention_mask=to(batch["attention_mask"]), labels=to(batch["labels"]),
+                images={"front_image": to(batch["images"]["front_image"]).to(BF)}, next_images=to(batch["next_images"]).to(BF),
+                point_cloud=to(batch["point_cloud"]), next_point_cloud=to(batch["next_point_cloud"]), actions=to(batch["actions"]),
+                proprio=to(batch["proprio"]), action_masks=to(batch["action_masks"]), camera_name=batch["camera_name"],
+                repeated_diffusion_steps=2, use_diff=True, noise=to(draws["noise"]), timestep=to(draws["timestep"]))
+    ld["total_loss"].backward()
+    print("\n== tiny MLA post-training step (configs[3] scaled down) vs reference golden: hip | mode C")
+    for k in ("total_loss", "image_gen_loss", "point_cloud_gen_loss", "img_pc_contrastive_loss"):
+        A, C = float(gold["A_" + k]), float(gold["C_" + k])
+        print(f"loss {k:<28} |hip - A| {abs(float(ld[k]) - A):.2e} | |C - A| {abs(C - A):.2e}   (A = {A:.6f})")
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    names = [str(n) for n in gold["grad_names"]]
+    A, C = gold["A_gradnorms"], gold["C_gradnorms"]
+    gn = np.array([float(grads[k].float().norm()) if k in grads else 0.0 for k in names])
+    live = A > 0
+    relA, relC = np.abs(gn - A)[live] / A[live], np.abs(C - A)[live] / A[live]
+    ln = np.array(names)[live]
+    print(f"gradient norms over {live.sum()} live parameters: median rel hip {np.median(relA):.2e} | mode C {np.median(relC):.2e}; "
+          f"max hip {relA.max():.2e} | max C {relC.max():.2e}")
+    print("parameters with rel(hip) > 2 x rel(C) (norm A, rel hip, rel C):")
+    for n, a, ra, rc in sorted(zip(ln, A[live], relA, relC), key=lambda t: -t[2]):
+        if ra > 2 * rc:
+            print(f"   {n:<100} |A| {a:.3e}  hip {ra:.2e}  C {rc:.2e}")
+    print("largest rel(C) (the yardstick's own tail):")
+    for n, a, ra, rc in sorted(zip(ln, A[live], relA, relC), key=lambda t: -t[3])[:8]:
+        print(f"   {n:<100} |A| {a:.3e}  hip {ra:.2e}  C {rc:.2e}")
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda", 0)
+    sft(dev)
+    gen(dev)
