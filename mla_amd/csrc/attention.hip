@@ -35,6 +35,27 @@
 
 #include <math.h>
 
+// Experiment build (tools/build_attn_variant.sh btrace "-DMLA_ATTN_BTRACE"): block-phase cycle stamps of the two backward kernels ->
+// mla_attn_btrace(). Per block (thread 0): 0 entry, 1 prologue issued, 2 first tile ready, 3 main loop done, 4 epilogue staged in LDS,
+// 5 stores issued, 6 tiles, 7 HW_ID | XCC_ID << 32 (which CU ran it: per-CU timelines show the gap between one block's last store
+// and the next block's entry). tools/exp_attn_btrace.py reduces them.
+#ifdef MLA_ATTN_BTRACE
+#define BTRACE_N 16384
+__device__ unsigned long long g_btrace[2][BTRACE_N][8];
+#define BT(kern, pt)                                                                                              \
+  do {                                                                                                            \
+    if (blockIdx.x < BTRACE_N && threadIdx.x == 0) g_btrace[kern][blockIdx.x][pt] = __builtin_readcyclecounter(); \
+  } while (0)
+#define BTV(kern, pt, val)                                                                                        \
+  do {                                                                                                            \
+    if (blockIdx.x < BTRACE_N && threadIdx.x == 0) g_btrace[kern][blockIdx.x][pt] = (unsigned long long)(val);    \
+  } while (0)
+#define BT_HWID() ((unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32))
+#else
+#define BT(kern, pt) ((void)0)
+#define BTV(kern, pt, val) ((void)0)
+#endif
+
 namespace {
 
 constexpr int D = 128;
@@ -903,6 +924,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
     dq_pad_block<RB>(p, myq, b, h, lane);
     return;
   }
+  BT(0, 0);
+  BTV(0, 6, nkt);
+#ifdef MLA_ATTN_BTRACE
+  BTV(0, 7, BT_HWID());
+#endif
   bf16x8_t qf[RB][4], dof[RB][4];
   f32x4_t dqt[RB][8];
   float lse2[RB], dlt[RB];
@@ -940,9 +966,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
 
   stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
   stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
+  BT(0, 1);
   for (int kt = 0; kt < nkt; ++kt) {
     ATTN_WAIT_VM0();
     __syncthreads();
+    if (kt == 0) BT(0, 2);
     const char* kt_ = smem + (kt & 1) * 2 * TILE_BYTES;
     const char* vt_ = kt_ + TILE_BYTES;
     if (kt + 1 < nkt) {
@@ -962,7 +990,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
       dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
     }
   }
+  BT(0, 3);
   dq_epilogue<RB, NW>(p, smem, dqt, myq, padq, b, h, q0, wave, lane);
+  BT(0, 5);
 }
 
 // ------------------------------------------------------------------------------------------------ 5-product backward (round 3)
@@ -1184,6 +1214,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   const float* dl_p = p.delta + ((long long)b * p.H + h) * p.S;
   float* stats = (float*)(smem + 4 * TILE_BYTES);  // [2 buffers][lse 64 | delta 64]
 
+  BT(1, 0);
+#ifdef MLA_ATTN_BTRACE
+  BTV(1, 7, BT_HWID());
+#endif
   const int kc = mykey < p.S ? mykey : p.S - 1;
   bf16x8_t kf[4], vf[4];
   load_row_frags(p.k + ((long long)b * p.S + kc) * p.ld + h * D, lane, kf);
@@ -1215,11 +1249,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     stage_rows64<ASW>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
     if (threadIdx.x < 128) nstat = load_stat(qt0);
   }
+  BT(1, 1);
+  BTV(1, 6, nqt_end - qt0);
   for (int qt = qt0; qt < nqt_end; ++qt) {
     const int bufi = (qt - qt0) & 1;
     if (threadIdx.x < 128) stats[bufi * 128 + threadIdx.x] = nstat;
     ATTN_WAIT_VM0();
     __syncthreads();
+    if (qt == qt0) BT(1, 2);
     if (qt + 1 < nqt_end && threadIdx.x < 128) nstat = load_stat(qt + 1);
     const char* qt_ = smem + bufi * 2 * TILE_BYTES;
     const char* dot_ = qt_ + TILE_BYTES;
@@ -1278,6 +1315,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(qt_, fd, 1, lane), ds1, dkt[fd], 0, 0, 0);
     }
   }
+  BT(1, 3);
   // ---- epilogue. Everything leaves through LDS (the Q / dO ring is free now) as whole row runs: dk / dv rows as 256 B (16 B per
   // lane, 4 rows per store instruction), dk^T / dv^T as 128-B runs per channel row. Stored straight from the MFMA layout it is
   // 8 B per lane = 32-B pieces of 16 different rows per instruction, and a workgroup keeps its CU until its last partial-line store
@@ -1317,6 +1355,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
   }
   __syncthreads();
+  BT(1, 4);
   {
     const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
 #pragma unroll
@@ -1344,6 +1383,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
   }
   (void)nkb;
+  BT(1, 5);
 }
 
 int check_common(const AttnArgs& p, const char* who) {
@@ -1358,6 +1398,9 @@ int check_common(const AttnArgs& p, const char* who) {
 
 #ifdef MLA_ATTN_TRACE
 extern "C" int mla_attn_trace(void* host, int bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_trace), bytes); }
+#endif
+#ifdef MLA_ATTN_BTRACE
+extern "C" int mla_attn_btrace(void* host, int bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_btrace), bytes); }
 #endif
 
 extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,

@@ -334,22 +334,37 @@ def test_mla_e2e_post_training(dev):
     sd = {k: recipe.det_weight(k, v.shape) for k, v in m.state_dict().items()}
     with torch.no_grad():
         ref = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, zero_pad_rows=True, gen_cfg=GEN_CFG)
-    assert abs(float(ld["image_gen_loss"]) - float(ref["image_gen_loss"])) < 3e-2
-    assert abs(float(ld["point_cloud_gen_loss"]) - float(ref["point_cloud_gen_loss"])) < 2e-2
-    assert abs(float(ld["total_loss"]) - float(ref["total_loss"])) < 8e-2
+    # vs the oracle with the kernels' own (flash / varlen) pad-row semantics: the generation heads READ pad rows (mean pool, cross
+    # attention without a key mask), so this is the like-for-like comparison; bound = the bf16 spread of the
+    # reference on the same quantity, 2 x |C - A| from the golden below
+    spread = {k: 2 * abs(float(gold["C_" + k]) - float(gold["A_" + k])) for k in ("image_gen_loss", "point_cloud_gen_loss", "total_loss")}
+    for k in spread:
+        assert abs(float(ld[k]) - float(ref[k])) <= spread[k], (k, float(ld[k]), float(ref[k]), spread[k])
     assert ld["diff_loss"] is ld["total_loss"]
-    # vs the (eager-attention) reference capture: pad rows differ slightly, losses stay close
-    assert abs(float(ld["image_gen_loss"]) - float(gold["A_image_gen_loss"])) < 5e-2
-    assert abs(float(ld["point_cloud_gen_loss"]) - float(gold["A_point_cloud_gen_loss"])) < 5e-2
+    # vs the (eager-attention) reference capture: yardstick alone, |hip - A| <= 2 |C - A| (measured 4.3e-4 / 3.3e-3 / 7.0e-3 against
+    # |C - A| = 3.8e-3 / 3.5e-3 / 2.1e-2; profiles/r5_parity_table.txt)
+    for k in spread:
+        assert abs(float(ld[k]) - float(gold["A_" + k])) <= spread[k], (k, float(ld[k]), float(gold["A_" + k]), spread[k])
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     names = [str(n) for n in gold["grad_names"]]
-    A = gold["A_gradnorms"]
+    A, C = gold["A_gradnorms"], gold["C_gradnorms"]
     gn = np.array([float(grads[k].float().norm()) if k in grads else 0.0 for k in names])
-    live = A > 0
-    assert all((k in grads) or not l for k, l in zip(names, live))
-    rel = np.abs(gn - A)[live] / A[live]
-    assert np.median(rel) < 3e-2, np.median(rel)
-    assert (rel < 0.15).mean() > 0.95, [(n, r) for n, r in zip(np.array(names)[live], rel) if r >= 0.15][:8]
+    # Named exceptions (gradient analytically ZERO; both reference runs hold only rounding noise there, |A| < 1e-7 against 1e-2 .. 1e+1):
+    #   image_gen_module.mae_alpha_head / mae_offset_head  -- use_roi=False: the heads feed nothing (exactly 0 in the reference, none here)
+    #   pointcloud_gen_module.future_predictor.0.bias       -- a Linear bias in front of train-mode BatchNorm: the batch mean removes it
+    #   pointcloud_gen_module.decoder_blocks.1.mlp.3.bias   -- the last block's output bias in front of the same mean-removing path
+    zero = {n for n in names if n.startswith(("vlm.generation_manager.image_gen_module.mae_alpha_head", "vlm.generation_manager.image_gen_module.mae_offset_head"))}
+    zero |= {"vlm.generation_manager.pointcloud_gen_module.future_predictor.0.bias", "vlm.generation_manager.pointcloud_gen_module.decoder_blocks.1.mlp.3.bias"}
+    live = np.array([n not in zero for n in names])
+    assert set(np.array(names)[A <= 1e-6]) == zero, "the reference's zero-gradient set changed"
+    assert all(k in grads for k in np.array(names)[live]), "a parameter with a reference gradient got none"
+    # on the analytically-zero set err(x, A) is |x| itself: the yardstick there is |hip| <= 2 |C| (C holds 2.5e-4 .. 4e-4 of bf16 noise on
+    # the two pre-normalisation biases, exactly 0 on the unused heads)
+    assert np.all(gn[~live] <= 2 * C[~live] + 1e-30), list(zip(np.array(names)[~live], gn[~live], C[~live]))
+    from test_model_gpu import gradnorm_yardstick
+    medA, medC, q90, bad = gradnorm_yardstick(gn[live], A[live], C[live], list(np.array(names)[live]))
+    assert medA <= 2 * medC, (medA, medC)                                            # measured 5.0e-3 vs 5.4e-3
+    assert not bad, (q90, bad)                                                       # worst measured 1.8e-2 against 2 x q90 = 6.1e-2
 
 
 def test_post_training_step_through_fsdp(dev):
@@ -472,9 +487,10 @@ def test_image_generation_module_at_7b_dimensions(dev):
     2 intent layers (FFN 8192) + 3 MAE layers (FFN 16 384), 128 queries, 256 patch tokens, the 5 292-wide delta head, memory = 548 LLM
     states, B = 2, dropout 0 -- forward + backward against oracle/gen_oracle.py. Criterion = the SURVEY 8c(ii)
     yardstick with NO floor: err(hip, fp32 oracle) <= 2 x err(bf16-autocast oracle, fp32 oracle) for the output, the gradient of the
-    LLM states and every parameter gradient. One named exception class, with its reason: the KEY third of every `in_proj_bias` --
-    softmax is invariant to a per-query constant, so that gradient is exactly zero in exact arithmetic and both oracles hold only
-    rounding noise there; it is checked to BE noise (tiny against the query third) instead."""
+    LLM states and every parameter gradient, whole tensors. One named fallback, with its reason: the KEY third of an `in_proj_bias` is
+    exactly zero in exact arithmetic (softmax is invariant to a per-query constant), so every implementation holds only rounding noise
+    there; should that noise tip a whole-tensor ratio over 2, the tensor passes if the other two thirds pass and the key third's
+    absolute error is within twice mode C's. Measured (profiles/r5_parity_image_gen_7b.txt): every ratio 0.79 .. 0.96."""
     from mla_amd.generation import ImageGenerationModule
     E, nh, B, S = 4096, 8, 2, 548
     torch.set_num_threads(min(64, os.cpu_count() or 1))
@@ -522,19 +538,24 @@ def test_image_generation_module_at_7b_dimensions(dev):
     noise = []
     for k in used:
         got, a, c = grads[k].float().cpu(), gA[k], gC[k]
-        if k.endswith("in_proj_bias"):
-            q, kk = float(a[:E].norm()), float(a[E:2 * E].norm())
-            noise.append((k, kk / q, float(got[E:2 * E].norm()) / q))
-            keep = torch.cat([torch.arange(E), torch.arange(2 * E, 3 * E)])
-            got, a, c = got[keep], a[keep], c[keep]
         errs[k], errc[k] = fro_rel(got, a), fro_rel(c, a)
+        if k.endswith("in_proj_bias"):
+            # the key third: an exact-arithmetic zero, so err(x, A) there is the rounding noise itself. Recorded; and if it ever tips
+            # the whole-tensor ratio over 2, the tensor still passes when the other two thirds pass AND the key third's ABSOLUTE
+            # error is within twice mode C's (the same yardstick, un-normalised because ||A|| ~ 0 on that slice)
+            ks = slice(E, 2 * E)
+            nh_, nc_ = float((got[ks] - a[ks]).norm()), float((c[ks] - a[ks]).norm())
+            noise.append((k, float(a[ks].norm()) / float(a[:E].norm()), nh_, nc_))
+            if not errs[k] <= 2.0 * errc[k]:
+                keep = torch.cat([torch.arange(E), torch.arange(2 * E, 3 * E)])
+                if fro_rel(got[keep], a[keep]) <= 2.0 * fro_rel(c[keep], a[keep]) and nh_ <= 2.0 * nc_:
+                    errs[k], errc[k] = fro_rel(got[keep], a[keep]), fro_rel(c[keep], a[keep])
     lines = [f"{k:<55} hip {errs[k]:.2e} | mode C {errc[k]:.2e} | ratio {errs[k] / errc[k]:.2f}" for k in errs]
     print("ImageGenerationModule @ d=4096 (Frobenius-relative error vs the fp32 oracle):\n" + "\n".join(lines))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "parity_image_gen_7b.txt"), "w") as fh:
-            fh.write("\n".join(lines) + "\n" + "\n".join(f"{k} key-bias |grad| / query-bias |grad|: oracle {a:.1e}, hip {b:.1e}" for k, a, b in noise) + "\n")
-    for k, a, b in noise:
-        assert a < 1e-3 and b < 2e-2, (k, a, b)      # exact-arithmetic zero: rounding noise on both sides
+            fh.write("\n".join(lines) + "\n" + "\n".join(f"{k} key third (exact-arithmetic zero): |A_k| / |A_q| {r:.1e}; absolute error hip {a:.2e} | mode C {b:.2e}"
+                                                          for k, r, a, b in noise) + "\n")
     bad = [(k, errs[k], errc[k]) for k in errs if not errs[k] <= 2.0 * errc[k]]
     assert not bad, bad

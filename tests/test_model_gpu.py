@@ -307,14 +307,28 @@ def _run_hip_e2e(dev, save_level=2):
     return m, loss_dict, out
 
 
+def gradnorm_yardstick(gn, A, C, names):
+    """The SURVEY 8c(ii) yardstick for SCALAR gradient norms, with no absolute constant: rel(x) = |x - A| / A per parameter.
+    A single parameter's rel(C) can vanish by cancellation (a norm is one number: the reference's own bf16 run hits |C - A| / A = 8e-5
+    on final_layer.mlp.fc1.weight while its neighbours sit at 1e-3 .. 4e-2), so the per-parameter bound is twice the LARGER of that
+    parameter's own rel(C) and the 90th percentile of rel(C) over all parameters -- the reference's own bf16 spread -- and the medians
+    are compared directly. Returns (median rel hip, median rel C, q90 rel C, list of violations)."""
+    relA, relC = np.abs(gn - A) / A, np.abs(C - A) / A
+    q90 = float(np.quantile(relC, 0.9))
+    bad = [(n, float(a), float(c)) for n, a, c in zip(names, relA, relC) if a > 2 * max(c, q90)]
+    return float(np.median(relA)), float(np.median(relC)), q90, bad
+
+
 def test_mla_e2e_against_reference_golden(dev, e2e):
+    """Whole tiny-MLA step against the reference golden. Every bound is the yardstick alone -- err(hip, A) <= 2 x err(C, A) with A the
+    reference in fp32 and C the reference in its own GPU arithmetic (bf16 autocast) -- no absolute floors (measured
+    values per tensor: profiles/r5_parity_table.txt, ratios 0.05 .. 0.76)."""
     m, ld, out = _run_hip_e2e(dev)
-    # losses: reference mode C (bf16) differs from mode A by |C - A|; allow 2x that + 2e-2
-    tolL = 2 * abs(float(e2e["C_total_loss"]) - float(e2e["A_total_loss"])) + 2e-2
-    assert abs(float(ld["total_loss"]) - float(e2e["A_total_loss"])) < tolL
-    assert abs(float(ld["img_pc_contrastive_loss"]) - float(e2e["A_contrastive"])) < tolL
+    for got, a, c in ((ld["total_loss"], "A_total_loss", "C_total_loss"), (ld["img_pc_contrastive_loss"], "A_contrastive", "C_contrastive"),
+                      (out.loss, "A_llm_loss", "C_llm_loss")):
+        A, C = float(e2e[a]), float(e2e[c])
+        assert abs(float(got) - A) <= 2 * abs(C - A), (a, float(got), A, C)        # measured 1.1e-2 / 4e-5 / 2.2e-3 vs |C - A| 1.4e-2 / 6.9e-4 / 2.8e-2
     assert ld["diff_loss"] is ld["total_loss"]                         # the reference's aliasing quirk (Appendix A #1)
-    assert abs(float(out.loss) - float(e2e["A_llm_loss"])) < tolL
     def err(a, ref):
         return float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
     for name, got in (("hidden8_slice", out.hidden_states[8][:, 250:270, :32]), ("last_hidden_slice", out.hidden_states[-1][:, -8:, :32]),
@@ -325,23 +339,22 @@ def test_mla_e2e_against_reference_golden(dev, e2e):
             keep = np.ones(A.shape[:2], dtype=bool)
             keep[1, -3:] = keep[3, -3:] = False
             A, C, g = A[keep], C[keep], g[keep]
-        assert err(g, A) < 2 * err(C, A) + 5e-3, (name, err(g, A), err(C, A))
+        assert err(g, A) <= 2 * err(C, A), (name, err(g, A), err(C, A))             # measured ratios 0.05 / 0.43 / 0.45
     # gradients (bf16 .grad tensors here: no main_grad installed)
     grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
     names = [str(n) for n in e2e["grad_names"]]
     assert sorted(grads) == names, "set of parameters receiving gradients differs from the reference"
     gn = np.array([float(grads[k].float().norm()) for k in names])
-    relA = np.abs(gn - e2e["A_gradnorms"]) / (e2e["A_gradnorms"] + 1e-12)
-    relC = np.abs(e2e["C_gradnorms"] - e2e["A_gradnorms"]) / (e2e["A_gradnorms"] + 1e-12)
-    assert np.median(relA) < 2 * np.median(relC) + 5e-3, (np.median(relA), np.median(relC))
-    assert (relA < 2 * relC + 5e-2).mean() > 0.97, list(zip(names, relA, relC))[:5]
+    medA, medC, q90, bad = gradnorm_yardstick(gn, e2e["A_gradnorms"], e2e["C_gradnorms"], names)
+    assert medA <= 2 * medC, (medA, medC)                                            # measured 3.6e-3 vs 3.5e-3
+    assert not bad, (q90, bad)                                                       # worst measured 1.8e-2 against 2 x q90 = 4.3e-2
     for key in e2e.files:
         if key.startswith("A_grad::"):
             n = key[len("A_grad::"):]
             A, C = e2e[key], e2e["C_grad::" + n]
             g = grads[n].float().cpu()
             g = (g if tuple(g.shape) == A.shape else g[:16, :64]).numpy()
-            assert err(g, A) < 2 * err(C, A) + 2e-2, (n, err(g, A), err(C, A))
+            assert err(g, A) <= 2 * err(C, A), (n, err(g, A), err(C, A))            # measured ratios 0.15 .. 0.53
 
 
 def test_mla_e2e_against_oracle_flash_semantics(dev):
