@@ -133,6 +133,15 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int fd, int ks2, i
   }
   return u.v;
 }
+// Pins a packed fragment to the place it is computed: an empty volatile asm that "rewrites" its four words. Without it LLVM sinks the
+// whole exp / pack chain of a tile half across the wave-uniform diagonal branches down to the MFMAs that consume it, and the fp32
+// scores of BOTH halves stay live together (the register saving of computing by halves is gone).
+__device__ __forceinline__ void pin_frag(bf16x8_t& f) {
+  union { bf16x8_t v; uint32_t w[4]; } u;
+  u.v = f;
+  asm volatile("" : "+v"(u.w[0]), "+v"(u.w[1]), "+v"(u.w[2]), "+v"(u.w[3]));
+  f = u.v;
+}
 __device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t& lo, const f32x4_t& hi) {
   union { bf16x8_t v; uint32_t w[4]; } u;
   u.w[0] = pack2bf(lo[0], lo[1]); u.w[1] = pack2bf(lo[2], lo[3]);
@@ -250,6 +259,29 @@ __device__ __forceinline__ void rope_bwd_row(f32x4_t (&v)[8], const float* __res
       const float s_ = -sn[r];
       v[fd][r] = fmaf(a, c[r], -(b * s_));
       v[fd + 4][r] = fmaf(b, c[r], a * s_);
+    }
+  }
+}
+
+// The same rotation with the table rows already in registers (rope_tab_load issues the eight 16-B loads; the epilogues issue them
+// first thing so that their round trip hides behind the LDS staging of whatever needs no tables). Bit-identical to rope_bwd_row.
+struct RopeTab { f32x4_t c[4], s[4]; };
+__device__ __forceinline__ void rope_tab_load(RopeTab& t, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int pos, int g) {
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd) {
+    t.c[fd] = *(const f32x4_t*)(cos_t + (size_t)pos * 64 + fd * 16 + g * 4);
+    t.s[fd] = *(const f32x4_t*)(sin_t + (size_t)pos * 64 + fd * 16 + g * 4);
+  }
+}
+__device__ __forceinline__ void rope_bwd_row_tab(f32x4_t (&v)[8], const RopeTab& t) {
+#pragma unroll
+  for (int fd = 0; fd < 4; ++fd) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = bf2f(f2bf(v[fd][r])), b = bf2f(f2bf(v[fd + 4][r]));
+      const float s_ = -t.s[fd][r];
+      v[fd][r] = fmaf(a, t.c[fd][r], -(b * s_));
+      v[fd + 4][r] = fmaf(b, t.c[fd][r], a * s_);
     }
   }
 }
@@ -765,6 +797,18 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
   static_assert(BQ == 128, "the epilogue stages 128-query images");
   const bool tr = p.dqT != nullptr;
   const int pq = lane & 3;
+  // Round 5: every global load of the epilogue -- the RoPE table rows of both row groups and, for o^T, the O rows -- is issued HERE,
+  // before the barrier that waits for the slowest wave of the block, instead of where it is consumed (the table loads sat in front
+  // of the first LDS image and the O rows behind the dq / dq^T stores, each with its round trip exposed: 19-21 k cycles of epilogue
+  // per block in profiles/r5_attn_bwd_block_trace_S548_before.txt).
+  RopeTab rt[RB];
+  bf16x8_t of[RB][4];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const bool valid = myq[rb] >= 0 && myq[rb] < p.S;
+    if (p.rope_cos) rope_tab_load(rt[rb], p.rope_cos, p.rope_sin, valid ? myq[rb] : 0, g);
+    if (tr) load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of[rb]);
+  }
   __syncthreads();
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -772,7 +816,7 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
     const float sc = padq[rb] ? 0.f : p.scale;
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) dqt[rb][fd] *= sc;
-    if (p.rope_cos) rope_bwd_row(dqt[rb], p.rope_cos, p.rope_sin, valid ? myq[rb] : 0, g);
+    if (p.rope_cos) rope_bwd_row_tab(dqt[rb], rt[rb]);
     const int grp = row_group<RB>(wave, rb);
     const int row = grp * 16 + (lane & 15);
 #pragma unroll
@@ -812,12 +856,10 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
-      bf16x8_t of[4];
-      load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         union { bf16x8_t v; uint32_t u[4]; } f;
-        f.v = of[ks];
+        f.v = of[rb][ks];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int c = ks * 32 + g * 8 + half * 4 + pq;
@@ -834,6 +876,9 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
   }
 }
 
+#ifndef MLA_ATTN_DQ_PF
+#define MLA_ATTN_DQ_PF 2         // transposed K fragments in flight in the dQ^T phase (0 = compiler order; 3 spills inside the loop)
+#endif
 // Same row-group pairing and per-(wave, group, tile) skipping as the forward kernel.
 template <int RB, int MASK>
 __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], const bf16x8_t (&dof)[RB][4],
@@ -841,14 +886,20 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
                                         const int (&myq)[RB], const int (&grow0)[RB], int kt, int lane, float sc2) {
   const int g = lane >> 4;
   bf16x8_t ds[RB][2];
-  {
-    f32x4_t st[RB][4], dp[RB][4];
+  // Two 32-key halves, each carried through S^T / dP^T -> dS^T -> bf16 before the next one starts (round 5): the scores of a half
+  // are 32 registers instead of 64 for the whole tile -- at 256 registers per wave that is the difference between no spill and a
+  // scratch reload inside this loop, whose vmcnt(0) would drain the staged prefetch -- and the second half's MFMAs have the first
+  // half's exp / pack VALU to overlap with. Same MFMA order per accumulator: bit-identical results.
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+  for (int ks2 = 0; ks2 < 2; ++ks2) {
+    f32x4_t st[RB][2], dp[RB][2];
+#pragma unroll
+    for (int ff = 0; ff < 2; ++ff) {
+      const int f = 2 * ks2 + ff;
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        st[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        st[rb][ff] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[rb][ff] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -856,8 +907,8 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
           if ((MASK >> rb) & 1) {
-            st[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][f], 0, 0, 0);
-            dp[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[rb][ks], dp[rb][f], 0, 0, 0);
+            st[rb][ff] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][ff], 0, 0, 0);
+            dp[rb][ff] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[rb][ks], dp[rb][ff], 0, 0, 0);
           }
       }
     }
@@ -866,22 +917,23 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
       if (!((MASK >> rb) & 1)) continue;
       if (kt * 64 + 63 > grow0[rb]) {   // diagonal tile: causal mask (exp2(-inf) = 0)
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int ff = 0; ff < 2; ++ff)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
+            if (kt * 64 + (2 * ks2 + ff) * 16 + g * 4 + r > myq[rb]) st[rb][ff][r] = -INFINITY;
       }
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+      for (int ff = 0; ff < 2; ++ff)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(st[rb][f][r] * sc2 - lse2[rb]);
-          st[rb][f][r] = pr * (dp[rb][f][r] - dlt[rb]);
+          const float pr = __builtin_amdgcn_exp2f(st[rb][ff][r] * sc2 - lse2[rb]);
+          st[rb][ff][r] = pr * (dp[rb][ff][r] - dlt[rb]);
         }
-      ds[rb][0] = pack_frag(st[rb][0], st[rb][1]);
-      ds[rb][1] = pack_frag(st[rb][2], st[rb][3]);
+      ds[rb][ks2] = pack_frag(st[rb][0], st[rb][1]);
+      pin_frag(ds[rb][ks2]);
     }
   }
+#if MLA_ATTN_DQ_PF == 0
 #pragma unroll
   for (int fd = 0; fd < 8; ++fd)
 #pragma unroll
@@ -891,6 +943,33 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
       for (int rb = 0; rb < RB; ++rb)
         if ((MASK >> rb) & 1) dqt[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, ds[rb][ks2], dqt[rb][fd], 0, 0, 0);
     }
+#else
+  // dQ^T += K^T dS^T as an explicit software pipeline over the 16 transposed K fragments (see the dK / dV kernel): fragment i + PF is
+  // requested before the MFMAs of fragment i issue. Same order per accumulator: bit-identical.
+  {
+    constexpr int PF = MLA_ATTN_DQ_PF;
+    constexpr int NM = ((MASK & 1) ? 1 : 0) + ((MASK & 2) ? 1 : 0);     // MFMAs per fragment
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = frag_tr<ASW>(kt_, i >> 1, i & 1, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bf16x8_t ktf = ring[i % PF];
+      if (i + PF < 16) ring[i % PF] = frag_tr<ASW>(kt_, (i + PF) >> 1, (i + PF) & 1, lane);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        if ((MASK >> rb) & 1) dqt[rb][i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, ds[rb][i & 1], dqt[rb][i >> 1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      if (i + PF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
 }
 
 template <int RB, int NW>
@@ -929,43 +1008,55 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
 #ifdef MLA_ATTN_BTRACE
   BTV(0, 7, BT_HWID());
 #endif
+  // Prologue as ONE memory round trip (round 5; block-phase stamps, profiles/r5_attn_bwd_block_trace_*: it used to be five -- per row
+  // group q|dO rows, then lse inside a divergent select with an immediate vmcnt(0), then the O rows, then delta, and only after both
+  // groups the first tile's staging copies: 12-15 k cycles of the 60 k a block lives at S = 548). Now the staging copies of key tile 0
+  // go out first, every row load of both groups is issued unconditionally behind them (clamped row index; padding is a select on the
+  // loaded value), and delta is formed when they are back.
+  stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
+  stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   bf16x8_t qf[RB][4], dof[RB][4];
   f32x4_t dqt[RB][8];
   float lse2[RB], dlt[RB];
   bool padq[RB];
+  {
+    bf16x8_t of[RB][4];
+    float lse_raw[RB], dlt_raw[RB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const int qc = myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1;
-    load_row_frags(qb_ + (long long)qc * p.ld, lane, qf[rb]);
-    load_row_frags(p.dout + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, dof[rb]);
-    padq[rb] = (myq[rb] >= seqlen) || (myq[rb] >= p.S) || (myq[rb] < 0);
-    lse2[rb] = padq[rb] ? INFINITY : p.lse[((long long)b * p.H + h) * p.S + qc] * LOG2E;
-    if (p.o) {
-      // delta = rowsum(O * dO) formed here (the four lanes of a row hold all 128 channels of dO already) and published for the
-      // dK / dV kernel that runs behind this one: replaces the stand-alone delta pass over O and dO
-      bf16x8_t of[4];
-      load_row_frags(p.o + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, of);
-      float acc = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        union { bf16x8_t v; uint32_t w[4]; } a, d;
-        a.v = of[ks];
-        d.v = dof[rb][ks];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc += bflo(a.w[j]) * bflo(d.w[j]) + bfhi(a.w[j]) * bfhi(d.w[j]);
-      }
-      dlt[rb] = group_sum(acc);
-      if (g == 0 && myq[rb] >= 0 && myq[rb] < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myq[rb]] = dlt[rb];
-    } else {
-      dlt[rb] = p.delta[((long long)b * p.H + h) * p.S + qc];
+    for (int rb = 0; rb < RB; ++rb) {
+      const int qc = myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1;
+      load_row_frags(qb_ + (long long)qc * p.ld, lane, qf[rb]);
+      load_row_frags(p.dout + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, dof[rb]);
+      if (p.o) load_row_frags(p.o + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, of[rb]);
+      else dlt_raw[rb] = p.delta[((long long)b * p.H + h) * p.S + qc];
+      lse_raw[rb] = p.lse[((long long)b * p.H + h) * p.S + qc];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dqt[rb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < RB; ++rb) {
+      padq[rb] = (myq[rb] >= seqlen) || (myq[rb] >= p.S) || (myq[rb] < 0);
+      lse2[rb] = padq[rb] ? INFINITY : lse_raw[rb] * LOG2E;
+      if (p.o) {
+        // delta = rowsum(O * dO) formed here (the four lanes of a row hold all 128 channels of dO already) and published for the
+        // dK / dV kernel that runs behind this one: replaces the stand-alone delta pass over O and dO
+        float acc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          union { bf16x8_t v; uint32_t w[4]; } a, d;
+          a.v = of[rb][ks];
+          d.v = dof[rb][ks];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc += bflo(a.w[j]) * bflo(d.w[j]) + bfhi(a.w[j]) * bfhi(d.w[j]);
+        }
+        dlt[rb] = group_sum(acc);
+        if (g == 0 && myq[rb] >= 0 && myq[rb] < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myq[rb]] = dlt[rb];
+      } else {
+        dlt[rb] = dlt_raw[rb];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dqt[rb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
   }
   const float sc2 = p.scale * LOG2E;
-
-  stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
-  stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
   BT(0, 1);
   for (int kt = 0; kt < nkt; ++kt) {
     ATTN_WAIT_VM0();
@@ -1197,6 +1288,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq5_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+#ifndef MLA_ATTN_DKV_PF
+#define MLA_ATTN_DKV_PF 6        // transposed fragments in flight in the dV^T / dK^T phase (0 = compiler order, one in flight)
+#endif
 template <bool STORE_DS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles + 2 x (64 lse + 64 delta) floats
@@ -1270,33 +1364,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         stage_rows64<ASW>(dob_, p.ld_o, (qt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
       }
     }
-    f32x4_t s[4], dp[4];
+    // two 32-query halves, each carried through S / dP -> P, dS -> bf16 before the next starts (see dq_tile): 16 score registers
+    // instead of 32, and the second half's MFMAs overlap the first half's exp / pack VALU. Bit-identical.
+    bf16x8_t ph[2], dsh[2];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      s[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      dp[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int hq = 0; hq < 2; ++hq) {
+      f32x4_t s[2], dp[2];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<ASW>(qt_, f, ks, lane), kf[ks], s[f], 0, 0, 0);
-        dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<ASW>(dot_, f, ks, lane), vf[ks], dp[f], 0, 0, 0);
+      for (int ff = 0; ff < 2; ++ff) {
+        const int f = 2 * hq + ff;
+        s[ff] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[ff] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s[ff] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<ASW>(qt_, f, ks, lane), kf[ks], s[ff], 0, 0, 0);
+          dp[ff] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<ASW>(dot_, f, ks, lane), vf[ks], dp[ff], 0, 0, 0);
+        }
       }
-    }
-    f32x4_t pr[4];
+      f32x4_t pr[2];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const f32x4_t l4 = *(const f32x4_t*)(stats + bufi * 128 + f * 16 + g * 4);
-      const f32x4_t d4 = *(const f32x4_t*)(stats + bufi * 128 + 64 + f * 16 + g * 4);
+      for (int ff = 0; ff < 2; ++ff) {
+        const int f = 2 * hq + ff;
+        const f32x4_t l4 = *(const f32x4_t*)(stats + bufi * 128 + f * 16 + g * 4);
+        const f32x4_t d4 = *(const f32x4_t*)(stats + bufi * 128 + 64 + f * 16 + g * 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float sv = s[f][r];
-        if (qt == kb && mykey > qt * 64 + f * 16 + g * 4 + r) sv = -INFINITY;   // only the first query tile touches the diagonal
-        const float pv = __builtin_amdgcn_exp2f(sv * sc2 - l4[r]);
-        pr[f][r] = pv;
-        s[f][r] = pv * (dp[f][r] - d4[r]);
+        for (int r = 0; r < 4; ++r) {
+          float sv = s[ff][r];
+          if (qt == kb && mykey > qt * 64 + f * 16 + g * 4 + r) sv = -INFINITY;   // only the first query tile touches the diagonal
+          const float pv = __builtin_amdgcn_exp2f(sv * sc2 - l4[r]);
+          pr[ff][r] = pv;
+          s[ff][r] = pv * (dp[ff][r] - d4[r]);
+        }
       }
+      ph[hq] = pack_frag(pr[0], pr[1]);
+      dsh[hq] = pack_frag(s[0], s[1]);
+      pin_frag(ph[hq]);
+      pin_frag(dsh[hq]);
     }
-    const bf16x8_t p0 = pack_frag(pr[0], pr[1]), p1 = pack_frag(pr[2], pr[3]);
-    const bf16x8_t ds0 = pack_frag(s[0], s[1]), ds1 = pack_frag(s[2], s[3]);
+    const bf16x8_t p0 = ph[0], p1 = ph[1], ds0 = dsh[0], ds1 = dsh[1];
     if (STORE_DS) {   // hand dS^T (16 keys x 64 queries of this wave) to the one-product dQ kernel: 4 x 512 contiguous bytes
       union { bf16x8_t v; u32x2_t h2[2]; } u0, u1;
       u0.v = ds0;
@@ -1307,6 +1412,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       *(u32x2_t*)(tile + (wave * 4 + 2) * 256) = u1.h2[0];
       *(u32x2_t*)(tile + (wave * 4 + 3) * 256) = u1.h2[1];
     }
+#if MLA_ATTN_DKV_PF == 0
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
       dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(dot_, fd, 0, lane), p0, dvt[fd], 0, 0, 0);
@@ -1314,6 +1420,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(qt_, fd, 0, lane), ds0, dkt[fd], 0, 0, 0);
       dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<ASW>(qt_, fd, 1, lane), ds1, dkt[fd], 0, 0, 0);
     }
+#else
+    // dV^T / dK^T products as an explicit software pipeline over their 32 transposed fragments (round 5): the compiler's own order is
+    // `2 x ds_read_b64_tr_b16 -> s_waitcnt -> v_mfma` with ONE fragment in flight, i.e. an LDS round trip in front of every MFMA
+    // (32 of them per tile and wave; the other resident wave covers only part of it). Here fragment i + PF is requested before MFMA i
+    // issues, PF fragments (4 registers each) ride in a ring, and the order is pinned with sched_group_barrier. Per accumulator the
+    // products are added in the same order as before (bit-identical); consecutive MFMAs alternate between dV^T and dK^T chains.
+    {
+      constexpr int PF = MLA_ATTN_DKV_PF;
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8_t ring[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) ring[i] = frag_tr<ASW>((i & 1) ? qt_ : dot_, i >> 2, (i & 3) >> 1, lane);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const bf16x8_t a = ring[i % PF];
+        if (i + PF < 32) ring[i % PF] = frag_tr<ASW>(((i + PF) & 1) ? qt_ : dot_, (i + PF) >> 2, ((i + PF) & 3) >> 1, lane);
+        const int fd = i >> 2;
+        if ((i & 3) == 0) dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, p0, dvt[fd], 0, 0, 0);
+        else if ((i & 3) == 1) dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ds0, dkt[fd], 0, 0, 0);
+        else if ((i & 3) == 2) dvt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, p1, dvt[fd], 0, 0, 0);
+        else dkt[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ds1, dkt[fd], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);          // the ring's first fill
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA i
+        if (i + PF < 32) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // fragment i + PF
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
   }
   BT(1, 3);
   // ---- epilogue. Everything leaves through LDS (the Q / dO ring is free now) as whole row runs: dk / dv rows as 256 B (16 B per
@@ -1324,25 +1461,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   // dk^T, dv^T [128 ch][64 keys] with the chunk index swizzled by ((ch >> 1) & 3) << 2 -- conflict-free writes and reads.
   const bool kvalid = mykey < p.S;
   u32x2_t wk[8], wv[8];
-#pragma unroll
-  for (int fd = 0; fd < 8; ++fd) dkt[fd] *= p.scale;
-  if (p.rope_cos) rope_bwd_row(dkt, p.rope_cos, p.rope_sin, kvalid ? mykey : 0, g);
+  // Round 5: the RoPE table row of this lane's key is requested first; dv (which needs no tables) is packed and staged while the
+  // loads are in flight, dk follows (the loads used to sit in front of everything with their round trip exposed).
+  RopeTab rt;
+  if (p.rope_cos) rope_tab_load(rt, p.rope_cos, p.rope_sin, kvalid ? mykey : 0, g);
 #pragma unroll
   for (int fd = 0; fd < 8; ++fd) {
-    wk[fd][0] = kvalid ? pack2bf(dkt[fd][0], dkt[fd][1]) : 0u;
-    wk[fd][1] = kvalid ? pack2bf(dkt[fd][2], dkt[fd][3]) : 0u;
     wv[fd][0] = kvalid ? pack2bf(dvt[fd][0], dvt[fd][1]) : 0u;
     wv[fd][1] = kvalid ? pack2bf(dvt[fd][2], dvt[fd][3]) : 0u;
   }
   __syncthreads();
-  {
-    const int row = wave * 16 + (lane & 15);
+  const int erow = wave * 16 + (lane & 15);
+#pragma unroll
+  for (int fd = 0; fd < 8; ++fd) {
+    const int off = erow * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8);
+    *(u32x2_t*)(smem + 16384 + off) = wv[fd];
+  }
+  if (p.dkT) {
+    const int pq = lane & 3;
 #pragma unroll
     for (int fd = 0; fd < 8; ++fd) {
-      const int off = row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8);
-      *(u32x2_t*)(smem + off) = wk[fd];
-      *(u32x2_t*)(smem + 16384 + off) = wv[fd];
+      const int c = fd * 16 + g * 4 + pq;
+      const int off = c * 128 + (((wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8);
+      *(u32x2_t*)(smem + 49152 + off) = quad_transpose_bf16(wv[fd][0], wv[fd][1], lane);
     }
+  }
+#pragma unroll
+  for (int fd = 0; fd < 8; ++fd) dkt[fd] *= p.scale;
+  if (p.rope_cos) rope_bwd_row_tab(dkt, rt);
+#pragma unroll
+  for (int fd = 0; fd < 8; ++fd) {
+    wk[fd][0] = kvalid ? pack2bf(dkt[fd][0], dkt[fd][1]) : 0u;
+    wk[fd][1] = kvalid ? pack2bf(dkt[fd][2], dkt[fd][3]) : 0u;
+  }
+#pragma unroll
+  for (int fd = 0; fd < 8; ++fd) {
+    const int off = erow * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8);
+    *(u32x2_t*)(smem + off) = wk[fd];
   }
   if (p.dkT) {
     const int pq = lane & 3;
@@ -1351,7 +1506,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       const int c = fd * 16 + g * 4 + pq;
       const int off = c * 128 + (((wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8);
       *(u32x2_t*)(smem + 32768 + off) = quad_transpose_bf16(wk[fd][0], wk[fd][1], lane);
-      *(u32x2_t*)(smem + 49152 + off) = quad_transpose_bf16(wv[fd][0], wv[fd][1], lane);
     }
   }
   __syncthreads();

@@ -29,5 +29,17 @@ for S, B, lens in ((548, 3, None), (548, 3, [548, 300, 37]), (100, 2, [100, 64])
     out[tag + "_o"], out[tag + "_lse"], out[tag + "_dqkv"] = o.cpu(), lse.cpu(), dqkv.cpu()
     if tr is not None:
         out[tag + "_dqkvT"], out[tag + "_oT"] = tr[0].cpu(), tr[1].cpu()
+    # the form the training step calls: RoPE backward fused into the epilogues (+ the transposed copies)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.outer(torch.arange(S, dtype=torch.float32), inv)
+    cos, sin = fr.cos().to(dev).contiguous(), fr.sin().to(dev).contiguous()
+    dqkv2 = torch.zeros_like(qkv)
+    tr2 = (torch.zeros_like(tr[0]), torch.zeros_like(tr[1])) if tr is not None else None
+    hip.attn_bwd(q, k, v, o, do, lse, sl, dqkv2[:, :H * D], dqkv2[:, H * D:2 * H * D], dqkv2[:, 2 * H * D:], B, S, H, D, 3 * H * D, D ** -0.5,
+                 rope_cos=cos, rope_sin=sin, transposed=tr2)
+    torch.cuda.synchronize()
+    out[tag + "_rope_dqkv"] = dqkv2.cpu()
+    if tr2 is not None:
+        out[tag + "_rope_dqkvT"], out[tag + "_rope_oT"] = tr2[0].cpu(), tr2[1].cpu()
 torch.save(out, sys.argv[1])
 print("saved", len(out), "tensors")
