@@ -89,6 +89,22 @@ __device__ __forceinline__ void stage_rows64(const bf16_t* __restrict__ base, lo
   }
 }
 
+// 64 rows starting at row0, which may be negative (end-aligned row blocks): source rows clamped to [0, row_lim - 1]
+template <int SW, int NW = 4>
+__device__ __forceinline__ void stage_rows64c(const bf16_t* __restrict__ base, long long ld, int row0, int row_lim,
+                                              char* tile, int wave, int lane) {
+#pragma unroll
+  for (int it = 0; it < 16 / NW; ++it) {
+    const int instr = wave * (16 / NW) + it;
+    const int p = instr * 64 + lane;
+    const int row = p >> 4, cp = p & 15;
+    const int c = swz<SW>(row, cp);
+    int gr = row0 + row;
+    gr = gr < 0 ? 0 : (gr < row_lim ? gr : row_lim - 1);
+    ATTN_GLDS(base + (long long)gr * ld + c * 8, tile + instr * 1024);
+  }
+}
+
 // Same staging with the per-lane source pointers of tile 0 precomputed (no row clamp): for tiles that lie fully inside the
 // sequence the address is just ptr + tile * 64 * ld -- keeps ~40 integer VALU instructions per tile out of the main loops.
 template <int SW, int NW = 4>
@@ -653,13 +669,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(AttnArgs p) {
     char* kdst = smem + k3n * TILE_BYTES;
     char* vdst = vring + ((k + 1) & 1) * TILE_BYTES;
     if (!in_asm) {
+      // (lane made opaque here: the clamped-row staging of the last, partial tiles derives its row index from it, and hoisted out of
+      // the loop that value was spilled and reloaded from scratch inside the loop -- round 5, check_attn_asm now reports 0)
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
       if (need_k) {
         if ((k + 3) * 64 <= p.S) stage_fast_b<NW>(kn, koff, kdst, wave);
-        else stage_rows64<0, NW>(kb_, p.ld, (k + 2) * 64, p.S, kdst, wave, lane);
+        else stage_rows64<0, NW>(kb_, p.ld, (k + 2) * 64, p.S, kdst, wave, lane_s);
       }
       if (need_v) {
         if ((k + 2) * 64 <= p.S) stage_fast_b<NW>(vn, voff, vdst, wave);
-        else stage_rows64<2, NW>(vb_, p.ld, (k + 1) * 64, p.S, vdst, wave, lane);
+        else stage_rows64<2, NW>(vb_, p.ld, (k + 1) * 64, p.S, vdst, wave, lane_s);
       }
     }
     ATTN_TR(3);
@@ -797,17 +817,13 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
   static_assert(BQ == 128, "the epilogue stages 128-query images");
   const bool tr = p.dqT != nullptr;
   const int pq = lane & 3;
-  // Round 5: every global load of the epilogue -- the RoPE table rows of both row groups and, for o^T, the O rows -- is issued HERE,
-  // before the barrier that waits for the slowest wave of the block, instead of where it is consumed (the table loads sat in front
-  // of the first LDS image and the O rows behind the dq / dq^T stores, each with its round trip exposed: 19-21 k cycles of epilogue
-  // per block in profiles/r5_attn_bwd_block_trace_S548_before.txt).
+  // Round 5: the RoPE table rows of both row groups are requested HERE, before the barrier that waits for the slowest wave of the
+  // block, instead of in front of the first LDS image; o^T is no longer produced here (the prologue makes it from the staged O rows).
   RopeTab rt[RB];
-  bf16x8_t of[RB][4];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const bool valid = myq[rb] >= 0 && myq[rb] < p.S;
     if (p.rope_cos) rope_tab_load(rt[rb], p.rope_cos, p.rope_sin, valid ? myq[rb] : 0, g);
-    if (tr) load_row_frags(p.o + ((long long)b * p.S + (myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1)) * p.ld_o + h * D, lane, of[rb]);
   }
   __syncthreads();
 #pragma unroll
@@ -852,33 +868,9 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
       const int c = ps * (NT / 32) + (threadIdx.x >> 5);
       if (jv) *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 32768 + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
     }
-    __syncthreads();
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        union { bf16x8_t v; uint32_t u[4]; } f;
-        f.v = of[rb][ks];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int c = ks * 32 + g * 8 + half * 4 + pq;
-          *(u32x2_t*)(smem + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
-      const int c = ps * (NT / 32) + (threadIdx.x >> 5);
-      if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
-    }
   }
 }
 
-#ifndef MLA_ATTN_DQ_PF
-#define MLA_ATTN_DQ_PF 2         // transposed K fragments in flight in the dQ^T phase (0 = compiler order; 3 spills inside the loop)
-#endif
 // Same row-group pairing and per-(wave, group, tile) skipping as the forward kernel.
 template <int RB, int MASK>
 __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], const bf16x8_t (&dof)[RB][4],
@@ -886,20 +878,14 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
                                         const int (&myq)[RB], const int (&grow0)[RB], int kt, int lane, float sc2) {
   const int g = lane >> 4;
   bf16x8_t ds[RB][2];
-  // Two 32-key halves, each carried through S^T / dP^T -> dS^T -> bf16 before the next one starts (round 5): the scores of a half
-  // are 32 registers instead of 64 for the whole tile -- at 256 registers per wave that is the difference between no spill and a
-  // scratch reload inside this loop, whose vmcnt(0) would drain the staged prefetch -- and the second half's MFMAs have the first
-  // half's exp / pack VALU to overlap with. Same MFMA order per accumulator: bit-identical results.
+  {
+    f32x4_t st[RB][4], dp[RB][4];
 #pragma unroll
-  for (int ks2 = 0; ks2 < 2; ++ks2) {
-    f32x4_t st[RB][2], dp[RB][2];
-#pragma unroll
-    for (int ff = 0; ff < 2; ++ff) {
-      const int f = 2 * ks2 + ff;
+    for (int f = 0; f < 4; ++f) {
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        st[rb][ff] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[rb][ff] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        st[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[rb][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -907,8 +893,8 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
           if ((MASK >> rb) & 1) {
-            st[rb][ff] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][ff], 0, 0, 0);
-            dp[rb][ff] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[rb][ks], dp[rb][ff], 0, 0, 0);
+            st[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rb][ks], st[rb][f], 0, 0, 0);
+            dp[rb][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[rb][ks], dp[rb][f], 0, 0, 0);
           }
       }
     }
@@ -917,23 +903,22 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
       if (!((MASK >> rb) & 1)) continue;
       if (kt * 64 + 63 > grow0[rb]) {   // diagonal tile: causal mask (exp2(-inf) = 0)
 #pragma unroll
-        for (int ff = 0; ff < 2; ++ff)
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kt * 64 + (2 * ks2 + ff) * 16 + g * 4 + r > myq[rb]) st[rb][ff][r] = -INFINITY;
+            if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
       }
 #pragma unroll
-      for (int ff = 0; ff < 2; ++ff)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(st[rb][ff][r] * sc2 - lse2[rb]);
-          st[rb][ff][r] = pr * (dp[rb][ff][r] - dlt[rb]);
+          const float pr = __builtin_amdgcn_exp2f(st[rb][f][r] * sc2 - lse2[rb]);
+          st[rb][f][r] = pr * (dp[rb][f][r] - dlt[rb]);
         }
-      ds[rb][ks2] = pack_frag(st[rb][0], st[rb][1]);
-      pin_frag(ds[rb][ks2]);
+      ds[rb][0] = pack_frag(st[rb][0], st[rb][1]);
+      ds[rb][1] = pack_frag(st[rb][2], st[rb][3]);
     }
   }
-#if MLA_ATTN_DQ_PF == 0
 #pragma unroll
   for (int fd = 0; fd < 8; ++fd)
 #pragma unroll
@@ -943,33 +928,6 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
       for (int rb = 0; rb < RB; ++rb)
         if ((MASK >> rb) & 1) dqt[rb][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, ds[rb][ks2], dqt[rb][fd], 0, 0, 0);
     }
-#else
-  // dQ^T += K^T dS^T as an explicit software pipeline over the 16 transposed K fragments (see the dK / dV kernel): fragment i + PF is
-  // requested before the MFMAs of fragment i issue. Same order per accumulator: bit-identical.
-  {
-    constexpr int PF = MLA_ATTN_DQ_PF;
-    constexpr int NM = ((MASK & 1) ? 1 : 0) + ((MASK & 2) ? 1 : 0);     // MFMAs per fragment
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8_t ring[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) ring[i] = frag_tr<ASW>(kt_, i >> 1, i & 1, lane);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const bf16x8_t ktf = ring[i % PF];
-      if (i + PF < 16) ring[i % PF] = frag_tr<ASW>(kt_, (i + PF) >> 1, (i + PF) & 1, lane);
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-        if ((MASK >> rb) & 1) dqt[rb][i >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, ds[rb][i & 1], dqt[rb][i >> 1], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-      if (i + PF < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#endif
 }
 
 template <int RB, int NW>
@@ -1008,29 +966,56 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
 #ifdef MLA_ATTN_BTRACE
   BTV(0, 7, BT_HWID());
 #endif
-  // Prologue as ONE memory round trip (round 5; block-phase stamps, profiles/r5_attn_bwd_block_trace_*: it used to be five -- per row
-  // group q|dO rows, then lse inside a divergent select with an immediate vmcnt(0), then the O rows, then delta, and only after both
-  // groups the first tile's staging copies: 12-15 k cycles of the 60 k a block lives at S = 548). Now the staging copies of key tile 0
-  // go out first, every row load of both groups is issued unconditionally behind them (clamped row index; padding is a select on the
-  // loaded value), and delta is formed when they are back.
-  stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem, wave, lane);
-  stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + TILE_BYTES, wave, lane);
+  // Prologue through the LDS-DMA path (round 5). The block-phase stamps (profiles/r5_attn_bwd_block_trace_*) put 12-15 k cycles of the
+  // ~60 k a block lives at S = 548 into the prologue, and issuing all of its loads at once did not change that: what it waits for is
+  // not round trips but cache-line REQUESTS. A row-per-lane fragment load (load_row_frags) touches 16 rows x 64 B per instruction =
+  // 16 half-used 128-B lines, 24 such instructions per wave for q | dO | o = 1 536 line requests per block against the handful of
+  // misses a CU keeps in flight. The same rows staged with global_load_lds (1 KiB = 8 whole lines per instruction, the path the K / V
+  // tiles take at ~2 k cycles per 32 KiB) and read back as fragments with ds_read_b128 are the same bytes in a third of the requests:
+  //   phase A  q rows -> smem[0:32K) (two 64-row tiles), dO rows -> smem[32K:64K); lse per lane;  wait, barrier;  fragments -> registers
+  //   phase B  o rows -> smem[0:32K), key tile 0 -> smem[32K:64K) (= ring buffer 1);              wait, barrier;  delta, o^T
+  // so key tile kt lives in ring buffer (kt + 1) & 1. o^T (the wo wgrad operand) is produced here from the staged O rows instead of
+  // re-reading O in the epilogue. Same fragments, same arithmetic: bit-identical to the round-4 kernel.
+  const bf16_t* dob_ = p.dout + (long long)b * p.S * p.ld_o + h * D;
+  stage_rows64c<ASW, NW>(qb_, p.ld, q0, p.S, smem, wave, lane);
+  stage_rows64c<ASW, NW>(qb_, p.ld, q0 + 64, p.S, smem + TILE_BYTES, wave, lane);
+  stage_rows64c<ASW, NW>(dob_, p.ld_o, q0, p.S, smem + 2 * TILE_BYTES, wave, lane);
+  stage_rows64c<ASW, NW>(dob_, p.ld_o, q0 + 64, p.S, smem + 3 * TILE_BYTES, wave, lane);
   bf16x8_t qf[RB][4], dof[RB][4];
   f32x4_t dqt[RB][8];
   float lse2[RB], dlt[RB];
   bool padq[RB];
+  float lse_raw[RB], dlt_raw[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int qc = myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1;
+    lse_raw[rb] = p.lse[((long long)b * p.H + h) * p.S + qc];
+    dlt_raw[rb] = p.o ? 0.f : p.delta[((long long)b * p.H + h) * p.S + qc];
+  }
+  ATTN_WAIT_VM0();
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int grp = row_group<RB>(wave, rb);
+    const char* qt_ = smem + (grp >> 2) * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[rb][ks] = frag_rows<ASW>(qt_, grp & 3, ks, lane);
+      dof[rb][ks] = frag_rows<ASW>(qt_ + 2 * TILE_BYTES, grp & 3, ks, lane);
+    }
+  }
+  __syncthreads();                                   // every wave holds its q | dO fragments: the staging area is free again
+  if (p.o) {
+    const bf16_t* ob_ = p.o + (long long)b * p.S * p.ld_o + h * D;
+    stage_rows64c<ASW, NW>(ob_, p.ld_o, q0, p.S, smem, wave, lane);
+    stage_rows64c<ASW, NW>(ob_, p.ld_o, q0 + 64, p.S, smem + TILE_BYTES, wave, lane);
+  }
+  stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem + 2 * TILE_BYTES, wave, lane);
+  stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + 3 * TILE_BYTES, wave, lane);
+  ATTN_WAIT_VM0();
+  __syncthreads();
   {
     bf16x8_t of[RB][4];
-    float lse_raw[RB], dlt_raw[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const int qc = myq[rb] < 0 ? 0 : myq[rb] < p.S ? myq[rb] : p.S - 1;
-      load_row_frags(qb_ + (long long)qc * p.ld, lane, qf[rb]);
-      load_row_frags(p.dout + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, dof[rb]);
-      if (p.o) load_row_frags(p.o + ((long long)b * p.S + qc) * p.ld_o + h * D, lane, of[rb]);
-      else dlt_raw[rb] = p.delta[((long long)b * p.H + h) * p.S + qc];
-      lse_raw[rb] = p.lse[((long long)b * p.H + h) * p.S + qc];
-    }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       padq[rb] = (myq[rb] >= seqlen) || (myq[rb] >= p.S) || (myq[rb] < 0);
@@ -1038,9 +1023,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
       if (p.o) {
         // delta = rowsum(O * dO) formed here (the four lanes of a row hold all 128 channels of dO already) and published for the
         // dK / dV kernel that runs behind this one: replaces the stand-alone delta pass over O and dO
+        const int grp = row_group<RB>(wave, rb);
         float acc = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+          of[rb][ks] = frag_rows<ASW>(smem + (grp >> 2) * TILE_BYTES, grp & 3, ks, lane);
           union { bf16x8_t v; uint32_t w[4]; } a, d;
           a.v = of[rb][ks];
           d.v = dof[rb][ks];
@@ -1055,17 +1042,48 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
 #pragma unroll
       for (int i = 0; i < 8; ++i) dqt[rb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
+    if (p.oT && p.o) {
+      // o^T of this block's 128 rows, from the fragments just read: [128 ch][128 q] image over the O staging area (chunk index
+      // swizzled by (ch & 7) << 2), written out as 256-B runs per channel row. Its stores are not waited for before key tile 0 (already
+      // on chip): the loop's first vmcnt(0) comes with tile 1.
+      const int pq = lane & 3;
+      __syncthreads();                               // all O fragments read
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int chunk0 = row_group<RB>(wave, rb) * 4 + ((lane & 15) >> 2);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          union { bf16x8_t v; uint32_t u[4]; } f;
+          f.v = of[rb][ks];
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int c = ks * 32 + g * 8 + half * 4 + pq;
+            *(u32x2_t*)(smem + c * 256 + ((chunk0 ^ ((c & 7) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
+          }
+        }
+      }
+      __syncthreads();
+      constexpr int NT = 64 * NW;
+      const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3 (q0 and S are multiples of 4)
+      const bool jv = q0 + j * 4 >= 0 && q0 + j * 4 < p.S;
+      const long long tok = (long long)b * p.S + q0 + j * 4;
+#pragma unroll
+      for (int ps = 0; ps < 128 / (NT / 32); ++ps) {
+        const int c = ps * (NT / 32) + (threadIdx.x >> 5);
+        if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
+      }
+    }
   }
   const float sc2 = p.scale * LOG2E;
   BT(0, 1);
   for (int kt = 0; kt < nkt; ++kt) {
-    ATTN_WAIT_VM0();
+    if (kt > 0) ATTN_WAIT_VM0();                     // tile 0 landed in the prologue; what is in flight there are the o^T stores
     __syncthreads();
     if (kt == 0) BT(0, 2);
-    const char* kt_ = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* kt_ = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
     const char* vt_ = kt_ + TILE_BYTES;
     if (kt + 1 < nkt) {
-      char* nx = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+      char* nx = smem + (kt & 1) * 2 * TILE_BYTES;
       stage_rows64<ASW, NW>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);       // (register budget: no precomputed offsets here)
       stage_rows64<ASW, NW>(vb_, p.ld, (kt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
     }
@@ -1073,12 +1091,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
       if (grow0[rb] < row_lim && kt * 64 <= grow0[rb] + 15) mask |= 1 << rb;
+    // The lane id the tile body derives its LDS fragment addresses from is made opaque once per iteration: otherwise LLVM hoists the
+    // ~12 per-lane address registers out of the loop, and at 256 registers per wave the allocator then spills some of them and
+    // RELOADS them inside the loop -- scratch loads are VMEM operations whose vmcnt(0) drains the staged prefetch of the next tile.
+    // Recomputing them costs ~30 VALU per tile.
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
     if (RB == 2) {
-      if (mask == 3) dq_tile<RB, 3>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
-      else if (mask == 2) dq_tile<RB, 2>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
-      else if (mask == 1) dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
+      if (mask == 3) dq_tile<RB, 3>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
+      else if (mask == 2) dq_tile<RB, 2>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
+      else if (mask == 1) dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
     } else if (mask) {
-      dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane, sc2);
+      dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
     }
   }
   BT(0, 3);
@@ -1312,10 +1336,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 #ifdef MLA_ATTN_BTRACE
   BTV(1, 7, BT_HWID());
 #endif
-  const int kc = mykey < p.S ? mykey : p.S - 1;
   bf16x8_t kf[4], vf[4];
-  load_row_frags(p.k + ((long long)b * p.S + kc) * p.ld + h * D, lane, kf);
-  load_row_frags(p.v + ((long long)b * p.S + kc) * p.ld + h * D, lane, vf);
 
   f32x4_t dkt[8], dvt[8];
 #pragma unroll
@@ -1339,9 +1360,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   };
   float nstat = 0.f;
   if (qt0 < nqt_end) {
+    // Round 5: this block's 64 K rows and 64 V rows come in through the LDS-DMA path together with the first Q / dO tile (ring buffer
+    // 1 is free until the first iteration requests tile qt0 + 1 behind its barrier) and are read back as fragments with ds_read_b128:
+    // whole 128-B lines, 8 per instruction, instead of 16 half-used lines per row-per-lane load (see the dQ kernel's prologue).
     stage_rows64<ASW>(qb_, p.ld, qt0 * 64, p.S, smem, wave, lane);
     stage_rows64<ASW>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
+    stage_rows64<ASW>(p.k + (long long)b * p.S * p.ld + h * D, p.ld, kb * 64, p.S, smem + 2 * TILE_BYTES, wave, lane);
+    stage_rows64<ASW>(p.v + (long long)b * p.S * p.ld + h * D, p.ld, kb * 64, p.S, smem + 3 * TILE_BYTES, wave, lane);
     if (threadIdx.x < 128) nstat = load_stat(qt0);
+    ATTN_WAIT_VM0();
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag_rows<ASW>(smem + 2 * TILE_BYTES, wave, ks, lane);
+      vf[ks] = frag_rows<ASW>(smem + 3 * TILE_BYTES, wave, ks, lane);
+    }
   }
   BT(1, 1);
   BTV(1, 6, nqt_end - qt0);
@@ -1571,7 +1604,10 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
   constexpr int FWD_LDS = 4 * TILE_BYTES;
   if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_RB, FWD_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS); attr = true; }
   // MLA_ATTN_FWD=1: the 32-rows-per-wave forward with the generated assembly tile body (opt-in, see attn_fwd32p_kernel)
-  static const int variant = getenv("MLA_ATTN_FWD") ? atoi(getenv("MLA_ATTN_FWD")) : 0;
+  // default (round 5): the assembly pipeline where it measures ahead of the compiler-scheduled kernel -- S >= 1024 (405-427 vs 452-471 us
+  // at S = 2048; at S = 548 it is 8 % behind) -- MLA_ATTN_FWD=0 / 1 forces one of them for A/B runs
+  static const int forced = getenv("MLA_ATTN_FWD") ? atoi(getenv("MLA_ATTN_FWD")) : -1;
+  const int variant = forced >= 0 ? forced : (S >= 1024 ? 1 : 0);
   if (variant == 1) {
     static bool attr3 = false;
     static const int lds_extra = getenv("MLA_ATTN_LDS_EXTRA") ? atoi(getenv("MLA_ATTN_LDS_EXTRA")) : 0;   // experiment (tools/exp_attn_trace.py): one block per CU

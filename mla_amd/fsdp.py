@@ -338,8 +338,20 @@ class FlatUnit:
         for _, p, _ in self.params:
             if p.requires_grad:
                 p._mg_touched = False
+                p._mg_locked = False
                 if hasattr(p, "_mg_regions"):
                     p._mg_regions = {}       # per-region state of parameters used through ops.param_view
+
+    def zero_stale_and_lock(self):
+        """Called when the unit's reduce-scatter is about to be launched from its backward hook (see ShardedModel._launch_reduce_scatter)."""
+        for _, p, _ in self.params:
+            if not p.requires_grad:
+                continue
+            touched = p._mg_touched or any(getattr(p, "_mg_regions", {}).values())
+            if not touched and p._mg_dirty and p.grad is None:
+                p.main_grad.zero_()
+                p._mg_dirty = False
+            p._mg_locked = True
 
     def collect_autograd_grads(self):
         """Gradients delivered by autograd into ``.grad`` (small broadcast parameters: queries, mask token, position tables) move
@@ -370,7 +382,7 @@ class FlatUnit:
                     raise RuntimeError(f"{self.name}: {n} received an autograd gradient after the unit's reduce-scatter was launched")
                 if not p._mg_touched and any(getattr(p, "_mg_regions", {}).values()):
                     p._mg_touched = True
-                if not p._mg_touched and p._mg_dirty:
+                if not p._mg_touched and p._mg_dirty:        # cannot happen since zero_stale_and_lock(): kept as an invariant check
                     raise RuntimeError(f"{self.name}: {n} holds a stale gradient that was reduced with this step's (untouched this step, "
                                        "but the unit's reduce-scatter fired from its backward hook)")
                 if p._mg_touched:
@@ -501,6 +513,12 @@ class ShardedModel:
     def _launch_reduce_scatter(self, u: FlatUnit):
         if not self.coll or not u.trainable or u.rs_event is not None or self.defer_reduce:
             return
+        # (advisor, round 4) Before the collective may read grad32: a parameter of this unit that got NO gradient in this window but
+        # still holds one from an earlier step is zeroed HERE, on the compute stream, in front of the event the side stream waits for --
+        # torch FSDP with use_orig_params presents zero gradients for unused parameters, and zeroing after the launch would race with
+        # the in-place collective. From here on the unit's main_grad is locked: a later write (the same layer run through backward a
+        # second time in one step, a late autograd .grad) raises in ops._touch / finish_backward instead of corrupting the reduced shard.
+        u.zero_stale_and_lock()
         cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if cur is not None:
             ev = torch.cuda.Event()

@@ -51,6 +51,11 @@ def _is_touched(w) -> bool:
 
 def _mark_touched(w) -> None:
     region = getattr(w, "_mg_region", None)
+    owner = region[0] if region is not None else w
+    if getattr(owner, "_mg_locked", False):
+        # the owning unit's reduce-scatter has been launched (mla_amd/fsdp.py: zero_stale_and_lock): its gradient buffer is being read,
+        # or already holds the reduced shard in place -- e.g. the same decoder layer run through backward twice in one step
+        raise RuntimeError("main_grad written after its sharding unit's reduce-scatter was launched in this step")
     if region is not None:
         region[0]._mg_regions[region[1]] = True
     else:

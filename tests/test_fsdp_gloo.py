@@ -173,3 +173,33 @@ def test_sharded_model_world1_matches_adamw():
     sm.begin_step()
     sm.finish_backward()
     assert all(float(p.main_grad.abs().max()) == 0.0 for p in model.parameters() if p.requires_grad)
+
+
+def test_hook_launched_reduce_scatter_zeroes_stale_gradients_and_locks_the_unit():
+    """(advisor, round 4) A decoder-layer unit whose reduce-scatter is launched from its backward hook: a parameter that got no gradient
+    in this window but holds one from an earlier step is ZEROED in front of the collective (torch FSDP with use_orig_params presents
+    zero gradients for unused parameters; the old code raised), and from the launch on any further main_grad write of the unit raises
+    (the same layer run through backward twice in one step would otherwise land on top of the reduced shard)."""
+    from mla_amd import ops
+    from mla_amd.fsdp import ShardedModel
+    model = _make()
+    sm = ShardedModel(model, lambda mod: isinstance(mod, Block), torch.device("cpu"), ops=TorchLocalOps())
+    u = next(u for u in sm.units if isinstance(getattr(u, "module", None), Block))
+    params = [p for _, p, _ in u.params if p.requires_grad]
+    sm.begin_step()
+    for p in params:                                  # step 1: every parameter of the unit receives a gradient
+        p.main_grad.fill_(1.0)
+        ops._mark_touched(p)
+    sm.finish_backward()
+    assert all(p._mg_dirty for p in params)
+    sm.begin_step()                                   # step 2: only the first one does
+    params[0].main_grad.fill_(2.0)
+    ops._mark_touched(params[0])
+    u.zero_stale_and_lock()                           # what _launch_reduce_scatter does in front of the collective
+    assert float(params[0].main_grad.min()) == 2.0
+    assert all(float(p.main_grad.abs().max()) == 0.0 and not p._mg_dirty for p in params[1:])
+    with pytest.raises(RuntimeError, match="reduce-scatter was launched"):
+        ops._mark_touched(params[1])
+    u.finish_backward(already_reduced=True)           # bookkeeping only; no stale-gradient error any more
+    sm.begin_step()
+    ops._mark_touched(params[1])                      # a new step unlocks the unit

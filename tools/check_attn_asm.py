@@ -15,24 +15,37 @@ def audit(text, name="attn_fwd32p_kernel", limit=64):
         return [f"kernel {name} not found"], {}
     end = text.index(".end_amdhsa_kernel", m.start())
     lines = text[m.start():end].split("\n")
-    blocks, cur = [], None              # (first line, last line, has MFMA) of every inline-asm statement
+    blocks, cur = [], None              # (first line, last line, has MFMA, touches AGPRs) of every inline-asm statement
     for i, ln in enumerate(lines):
         if "#ASMSTART" in ln:
-            cur = [i, i, False]
+            cur = [i, i, False, False]
         elif "#ASMEND" in ln and cur:
             cur[1] = i
             blocks.append(tuple(cur))
             cur = None
         elif cur and "v_mfma" in ln:
             cur[2] = True
+        elif cur and "v_accvgpr" in ln:
+            cur[3] = True
     tiles = [b for b in blocks if b[2]]
     if len(tiles) < 2:
         return [f"{name}: expected two tile statements (parity 0 / 1), found {len(tiles)}"], {}
     lo, hi = tiles[0][0], tiles[-1][1]
     inside = set()
-    for a, b, _ in blocks:
+    for a, b, _, _ in blocks:
         inside.update(range(a, b + 1))
+    # AGPR lifetime (advisor, round 4): Q (a[96:127]) and the zeroed accumulators are live from the first statement that writes an
+    # AGPR (QW / Z4) up to the last one that reads one (EXPORT16), i.e. also across the compiler's staging set-up before the first tile
+    # statement and the epilogue arithmetic after the last -- a compiler that used AGPRs as spill space there would corrupt Q or O
+    acc = [b for b in blocks if b[3] or b[2]]
+    alo, ahi = acc[0][0], acc[-1][1]
     findings, n, scratch = [], 0, 0
+    for i in list(range(alo, lo)) + list(range(hi + 1, ahi + 1)):
+        if i in inside:
+            continue
+        t = lines[i].split(";")[0].strip()
+        if t and not t.startswith(".") and not t.endswith(":") and re.search(r"\ba\d+\b|\ba\[\d+", t):
+            findings.append(f"line {i}: compiler code names an AGPR while Q / O live in AGPRs (outside the tile loop): {t}")
     for i in range(lo, hi + 1):
         if i in inside:
             continue
@@ -47,7 +60,7 @@ def audit(text, name="attn_fwd32p_kernel", limit=64):
             findings.append(f"line {i}: compiler code names an AGPR inside the tile loop: {t}")
         if "scratch_" in t:
             scratch += 1
-    return findings, dict(statements=len(tiles), loop_instructions=n, scratch_accesses_in_loop=scratch)
+    return findings, dict(statements=len(tiles), loop_instructions=n, scratch_accesses_in_loop=scratch, agpr_live_region_lines=ahi - alo + 1)
 
 
 def main():
