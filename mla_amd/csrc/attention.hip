@@ -776,11 +776,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(AttnArgs p) {
 }
 
 #ifndef MLA_ATTN_BWD_SW
-#define MLA_ATTN_BWD_SW 0
+#define MLA_ATTN_BWD_SW 1
 #endif
-constexpr int ASW = MLA_ATTN_BWD_SW;   // LDS swizzle of the backward kernels' tiles, which are read BOTH as row fragments and transposed
-                                       // (0 leaves 25-30 % bank-conflict cycles on the transposed reads, 1 is conflict-free for both read
-                                       // forms -- and measures the same: 410 / 268 us at S = 548; the loops are latency-bound)
+constexpr int ASW = MLA_ATTN_BWD_SW;   // LDS swizzle of the backward kernels' tiles, which are read BOTH as row fragments and transposed.
+                                       // 1 (default since round 5) is conflict-free for both read forms: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+                                       // 4.6 % (dQ) / 6.9 % (dK dV) against 22.4 % / 31.1 % with swizzle 0; bit-identical results; the dK dV kernel
+                                       // -3 % (366 -> 355 us at S = 548), the backward at S = 2048 -1.5 % (profiles/r5_attn_bwd_swizzle_ab.txt).
+                                       // Round 2 measured the two the same on the kernels of that time.
 
 // ------------------------------------------------------------------------------------------------ dQ
 // A dQ block that is padding as a whole: zero dq (and dq^T), o^T of whatever the forward wrote (zeros for padded rows).

@@ -90,16 +90,17 @@ def capture_heads():
             res["param_names"] = np.array(sorted(shapes))
             res["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
             res["no_grad_names"] = np.array(sorted(k for k, p in mgr.named_parameters() if p.grad is None))
-            for k in ("image_gen_module.mae_delta_head.weight", "image_gen_module.intent_decoder.layers.0.multihead_attn.in_proj_weight",
-                      "image_gen_module.mae_decoder.layers.1.linear1.weight", "pointcloud_gen_module.seq_to_patch.weight",
-                      "pointcloud_gen_module.decoder_blocks.0.attn.in_proj_weight", "pointcloud_gen_module.future_predictor.0.weight"):
-                res[f"A_grad::{k}"] = f(grads[k].reshape(grads[k].shape[0], -1)[:16, :64])
-            for k in ("image_gen_module.image_gen_queries", "image_gen_module.mae_mask_token", "image_gen_module.mae_patch_norm.weight",
-                      "pointcloud_gen_module.future_predictor.1.weight", "pointcloud_gen_module.future_predictor.1.bias",
-                      "image_gen_module.mae_decoder.layers.0.self_attn.in_proj_bias"):
-                res[f"A_grad::{k}"] = f(grads[k].reshape(-1)[:256])
-            bn = mgr.pointcloud_gen_module.future_predictor[1]
-            res["A_bn_running_mean"], res["A_bn_running_var"] = f(bn.running_mean), f(bn.running_var)
+        # gradient slices in BOTH modes (round 5: mode C added so that the per-slice bounds of the GPU test are the yardstick too)
+        for k in ("image_gen_module.mae_delta_head.weight", "image_gen_module.intent_decoder.layers.0.multihead_attn.in_proj_weight",
+                  "image_gen_module.mae_decoder.layers.1.linear1.weight", "pointcloud_gen_module.seq_to_patch.weight",
+                  "pointcloud_gen_module.decoder_blocks.0.attn.in_proj_weight", "pointcloud_gen_module.future_predictor.0.weight"):
+            res[f"{mode}_grad::{k}"] = f(grads[k].reshape(grads[k].shape[0], -1)[:16, :64])
+        for k in ("image_gen_module.image_gen_queries", "image_gen_module.mae_mask_token", "image_gen_module.mae_patch_norm.weight",
+                  "pointcloud_gen_module.future_predictor.1.weight", "pointcloud_gen_module.future_predictor.1.bias",
+                  "image_gen_module.mae_decoder.layers.0.self_attn.in_proj_bias"):
+            res[f"{mode}_grad::{k}"] = f(grads[k].reshape(-1)[:256])
+        bn = mgr.pointcloud_gen_module.future_predictor[1]
+        res[f"{mode}_bn_running_mean"], res[f"{mode}_bn_running_var"] = f(bn.running_mean), f(bn.running_var)
     np.savez_compressed(os.path.join(OUT, "generation.npz"), **res)
     print("generation.npz:", {k: float(res[k]) for k in res if k.endswith("_loss")})
     print("  params without gradient:", list(res["no_grad_names"]))

@@ -233,38 +233,64 @@ def test_generation_heads_against_reference_golden(dev):
 
     def err(a, ref):
         return float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
+    # Every bound below is the yardstick alone: err(hip, A) <= 2 x err(C, A), A = the reference in fp32, C = the
+    # reference under bf16 autocast, both in tests/golden/generation.npz (mode-C gradient slices added in round 5). Measured values:
+    # profiles/r5_parity_table.txt, section "generation heads alone". Two refinements, both stated, neither an absolute constant:
+    #  * a scalar LOSS of mode C is itself a bf16 number (ulp 2^-4 at 12.3): |C - A| below half such an ulp is luck, so the bound is
+    #    2 x max(|C - A|, ulp_bf16(A) / 2);
+    #  * gradient NORMS are single numbers whose rel(C) can vanish by cancellation -> per parameter 2 x max(own rel C, 90th percentile of
+    #    rel C over the parameters of the same head); the two heads are separate families because the chamfer loss of the point head
+    #    re-assigns nearest neighbours under bf16 noise (piecewise loss surface: heavier tail, q90 7.6e-3 vs 2.7e-3 for the image head).
+    def half_ulp_bf16(x):
+        return 2.0 ** (math.floor(math.log2(abs(x))) - 7) / 2
     for key, got in (("image_gen_loss", loss_img), ("point_cloud_gen_loss", loss_pc)):
         A, C = float(gold["A_" + key]), float(gold["C_" + key])
-        assert abs(float(got) - A) < 2 * abs(C - A) + 2e-2, (key, float(got), A, C)
+        assert abs(float(got) - A) <= 2 * max(abs(C - A), half_ulp_bf16(A)), (key, float(got), A, C)   # measured 4.7e-3 / 2.2e-3
     assert outs["delta_raw"].shape[-1] == 5312 and float(outs["delta_raw"][..., 5292:].float().abs().max()) == 0.0
     delta = (torch.tanh(outs["delta_raw"][..., :5292].float()) * 5.0)[:, ::16, ::97].detach().cpu().numpy()
-    assert err(delta, gold["A_delta_slice"]) < 2 * err(gold["C_delta_slice"], gold["A_delta_slice"]) + 1e-2
+    assert err(delta, gold["A_delta_slice"]) <= 2 * err(gold["C_delta_slice"], gold["A_delta_slice"])          # ratio 0.95
     pts = outs["pointcloud_coord_generation"].detach().float().cpu().numpy()
-    assert err(pts, gold["A_points"]) < 2 * err(gold["C_points"], gold["A_points"]) + 1e-2
+    assert err(pts, gold["A_points"]) <= 2 * err(gold["C_points"], gold["A_points"])                            # ratio 0.95
     hg = hd.grad.float().cpu().numpy()
-    assert err(hg, gold["A_hidden_grad"]) < 2 * err(gold["C_hidden_grad"], gold["A_hidden_grad"]) + 2e-2
+    assert err(hg, gold["A_hidden_grad"]) <= 2 * err(gold["C_hidden_grad"], gold["A_hidden_grad"])              # ratio 1.58
     grads = {k: p.grad for k, p in mgr.named_parameters() if p.grad is not None}
     names = [str(n) for n in gold["grad_names"]]
     A, C = gold["A_gradnorms"], gold["C_gradnorms"]
     gn = np.array([float(grads[k].float().norm()) if k in grads else 0.0 for k in names])
-    live = A > 0            # alpha / offset heads: exactly zero gradient in the reference, none here
-    assert all((k in grads) or not l for k, l in zip(names, live)), "a parameter with a reference gradient got none"
-    assert np.all(gn[~live] == 0)
-    relA, relC = np.abs(gn - A)[live] / A[live], np.abs(C - A)[live] / A[live]
-    assert np.median(relA) < 2 * np.median(relC) + 5e-3, (np.median(relA), np.median(relC))
-    assert (relA < 2 * relC + 5e-2).mean() > 0.97, [(n, a, c) for n, a, c in zip(np.array(names)[live], relA, relC) if a >= 2 * c + 5e-2][:6]
+    # analytically-zero gradients (named, see test_mla_e2e_post_training): unused alpha / offset heads -> exactly 0 on both sides; the two
+    # pre-normalisation biases of the point head hold only rounding noise -> |hip| <= 2 |C|
+    zero = {n for n in names if n.startswith(("image_gen_module.mae_alpha_head", "image_gen_module.mae_offset_head"))}
+    zero |= {"pointcloud_gen_module.future_predictor.0.bias", "pointcloud_gen_module.decoder_blocks.1.mlp.3.bias"}
+    live = np.array([n not in zero for n in names])
+    assert set(np.array(names)[A <= 1e-6]) == zero, "the reference's zero-gradient set changed"
+    assert all((k in grads) for k in np.array(names)[live]), "a parameter with a reference gradient got none"
+    assert np.all(gn[~live] <= 2 * C[~live] + 1e-30), list(zip(np.array(names)[~live], gn[~live], C[~live]))
+    relA, relC = np.abs(gn - A) / np.where(live, A, 1.0), np.abs(C - A) / np.where(live, A, 1.0)
+    assert np.median(relA[live]) <= 2 * np.median(relC[live]), (np.median(relA[live]), np.median(relC[live]))   # 9.0e-4 vs 1.5e-3
+    # Named exceptions of the per-parameter rule (measured 1.8e-2 / 2.2e-2 against own rel C 8.7e-3 / 7.1e-3 and a family q90 of
+    # 7.6e-3): two LayerNorm parameters of the point-cloud decoder, whose gradients are sums over the chamfer-assigned points and
+    # move with every re-assignment; bound = twice the WORST rel C of any parameter of that head (1.9e-2), still the reference's own spread
+    exceptions = {"pointcloud_gen_module.decoder_blocks.0.norm2.bias", "pointcloud_gen_module.decoder_blocks.1.norm2.weight"}
+    bad = []
+    for fam in ("image_gen_module", "pointcloud_gen_module"):
+        m = live & np.array([n.startswith(fam) for n in names])
+        q90, worst = float(np.quantile(relC[m], 0.9)), float(relC[m].max())
+        for n, a, c in zip(np.array(names)[m], relA[m], relC[m]):
+            lim = 2 * worst if n in exceptions else 2 * max(c, q90)
+            if a > lim:
+                bad.append((n, float(a), float(c), q90))
+    assert not bad, bad
     for key in gold.files:
         if key.startswith("A_grad::"):
             n = key[len("A_grad::"):]
-            ref = gold[key]
+            ref, refc = gold[key], gold["C_grad::" + n]
             g = grads[n].float().cpu()
             got = (g.reshape(g.shape[0], -1)[:16, :64] if ref.ndim == 2 else g.reshape(-1)[:256]).numpy()
-            # chamfer picks nearest neighbours: bf16 noise flips some assignments, so point-head slices are looser
-            tol = 0.25 if n.startswith("pointcloud_gen_module") else 5e-2
-            assert err(got, ref) < tol, (n, err(got, ref))
+            assert err(got, ref) <= 2 * err(refc, ref), (n, err(got, ref), err(refc, ref))                      # ratios 0.90 .. 1.62
     bn = mgr.pointcloud_gen_module.future_predictor[1]
-    assert fro_rel(bn.running_mean, torch.from_numpy(gold["A_bn_running_mean"])) < 3e-2
-    assert fro_rel(bn.running_var, torch.from_numpy(gold["A_bn_running_var"])) < 3e-2
+    for stat in ("running_mean", "running_var"):
+        ref, refc = gold["A_bn_" + stat], gold["C_bn_" + stat]
+        assert err(getattr(bn, stat).float().cpu().numpy(), ref) <= 2 * err(refc, ref), stat                     # 5.5e-3 | 6.1e-3, 5.1e-4 | 2.0e-3
     assert int(bn.num_batches_tracked) == 1
 
 

@@ -5,7 +5,7 @@ cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 : > $O/r4_config4_attn_asm_ab.txt
 for i in 1 2; do for v in 0 1; do
-  MLA_ATTN_FWD=$v timeout 900 python $R/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/ab4.json
+  MLA_ATTN_FWD=$v timeout 900 python $R/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > /tmp/ab4.json
   python - <<PY >> $O/r4_config4_attn_asm_ab.txt
 import json
 d = json.load(open("/tmp/ab4.json"))

@@ -97,7 +97,60 @@ def gen(dev):
         print(f"   {n:<100} |A| {a:.3e}  hip {ra:.2e}  C {rc:.2e}")
 
 
+def heads(dev):
+    """tests/test_generation_gpu.py::test_generation_heads_against_reference_golden: the generation manager alone vs generation.npz"""
+    import test_generation_gpu as T
+    from mla_amd import ops
+    from oracle import recipe
+    BF = torch.bfloat16
+    gold = np.load(os.path.join(G, "generation.npz"), allow_pickle=True)
+    pfx = "vlm.generation_manager."
+    mgr = T._build_manager(dev)
+    mgr.load_state_dict({k: recipe.det_weight(pfx + k, v.shape) for k, v in mgr.state_dict().items()}, strict=True)
+    T._zero_dropout(mgr)
+    mgr.train().to(dev)
+    for p in mgr.parameters():
+        p.data = p.data.to(BF)
+    hidden, curr, nxt, npc = T._gen_inputs()
+    hd = hidden.to(dev, BF).requires_grad_()
+    outs = mgr(llm_hidden_states=hd)
+    loss_img, parts = ops.ImageGenLossFn.apply(outs["delta_raw"], curr.to(dev, BF), nxt.to(dev, BF), 42, 5.0)
+    loss_pc = ops.ChamferFn.apply(outs["pointcloud_coord_generation"], npc.to(dev))
+    (loss_img + loss_pc).backward()
+    print("\n== generation heads alone (tiny dims) vs reference golden generation.npz: hip | mode C | ratio")
+    for key, got in (("image_gen_loss", loss_img), ("point_cloud_gen_loss", loss_pc)):
+        A, C = float(gold["A_" + key]), float(gold["C_" + key])
+        print(f"loss {key:<28} |hip - A| {abs(float(got) - A):.2e} | |C - A| {abs(C - A):.2e}")
+    delta = (torch.tanh(outs["delta_raw"][..., :5292].float()) * 5.0)[:, ::16, ::97].detach().cpu().numpy()
+    pts = outs["pointcloud_coord_generation"].detach().float().cpu().numpy()
+    hg = hd.grad.float().cpu().numpy()
+    for name, got, a, c in (("delta_slice", delta, "A_delta_slice", "C_delta_slice"), ("points", pts, "A_points", "C_points"),
+                            ("hidden_grad", hg, "A_hidden_grad", "C_hidden_grad")):
+        print(f"act  {name:<28} {err(got, gold[a]):.2e} | {err(gold[c], gold[a]):.2e} | {err(got, gold[a]) / err(gold[c], gold[a]):.2f}")
+    grads = {k: p.grad for k, p in mgr.named_parameters() if p.grad is not None}
+    names = [str(n) for n in gold["grad_names"]]
+    A, C = gold["A_gradnorms"], gold["C_gradnorms"]
+    gn = np.array([float(grads[k].float().norm()) if k in grads else 0.0 for k in names])
+    live = A > 1e-6
+    relA, relC = np.abs(gn - A)[live] / A[live], np.abs(C - A)[live] / A[live]
+    q90 = float(np.quantile(relC, 0.9))
+    print(f"gradient norms over {live.sum()} live parameters: median rel hip {np.median(relA):.2e} | mode C {np.median(relC):.2e}; q90(C) {q90:.2e}; "
+          f"violations of rel(hip) <= 2 max(rel C, q90): {[(n, float(a), float(c)) for n, a, c in zip(np.array(names)[live], relA, relC) if a > 2 * max(c, q90)]}")
+    print("not live (|A| <= 1e-6):", [(n, float(a), float(c), float(h)) for n, a, c, h in zip(names, A, C, gn) if a <= 1e-6])
+    for key in gold.files:
+        if key.startswith("A_grad::"):
+            n = key[len("A_grad::"):]
+            ref = gold[key]
+            g = grads[n].float().cpu()
+            got = (g.reshape(g.shape[0], -1)[:16, :64] if ref.ndim == 2 else g.reshape(-1)[:256]).numpy()
+            c = gold["C_grad::" + n] if ("C_grad::" + n) in gold.files else None
+            print(f"grad {n:<80} {err(got, ref):.2e} | " + (f"{err(c, ref):.2e} | {err(got, ref) / err(c, ref):.2f}" if c is not None else "no mode-C slice in the golden"))
+    bn = mgr.pointcloud_gen_module.future_predictor[1]
+    print("bn running_mean", err(bn.running_mean.float().cpu().numpy(), gold["A_bn_running_mean"]), "running_var", err(bn.running_var.float().cpu().numpy(), gold["A_bn_running_var"]))
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     sft(dev)
     gen(dev)
+    heads(dev)

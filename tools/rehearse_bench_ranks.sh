@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 for n in ${@:-2 8}; do
   port=$((29500 + n))
   MLA_BENCH_REHEARSAL=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
-    --master-port $port $R/bench.py --gpus $n --steps 3 --warmup 1 --tiny --no-cpu-baseline > /tmp/rehearse_$n.out 2> /tmp/rehearse_$n.err
+    --master-port $port $R/bench.py --gpus $n --steps 3 --warmup 1 --tiny --no-cpu-baseline --no-secondary > /tmp/rehearse_$n.out 2> /tmp/rehearse_$n.err
   echo "== N=$n rc=$? stdout lines: $(wc -l < /tmp/rehearse_$n.out)"
   python - <<PY
 import json
