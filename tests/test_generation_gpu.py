@@ -585,3 +585,77 @@ def test_image_generation_module_at_7b_dimensions(dev):
                                                           for k, r, a, b in noise) + "\n")
     bad = [(k, errs[k], errc[k]) for k in errs if not errs[k] <= 2.0 * errc[k]]
     assert not bad, bad
+
+
+def test_pointcloud_generation_module_at_true_dimensions(dev):
+    """`PointCloudGenerationModule` (models/mla/generation/models.py:289-386) at the dimensions `bench.py --config 3` runs -- LLM width
+    4096, transformer width 1024, 4 pre-norm blocks x 8 heads, 128 groups x 32 points, 548 LLM states, B = 2, dropout / DropPath 0,
+    train-mode BatchNorm -- forward + backward against oracle/gen_oracle.py with the yardstick alone (err(hip, fp32 oracle) <=
+    2 x err(bf16-autocast oracle, fp32 oracle), no floor) for the output, d(hidden) and every parameter gradient. The loss is a fixed
+    linear functional of the predicted coordinates (the chamfer loss re-assigns neighbours under bf16 noise and is checked on its own
+    in test_chamfer_fwd_bwd). Named exceptions: the biases in front of train-mode BatchNorm and the key third of `in_proj_bias`
+    (analytically zero gradients: |hip| <= 2 |C| instead of a relative error)."""
+    from mla_amd.generation import PointCloudGenerationModule
+    Hd, C, nh, depth, G, M, B, S = 4096, 1024, 8, 4, 128, 32, 2, 548
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    mod = PointCloudGenerationModule(prismatic_hidden_dim=Hd, trans_dim=C, decoder_depth=depth, decoder_num_heads=nh, group_size=M, num_groups=G)
+    _zero_dropout(mod)
+    g = torch.Generator().manual_seed(23)
+    sd32 = {}
+    for k, v in mod.state_dict().items():
+        if not v.is_floating_point() or "running_" in k:
+            continue
+        if (k.endswith("weight") and v.dim() == 1):
+            t = torch.ones(v.shape) + 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            t = 0.02 * torch.randn(v.shape, generator=g)
+        sd32[k] = t.to(BF).float()
+    mod.load_state_dict({k: v.to(BF) for k, v in sd32.items()}, strict=False)
+    mod.train().to(dev)
+    for p in mod.parameters():
+        p.data = p.data.to(BF)
+    hidden = torch.randn(B, S, Hd, generator=g).to(BF)
+    gy = torch.randn(B, G * M, 3, generator=g).to(BF)
+    names = list(sd32)
+
+    def oracle(sd, h, autocast):
+        for k in names:
+            sd[k].requires_grad_(True)
+        h.requires_grad_(True)
+        if autocast:
+            with torch.autocast("cpu", dtype=BF):
+                d = gen_oracle.pointcloud_generation(h, sd, "", nh, depth, G, M)
+        else:
+            d = gen_oracle.pointcloud_generation(h, sd, "", nh, depth, G, M)
+        (d.float() * gy.float()).sum().backward()
+        return d.detach().float(), h.grad.float(), {k: sd[k].grad.float() for k in names}
+    dA, hA, gA = oracle({k: v.clone() for k, v in sd32.items()}, hidden.float(), False)
+    dC, hC, gC = oracle({k: v.to(BF) for k, v in sd32.items()}, hidden.clone(), True)
+    hd = hidden.to(dev).requires_grad_()
+    out = mod(hd)["pointcloud_coord_generation"]
+    (out.float() * gy.to(dev).float()).sum().backward()
+    grads = {k: p.grad for k, p in mod.named_parameters()}
+    errs = {"points": fro_rel(out, dA), "d_hidden": fro_rel(hd.grad, hA)}
+    errc = {"points": fro_rel(dC, dA), "d_hidden": fro_rel(hC, hA)}
+    zero_abs = []
+    for k in names:
+        got, a, c = grads[k].float().cpu().reshape(gA[k].shape), gA[k], gC[k]
+        if k in ("future_predictor.0.bias", f"decoder_blocks.{depth - 1}.mlp.3.bias"):   # constant row shifts in front of train-mode BatchNorm: the batch mean removes them
+            zero_abs.append((k, float(got.norm()), float(c.norm()), float(a.norm())))
+            continue
+        if k.endswith("in_proj_bias"):
+            ks = slice(C, 2 * C)
+            zero_abs.append((k + "[key third]", float((got[ks] - a[ks]).norm()), float((c[ks] - a[ks]).norm()), float(a[ks].norm())))
+            keep = torch.cat([torch.arange(C), torch.arange(2 * C, 3 * C)])
+            got, a, c = got[keep], a[keep], c[keep]
+        errs[k], errc[k] = fro_rel(got, a), fro_rel(c, a)
+    lines = [f"{k:<45} hip {errs[k]:.2e} | mode C {errc[k]:.2e} | ratio {errs[k] / errc[k]:.2f}" for k in errs]
+    lines += [f"{k:<45} analytically zero: |hip| {h_:.2e} | |C| {c_:.2e} | |A| {a_:.2e}" for k, h_, c_, a_ in zero_abs]
+    print("PointCloudGenerationModule @ true dims (Frobenius-relative error vs the fp32 oracle):\n" + "\n".join(lines))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_pointcloud_gen_true_dims.txt"), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+    bad = [(k, errs[k], errc[k]) for k in errs if not errs[k] <= 2.0 * errc[k]]
+    bad += [(k, h_, c_) for k, h_, c_, _ in zero_abs if not h_ <= 2.0 * c_]
+    assert not bad, bad

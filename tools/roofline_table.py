@@ -17,6 +17,10 @@ ROWS = [   # (substring of the kernel symbol, label, bound, work per STEP, note)
     ("attn_bwd_dq_kernel", "attention backward: dQ kernel", "mfma", 2.5 * ATT * L * 3 / 7, "3 of the 7 executed products (algorithmic bwd = 2.5 x fwd over both kernels)"),
     ("attn_bwd_dkv_kernel", "attention backward: dK/dV kernel", "mfma", 2.5 * ATT * L * 4 / 7, "4 of the 7 executed products"),
     ("attn_bwd_kernel", "attention backward (one pass)", "mfma", 2.5 * ATT * L, "5 products"),
+    # round 5: at S = 548 the backward pair is nearer its HBM roof than its MFMA one -- algorithmic bytes of the TWO-kernel form, per layer:
+    # dQ reads q, k, v, dO, o and writes dq, dq^T, o^T (8 x T x H x 2 B); dK dV reads q, k, v, dO and writes dk, dv, dk^T, dv^T (8 x ...)
+    ("attn_bwd_dq_kernel#hbm", "  same kernel against the HBM roof", "hbm", 8.0 * T * H * 2 * L, "q k v dO o read once, dq dq^T o^T written (two-kernel form)"),
+    ("attn_bwd_dkv_kernel#hbm", "  same kernel against the HBM roof", "hbm", 8.0 * T * H * 2 * L, "q k v dO read once, dk dv dk^T dv^T written"),
     ("adamw_vec4_kernel", "fused AdamW (+ bf16 copy)", "hbm", 30.0 * PARAMS, "30 B / parameter: p, m, v read+write, g read, bf16 write"),
     ("tile_transpose_kernelINS_6CopyOp", "tile transposes (W^T, dy^T)", "hbm", (4.0 * (3 * I * H + 4 * H * H) + 8.0 * T * H) * L, "read + write, 2 B each"),
     ("tile_transpose_kernelINS_10RmsApplyOp", "RMSNorm re-apply, transposed out", "hbm", 4.0 * T * H * 2 * L, "read h, write xn^T"),
@@ -42,6 +46,7 @@ for ln in lines[1:]:
     if ms < 0.001 * wall:
         continue
     row = next((r for r in ROWS if r[0] in sym), None)
+    extra = next((r for r in ROWS if r[0].endswith("#hbm") and r[0][:-4] in sym), None)
     seen += ms
     if row is None:
         print(f"{sym[-38:]:38s} {calls:5d} {ms:8.2f} {100 * ms / wall:6.2f} {'-':>5s} {'-':>12s} {'-':>13s} {'-':>11s} {'-':>6s}  (point / vision tower or framework kernel)")
@@ -55,4 +60,8 @@ for ln in lines[1:]:
         print(f"{label:38s} {calls:5d} {ms:8.2f} {100 * ms / wall:6.2f} {'hbm':>5s} {work / 1e9:9.1f} GB {ach / 1e12:8.2f} TB/s {TB / 1e12:6.1f} TB/s {ach / TB:6.3f}  {note}")
     else:
         print(f"{label:38s} {calls:5d} {ms:8.2f} {100 * ms / wall:6.2f} {'-':>5s} {'-':>12s} {'-':>13s} {'-':>11s} {'-':>6s}  {note}")
+    if extra is not None:
+        _, label, _, work, note = extra
+        ach = work / (ms * 1e-3)
+        print(f"{label:38s} {'':5s} {'':8s} {'':6s} {'hbm':>5s} {work / 1e9:9.1f} GB {ach / 1e12:8.2f} TB/s {TB / 1e12:6.1f} TB/s {ach / TB:6.3f}  {note}")
 print(f"# kernels listed: {seen:.1f} ms of the {wall:.1f} ms step")
