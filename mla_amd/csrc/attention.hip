@@ -1314,6 +1314,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq5_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+#ifndef MLA_ATTN_DKV_RSTAGE
+#define MLA_ATTN_DKV_RSTAGE 0    // 1 = next Q / dO tile through registers (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA: built to test
+                                 // whether the loop is bound by the CU's LDS-DMA landing rate -- it is not: bit-identical and 1.7 % (S = 548) /
+                                 // 4 % (S = 2048) SLOWER (profiles/r5_attn_bwd_regstage_ab.txt), so the copies stay on the DMA path
+#endif
 #ifndef MLA_ATTN_DKV_PF
 #define MLA_ATTN_DKV_PF 6        // transposed fragments in flight in the dV^T / dK^T phase (0 = compiler order, one in flight)
 #endif
@@ -1383,14 +1388,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   for (int qt = qt0; qt < nqt_end; ++qt) {
     const int bufi = (qt - qt0) & 1;
     if (threadIdx.x < 128) stats[bufi * 128 + threadIdx.x] = nstat;
+#if !MLA_ATTN_DKV_RSTAGE
     ATTN_WAIT_VM0();
+#endif
     __syncthreads();
     if (qt == qt0) BT(1, 2);
     if (qt + 1 < nqt_end && threadIdx.x < 128) nstat = load_stat(qt + 1);
     const char* qt_ = smem + bufi * 2 * TILE_BYTES;
     const char* dot_ = qt_ + TILE_BYTES;
-    if (qt + 1 < nqt_end) {
-      char* nx = smem + (bufi ^ 1) * 2 * TILE_BYTES;
+    char* nx = smem + (bufi ^ 1) * 2 * TILE_BYTES;
+    const bool have_next = qt + 1 < nqt_end;
+#if MLA_ATTN_DKV_RSTAGE
+    // Register staging of the next Q / dO tile (round 5 experiment, off by default): coalesced 16-B loads (a wave reads 4 whole 256-B
+    // rows per instruction, the same (row, swizzled chunk) -> lane map as the LDS-DMA copies) held in 32 registers across this tile's
+    // products and written to the other ring buffer with ds_write_b128 at the bottom of the iteration. Hypothesis tested: two resident
+    // blocks x 32 KiB per 64-query tile every ~4.4 k cycles = 14.5 B/cycle/CU is about what one CU's LDS-DMA path lands (~25 GB/s), so
+    // the loop might be bound by the copy engine. Measured: no -- the same tile time through the TA / L1 path, slightly worse overall.
+    u32x4_t stg[8];
+    if (have_next) {
+      if ((qt + 2) * 64 <= p.S) {
+        const bf16_t* qn = qb_ + (long long)(qt + 1) * 64 * p.ld;
+        const bf16_t* dn = dob_ + (long long)(qt + 1) * 64 * p.ld_o;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          stg[it] = *(const u32x4_t*)(qn + qoff[it]);
+          stg[4 + it] = *(const u32x4_t*)(dn + dooff[it]);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int pp = (wave * 4 + it) * 64 + lane;
+          const int row = pp >> 4, c = swz<ASW>(row, pp & 15);
+          int gr = (qt + 1) * 64 + row;
+          gr = gr < p.S ? gr : p.S - 1;
+          stg[it] = *(const u32x4_t*)(qb_ + (long long)gr * p.ld + c * 8);
+          stg[4 + it] = *(const u32x4_t*)(dob_ + (long long)gr * p.ld_o + c * 8);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    if (have_next) {
       if ((qt + 2) * 64 <= p.S) {
         stage_fast(qb_ + (long long)(qt + 1) * 64 * p.ld, qoff, nx, wave);
         stage_fast(dob_ + (long long)(qt + 1) * 64 * p.ld_o, dooff, nx + TILE_BYTES, wave);
@@ -1399,6 +1437,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         stage_rows64<ASW>(dob_, p.ld_o, (qt + 1) * 64, p.S, nx + TILE_BYTES, wave, lane);
       }
     }
+#endif
     // two 32-query halves, each carried through S / dP -> P, dS -> bf16 before the next starts (see dq_tile): 16 score registers
     // instead of 32, and the second half's MFMAs overlap the first half's exp / pack VALU. Bit-identical.
     bf16x8_t ph[2], dsh[2];
@@ -1484,6 +1523,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         if (i + PF < 32) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // fragment i + PF
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+#if MLA_ATTN_DKV_RSTAGE
+    if (have_next) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        *(u32x4_t*)(nx + (wave * 4 + it) * 1024 + lane * 16) = stg[it];
+        *(u32x4_t*)(nx + TILE_BYTES + (wave * 4 + it) * 1024 + lane * 16) = stg[4 + it];
+      }
     }
 #endif
   }
