@@ -1623,6 +1623,425 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   BT(1, 5);
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward (round 5 experiment)
+// ONE workgroup per (batch, head) for sequences of at most 9 key tiles (S <= 576: the benchmark's 548): every operand is read once and
+// S / dP are computed once (5 products instead of 7). Why: the block-phase stamps of the two-kernel form (profiles/r5_attn_bwd_block_trace_*)
+// put 40-60 % of a block's life at S = 548 into prologue / epilogue memory time, both kernels read q, k, v, dO, and a lone wave needs
+// ~9.4 cycles per instruction against ~5.9 per SIMD with two -- so the lever is fewer instructions and bytes per (query tile, key tile)
+// pair, not a better schedule of the same ones.
+//   outer loop: key tile kb;  inner: query tiles qt >= kb.  Per pair:
+//     phase 1  wave (qg = w & 3, key half) : S = Q K^T, dP = dO V^T for 16 queries x (64 or 32) keys -> P, dS (bf16) into two [key][q]
+//              LDS images (PT, DST)
+//     phase 2  wave w owns head-dim slice [w * 128/NW, ...): dV^T += dO^T P, dK^T += Q^T dS (this key tile), dQ^T[qt] += K^T dS^T
+//   dQ^T of ALL query tiles stays in registers for the whole head (9 x 16 registers per 16-wide slice), dK^T / dV^T for the key tile.
+//   Every output leaves through fb_epilogue (scale, RoPE backward with the (d, d + 64) partner fetched through LDS, row image +
+//   transposed image -> whole-row stores), the same images as the two-kernel form.
+// Reduction orders match the two-kernel form (key tiles ascending for dQ, query tiles ascending for dK / dV, two 32-deep MFMA steps per
+// tile): results are compared bit for bit in tools/exp_attn_bits.py and tests/test_kernels_gpu.py.
+// STATUS (round 5): correct on the first GPU run and bit-identical on all 48 comparison tensors, but 1 212 us against 742 us for the
+// two-kernel form at S = 548, B = 32 (8 waves; the 4-wave / 512-register variant spilled 700+ registers and is not instantiated).
+// Per head 640 k cycles (tools/exp_attn_fused_trace.py): prologue 57 k, phase 1 2.5 k x 45 pairs, phase 2 4.65 k x 45 (24 MFMAs behind
+// 64 un-pipelined LDS reads, ~50 cycles per instruction: the [key][q] images are read with bank conflicts and one fragment in
+// flight), key-tile epilogues 14 k x 9, dQ epilogues 8 k x 9 (each ends in stores whose acknowledgement the next vmcnt(0) waits for).
+// With one workgroup per CU nothing hides any of it. Kept opt-in (MLA_ATTN_BWD_FUSED=8) as the starting point for the next round.
+constexpr int FB_MAXT = 9;
+constexpr int FB_KV = 4 * TILE_BYTES;            // K tile, V tile
+constexpr int FB_PT = 6 * TILE_BYTES;            // P  [64 keys][64 q] bf16 (8 KiB)
+constexpr int FB_DST = FB_PT + 8192;             // dS [64 keys][64 q] bf16
+constexpr int FB_EPI = FB_DST + 8192;            // epilogue images: rows 16 KiB + transposed 16 KiB
+constexpr int FB_STAT = FB_EPI + 2 * TILE_BYTES; // lse * log2(e) [576] | delta [576]
+constexpr int FB_LDS = FB_STAT + 2 * FB_MAXT * 64 * 4;
+
+// B operand of the dV^T / dK^T products from a [key][q] image: lane (key = kf * 16 + (lane & 15), g) gets the 8 queries
+// ks2 * 32 + jj * 16 + g * 4 + (0..3) -- the reduction mapping of frag_tr -- as two 8-byte reads
+__device__ __forceinline__ bf16x8_t fb_pfrag(const char* img, int kf, int ks2, int lane) {
+  const int key = kf * 16 + (lane & 15), g = lane >> 4;
+  union { bf16x8_t v; u32x2_t h[2]; } u;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+    u.h[jj] = *(const u32x2_t*)(img + (key * 8 + swz64(key, ks2 * 4 + jj * 2 + (g >> 1))) * 16 + (g & 1) * 8);
+  return u.v;
+}
+
+// acc[DF][4]: this wave's head-dim fragments fd = wave * DF + df of a 64-token tile, lane = (token tf * 16 + (lane & 15); d = fd * 16 + g * 4 + r).
+// Writes rows[tok0 + token][d] (bf16, ld_rows) and, when outT, outT[d][tokT0 + token]. RoPE backward pairs d with d + 64, which lives in
+// another wave: the bf16-rounded pre-rotation values go through the row image first.
+template <int NW>
+__device__ __forceinline__ void fb_epilogue(const AttnArgs& p, char* smem, f32x4_t (&acc)[8 / NW][4], bf16_t* __restrict__ rows, long long ld_rows,
+                                            bf16_t* __restrict__ outT, long long tokT0, int tok0, float scale, bool rope, int wave, int lane) {
+  constexpr int DF = 8 / NW, NT = 64 * NW;
+  asm volatile("" : "+v"(lane));
+  const int g = lane >> 4, pq = lane & 3;
+  char* img = smem + FB_EPI;
+  char* imgT = smem + FB_EPI + TILE_BYTES;
+  u32x2_t w[DF][4];
+  f32x4_t cs[DF][4], sn[DF][4];
+  if (rope) {
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int tf = 0; tf < 4; ++tf) {
+        const int tok = tok0 + tf * 16 + (lane & 15);
+        const int pos = tok < p.S ? tok : 0;
+        const int fd = wave * DF + df;
+        cs[df][tf] = *(const f32x4_t*)(p.rope_cos + (size_t)pos * 64 + (fd & 3) * 16 + g * 4);
+        sn[df][tf] = *(const f32x4_t*)(p.rope_sin + (size_t)pos * 64 + (fd & 3) * 16 + g * 4);
+      }
+  }
+#pragma unroll
+  for (int df = 0; df < DF; ++df)
+#pragma unroll
+    for (int tf = 0; tf < 4; ++tf) {
+      const bool valid = tok0 + tf * 16 + (lane & 15) < p.S;
+      acc[df][tf] *= scale;
+      w[df][tf][0] = valid ? pack2bf(acc[df][tf][0], acc[df][tf][1]) : 0u;
+      w[df][tf][1] = valid ? pack2bf(acc[df][tf][2], acc[df][tf][3]) : 0u;
+    }
+  auto img_off = [&](int fd, int tf) { const int row = tf * 16 + (lane & 15); return row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8); };
+  if (rope) {
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int tf = 0; tf < 4; ++tf) *(u32x2_t*)(img + img_off(wave * DF + df, tf)) = w[df][tf];
+    __syncthreads();
+    u32x2_t part[DF][4];
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int tf = 0; tf < 4; ++tf) part[df][tf] = *(const u32x2_t*)(img + img_off((wave * DF + df) ^ 4, tf));
+    __syncthreads();
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int tf = 0; tf < 4; ++tf) {
+        const bool hi = ((wave * DF + df) & 4) != 0;          // this lane holds the second half (d >= 64) of the pair
+        const bool valid = tok0 + tf * 16 + (lane & 15) < p.S;
+        float o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t ow = w[df][tf][r >> 1], pw = part[df][tf][r >> 1];
+          const float own = (r & 1) ? bfhi(ow) : bflo(ow), oth = (r & 1) ? bfhi(pw) : bflo(pw);
+          const float a = hi ? oth : own, b_ = hi ? own : oth;      // a = first half, b = second half (bf16-rounded, as rope_bwd_row)
+          const float s_ = -sn[df][tf][r], c = cs[df][tf][r];
+          o4[r] = hi ? fmaf(b_, c, a * s_) : fmaf(a, c, -(b_ * s_));
+        }
+        w[df][tf][0] = valid ? pack2bf(o4[0], o4[1]) : 0u;
+        w[df][tf][1] = valid ? pack2bf(o4[2], o4[3]) : 0u;
+      }
+  }
+#pragma unroll
+  for (int df = 0; df < DF; ++df)
+#pragma unroll
+    for (int tf = 0; tf < 4; ++tf) {
+      const int fd = wave * DF + df;
+      *(u32x2_t*)(img + img_off(fd, tf)) = w[df][tf];
+      if (outT) {
+        const int c = fd * 16 + g * 4 + pq;
+        *(u32x2_t*)(imgT + c * 128 + (((tf * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(w[df][tf][0], w[df][tf][1], lane);
+      }
+    }
+  __syncthreads();
+  {
+    const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
+#pragma unroll
+    for (int ps = 0; ps < 64 / (NT / 16); ++ps) {
+      const int r = ps * (NT / 16) + (threadIdx.x >> 4);
+      if (tok0 + r < p.S) *(u32x4_t*)(rows + (long long)(tok0 + r) * ld_rows + j * 8) = *(const u32x4_t*)(img + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
+    }
+  }
+  if (outT) {
+    const int j = threadIdx.x & 15;                       // 8-B chunk = tokens tok0 + 4 j .. + 3
+    if (tok0 + j * 4 < p.S) {
+#pragma unroll
+      for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
+        const int c = ps * (NT / 16) + (threadIdx.x >> 4);
+        *(u32x2_t*)(outT + (long long)c * p.ldT + tokT0 + tok0 + j * 4) = *(const u32x2_t*)(imgT + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Per-lane LDS byte offsets of every fragment form the pair body reads, computed ONCE: each accessor below is `base + offset + constant`,
+// so a pair costs a handful of address adds (the ring parity) instead of re-deriving ~60 swizzled addresses (first version: ~600 VALU
+// per pair and wave against 40 MFMAs -- 1 200-1 350 us) and the compiler has nothing lane-dependent left to hoist and spill.
+template <int NW>
+struct FbOff {
+  unsigned R[4];        // frag_rows<ASW>(tile, 0, ks, lane): + rb * 4096
+  unsigned T[8 / NW];   // frag_tr<ASW>(tile, fd, 0, lane) first read: + ks2 * 8192 + jj * 4096
+  unsigned P[2][2];     // fb_pfrag(img, 0, ks2, lane) read jj: + kf * 2048
+  unsigned Q4[4];       // frag_tr64(img, qf, 0, lane) first read: + ks2 * 4096 + jj * 2048
+  unsigned W;           // producer write into PT / DST for key fragment 0: + kf * 2048
+  unsigned ST;          // stats: (qg * 16 + g * 4) * 4 bytes: + qt * 256
+};
+template <int NW>
+__device__ __forceinline__ void fb_offsets(FbOff<NW>& o, int wave, int lane) {
+  const int i = lane & 15, g = lane >> 4, qg = wave & 3;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) o.R[ks] = (unsigned)((i * 16 + swz<ASW>(i, ks * 4 + g)) * 16);
+#pragma unroll
+  for (int df = 0; df < 8 / NW; ++df) {
+    const int fd = wave * (8 / NW) + df, row = g * 4 + (i >> 2);
+    o.T[df] = (unsigned)((row * 16 + swz<ASW>(row, fd * 2 + ((i & 3) >> 1))) * 16 + (i & 1) * 8);
+  }
+#pragma unroll
+  for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) o.P[ks2][jj] = (unsigned)((i * 8 + swz64(i, ks2 * 4 + jj * 2 + (g >> 1))) * 16 + (g & 1) * 8);
+#pragma unroll
+  for (int qf = 0; qf < 4; ++qf) {
+    const int row = g * 4 + (i >> 2);
+    o.Q4[qf] = (unsigned)((row * 8 + swz64(row, qf * 2 + ((i & 3) >> 1))) * 16 + (i & 1) * 8);
+  }
+  o.W = (unsigned)((i * 8 + swz64(i, qg * 2 + (g >> 1))) * 16 + (g & 1) * 8);
+  o.ST = (unsigned)((qg * 16 + g * 4) * 4);
+}
+// (the swizzles only look at row & 7 / (row >> 1) & 3, so adding rb * 16 or ks2 * 32 + jj * 16 rows leaves the chunk index unchanged:
+// the constants above are exact)
+static_assert(ASW == 1 || ASW == 0, "fb_offsets: frag_tr's row term assumes a swizzle of the low 3 / 4 row bits");
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_bwd_fused_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DF = 8 / NW, NKF = 16 / NW, NST = 16 / NW;
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+  const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
+  const int row_lim = seqlen < p.S ? seqlen : p.S;
+  const int NT_ = (p.S + 63) / 64;
+  const bf16_t* qb_ = p.q + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* vb_ = p.v + (long long)b * p.S * p.ld + h * D;
+  const bf16_t* dob_ = p.dout + (long long)b * p.S * p.ld_o + h * D;
+  const bf16_t* ob_ = p.o + (long long)b * p.S * p.ld_o + h * D;
+  float* lse2s = (float*)(smem + FB_STAT);
+  float* dlts = lse2s + FB_MAXT * 64;
+  const float sc2 = p.scale * LOG2E;
+  const bool tr = p.dqT != nullptr;
+  const long long tokT0 = (long long)b * p.S;
+  BT(0, 0);
+#ifdef MLA_ATTN_BTRACE
+  unsigned long long tp1 = 0, tp2 = 0, tep = 0, tc = 0;
+#define FBT(acc) do { const unsigned long long now__ = __builtin_readcyclecounter(); acc += now__ - tc; tc = now__; } while (0)
+#else
+#define FBT(acc) ((void)0)
+#endif
+
+  // ---- prologue: lse, delta = rowsum(O * dO) and o^T for the whole head, one 64-row tile at a time through the ring
+  for (int t = 0; t < NT_; ++t) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4;
+    char* ot = smem + (t & 1) * 2 * TILE_BYTES;
+    stage_rows64<ASW, NW>(ob_, p.ld_o, t * 64, p.S, ot, wave, lane);
+    stage_rows64<ASW, NW>(dob_, p.ld_o, t * 64, p.S, ot + TILE_BYTES, wave, lane);
+    float lse_raw = 0.f;
+    const int myrow = t * 64 + (wave & 3) * 16 + (lane & 15);
+    if (wave < 4) lse_raw = p.lse[((long long)b * p.H + h) * p.S + (myrow < p.S ? myrow : p.S - 1)];
+    ATTN_WAIT_VM0();
+    __syncthreads();
+    if (wave < 4) {
+      bf16x8_t of[4];
+      float acc = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        of[ks] = frag_rows<ASW>(ot, wave, ks, lane);
+        const bf16x8_t dfr = frag_rows<ASW>(ot + TILE_BYTES, wave, ks, lane);
+        union { bf16x8_t v; uint32_t w[4]; } a, d;
+        a.v = of[ks];
+        d.v = dfr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += bflo(a.w[j]) * bflo(d.w[j]) + bfhi(a.w[j]) * bfhi(d.w[j]);
+      }
+      const float dl = group_sum(acc);
+      const bool pad = myrow >= row_lim;
+      if (g == 0) {
+        lse2s[myrow] = pad ? INFINITY : lse_raw * LOG2E;
+        dlts[myrow] = dl;
+        if (myrow < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myrow] = dl;
+      }
+      if (tr) {
+        char* imgT = smem + FB_EPI + TILE_BYTES;
+        const int pq = lane & 3;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          union { bf16x8_t v; uint32_t u[4]; } f;
+          f.v = of[ks];
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int c = ks * 32 + g * 8 + half * 4 + pq;
+            *(u32x2_t*)(imgT + c * 128 + (((wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
+          }
+        }
+      }
+    }
+    if (tr) {
+      __syncthreads();
+      const char* imgT = smem + FB_EPI + TILE_BYTES;
+      const int j = threadIdx.x & 15;
+      if (t * 64 + j * 4 < p.S) {
+#pragma unroll
+        for (int ps = 0; ps < 128 / (4 * NW); ++ps) {
+          const int c = ps * (4 * NW) + (threadIdx.x >> 4);
+          *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tokT0 + t * 64 + j * 4) = *(const u32x2_t*)(imgT + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  BT(0, 1);
+  // ---- main loop
+  FbOff<NW> fo;
+  fb_offsets<NW>(fo, wave, lane0);
+  const int li = lane0 & 15;
+  f32x4_t dqt[FB_MAXT][DF][4];
+#pragma unroll
+  for (int t = 0; t < FB_MAXT; ++t)
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int qf = 0; qf < 4; ++qf) dqt[t][df][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem + FB_KV, wave, lane0);
+  stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + FB_KV + TILE_BYTES, wave, lane0);
+  stage_rows64<ASW, NW>(qb_, p.ld, 0, p.S, smem, wave, lane0);
+  stage_rows64<ASW, NW>(dob_, p.ld_o, 0, p.S, smem + TILE_BYTES, wave, lane0);
+  int n = 0;                                       // pair counter: ring buffer n & 1 holds the pair's Q | dO tile
+  const int qg = wave & 3, kh = NW == 8 ? (wave >> 2) : 0;
+  for (int kb = 0; kb < NT_; ++kb) {
+    f32x4_t dkt[DF][4], dvt[DF][4];
+    bf16x8_t kT[DF][2];
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) { dkt[df][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[df][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qt = 0; qt < FB_MAXT; ++qt) {
+      if (qt < kb || qt >= NT_) continue;
+      ATTN_WAIT_VM0();
+      __syncthreads();                             // pair n's tile landed; everybody is done with pair n - 1
+#ifdef MLA_ATTN_BTRACE
+      tc = __builtin_readcyclecounter();
+#endif
+      const char* ring = smem + (n & 1) * 2 * TILE_BYTES;      // Q tile, dO tile at + TILE_BYTES
+      const char* kv = smem + FB_KV;                           // K tile, V tile at + TILE_BYTES
+      // (staging addresses are re-derived from an opaque copy of the lane id: hoisted out of the key-tile loop they were spilled and
+      // reloaded inside it, and a scratch reload's vmcnt(0) waits for the copies just issued)
+      int lane_s = lane0;
+      asm volatile("" : "+v"(lane_s));
+      {                                            // next pair's Q | dO tile into the other ring buffer
+        const int nqt = qt + 1 < NT_ ? qt + 1 : kb + 1;
+        if (nqt < NT_) {
+          char* nx = smem + ((n + 1) & 1) * 2 * TILE_BYTES;
+          stage_rows64<ASW, NW>(qb_, p.ld, nqt * 64, p.S, nx, wave, lane_s);
+          stage_rows64<ASW, NW>(dob_, p.ld_o, nqt * 64, p.S, nx + TILE_BYTES, wave, lane_s);
+        }
+      }
+      if (qt == kb) {
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+          for (int ks2 = 0; ks2 < 2; ++ks2) {
+            union { bf16x8_t v; short4_t hh[2]; } u;
+            u.hh[0] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192);
+            u.hh[1] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192 + 4096);
+            kT[df][ks2] = u.v;
+          }
+      }
+      // phase 1: S, dP for 16 queries (group qg) x NKF key fragments
+      {
+        f32x4_t s[NKF], dp[NKF];
+#pragma unroll
+        for (int kk = 0; kk < NKF; ++kk) { s[kk] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kk] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8_t qa = *(const bf16x8_t*)(ring + fo.R[ks] + qg * 4096), da = *(const bf16x8_t*)(ring + fo.R[ks] + TILE_BYTES + qg * 4096);
+#pragma unroll
+          for (int kk = 0; kk < NKF; ++kk) {
+            const int kf = kh * NKF + kk;
+            s[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, *(const bf16x8_t*)(kv + fo.R[ks] + kf * 4096), s[kk], 0, 0, 0);
+            dp[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, *(const bf16x8_t*)(kv + fo.R[ks] + TILE_BYTES + kf * 4096), dp[kk], 0, 0, 0);
+          }
+        }
+        const f32x4_t l4 = *(const f32x4_t*)(smem + FB_STAT + fo.ST + qt * 256);
+        const f32x4_t d4 = *(const f32x4_t*)(smem + FB_STAT + FB_MAXT * 256 + fo.ST + qt * 256);
+        const int g = lane0 >> 4;
+#pragma unroll
+        for (int kk = 0; kk < NKF; ++kk) {
+          const int kf = kh * NKF + kk;
+          const int key = kf * 16 + li;
+          float pr[4], dsv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = s[kk][r];
+            if (qt == kb && key > qg * 16 + g * 4 + r) sv = -INFINITY;     // diagonal tile: causal mask
+            const float pv = __builtin_amdgcn_exp2f(sv * sc2 - l4[r]);
+            pr[r] = pv;
+            dsv[r] = pv * (dp[kk][r] - d4[r]);
+          }
+          *(u32x2_t*)(smem + FB_PT + fo.W + kf * 2048) = u32x2_t{pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3])};
+          *(u32x2_t*)(smem + FB_DST + fo.W + kf * 2048) = u32x2_t{pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
+        }
+      }
+      __syncthreads();
+      FBT(tp1);
+      if (qt == NT_ - 1 && kb + 1 < NT_) {         // last pair of this key tile: its K | V rows are no longer read
+        stage_rows64<ASW, NW>(kb_, p.ld, (kb + 1) * 64, p.S, smem + FB_KV, wave, lane_s);
+        stage_rows64<ASW, NW>(vb_, p.ld, (kb + 1) * 64, p.S, smem + FB_KV + TILE_BYTES, wave, lane_s);
+      }
+      // phase 2: this wave's head-dim slice of dV^T, dK^T (key tile kb) and dQ^T (query tile qt)
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          union { bf16x8_t v; short4_t hh[2]; } ado, aq;
+          ado.hh[0] = lds_tr16_b64(ring + TILE_BYTES + fo.T[df] + ks2 * 8192);
+          ado.hh[1] = lds_tr16_b64(ring + TILE_BYTES + fo.T[df] + ks2 * 8192 + 4096);
+          aq.hh[0] = lds_tr16_b64(ring + fo.T[df] + ks2 * 8192);
+          aq.hh[1] = lds_tr16_b64(ring + fo.T[df] + ks2 * 8192 + 4096);
+#pragma unroll
+          for (int kf = 0; kf < 4; ++kf) {
+            union { bf16x8_t v; u32x2_t hh[2]; } bp, bs;
+            bp.hh[0] = *(const u32x2_t*)(smem + FB_PT + fo.P[ks2][0] + kf * 2048);
+            bp.hh[1] = *(const u32x2_t*)(smem + FB_PT + fo.P[ks2][1] + kf * 2048);
+            bs.hh[0] = *(const u32x2_t*)(smem + FB_DST + fo.P[ks2][0] + kf * 2048);
+            bs.hh[1] = *(const u32x2_t*)(smem + FB_DST + fo.P[ks2][1] + kf * 2048);
+            dvt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado.v, bp.v, dvt[df][kf], 0, 0, 0);
+            dkt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.v, bs.v, dkt[df][kf], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+          for (int qf = 0; qf < 4; ++qf) {
+            union { bf16x8_t v; short4_t hh[2]; } bt;
+            bt.hh[0] = lds_tr16_b64(smem + FB_DST + fo.Q4[qf] + ks2 * 4096);
+            bt.hh[1] = lds_tr16_b64(smem + FB_DST + fo.Q4[qf] + ks2 * 4096 + 2048);
+            dqt[qt][df][qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[df][ks2], bt.v, dqt[qt][df][qf], 0, 0, 0);
+          }
+      }
+      FBT(tp2);
+      ++n;
+    }
+    // ---- key tile kb done: dv, dk (+ transposed copies)
+    fb_epilogue<NW>(p, smem, dvt, p.dv + ((long long)b * p.S) * p.ld + h * D, p.ld, tr ? p.dvT + (long long)h * D * p.ldT : nullptr, tokT0, kb * 64, 1.0f, false, wave, lane0);
+    fb_epilogue<NW>(p, smem, dkt, p.dk + ((long long)b * p.S) * p.ld + h * D, p.ld, tr ? p.dkT + (long long)h * D * p.ldT : nullptr, tokT0, kb * 64, p.scale, p.rope_cos != nullptr, wave, lane0);
+    FBT(tep);
+  }
+  BT(0, 2);
+#pragma unroll
+  for (int qt = 0; qt < FB_MAXT; ++qt) {
+    if (qt >= NT_) continue;
+    fb_epilogue<NW>(p, smem, dqt[qt], p.dq + ((long long)b * p.S) * p.ld + h * D, p.ld, tr ? p.dqT + (long long)h * D * p.ldT : nullptr, tokT0, qt * 64, p.scale, p.rope_cos != nullptr, wave, lane0);
+  }
+  BT(0, 3);
+  BTV(0, 4, tep);
+  BTV(0, 5, tp1);
+  BTV(0, 6, tp2);
+}
+
 int check_common(const AttnArgs& p, const char* who) {
   if (!(p.B > 0 && p.S > 0 && p.H > 0)) { mla_set_error("%s: bad shape", who); return -1; }
   if ((p.ld % 8) || (p.ld_o % 8)) { mla_set_error("%s: strides must be multiples of 8 elements", who); return -1; }
@@ -1695,12 +2114,24 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   if (check_common(p, "mla_attn_bwd")) return -1;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_RB, DQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_RB, DQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 32768);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024 + 32768);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
     attr = true;
   }
   p.o = (bf16_t*)o;
+  // MLA_ATTN_BWD_FUSED=8: the one-workgroup-per-head backward (S <= 576; experiment, opt-in: bit-identical to the two-kernel form and
+  // 1.6 x SLOWER in its first, un-pipelined form -- see attn_bwd_fused_kernel and HISTORY.md "Round 5")
+  static const int fused = getenv("MLA_ATTN_BWD_FUSED") ? atoi(getenv("MLA_ATTN_BWD_FUSED")) : 0;
+  if (!ws && fused == 8 && S <= 64 * FB_MAXT && S % 4 == 0) {
+    static bool fattr = false;
+    if (!fattr) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+      fattr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(B * H), dim3(512), FB_LDS, stream, p);
+    MLA_LAUNCH_CHECK();
+  }
   if (ws) {
     // 5-product form: delta pass -> dK / dV kernel (stores dS^T) -> one-product dQ kernel
     const long long nqt = (S + 63) / 64, need = (long long)B * H * (nqt * (nqt + 1) / 2) * 8192;
@@ -1720,8 +2151,11 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   // delta = rowsum(O * dO) is computed by the dQ kernel's prologue (p.o set) and read by the dK / dV kernel launched behind it
   constexpr int BQ = 16 * DQ_NW * DQ_RB;
   static_assert(BQ == 128, "the transposed-output epilogue of the dQ kernel stages a 128-query image");
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DQ_RB, DQ_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * DQ_NW), 4 * TILE_BYTES, stream, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
+  // experiment knob (tools/exp_attn_btrace.py): MLA_ATTN_BWD_LDS_EXTRA=32768 leaves ONE block per CU (one wave per SIMD) -- what a wave's
+  // tile costs without a second resident block to share the CU with
+  static const int lds_extra = getenv("MLA_ATTN_BWD_LDS_EXTRA") ? (atoi(getenv("MLA_ATTN_BWD_LDS_EXTRA")) > 0 ? 32768 : 0) : 0;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DQ_RB, DQ_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * DQ_NW), 4 * TILE_BYTES + lds_extra, stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024 + lds_extra, stream, p);
   MLA_LAUNCH_CHECK();
 }
 extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,

@@ -62,3 +62,19 @@ def test_the_variable_selects_another_kernel_with_the_same_results(dev, tmp_path
         assert torch.equal(o0 == 0, o1 == 0) or float(((o0 == 0) != (o1 == 0)).float().mean()) < 1e-3, key
         differ += int(not torch.equal(o0, o1))
     assert differ > 0, "MLA_ATTN_FWD=1 produced the default kernel's bits: the assembly forward did not run"
+
+
+def test_fused_backward_is_bit_identical_to_the_two_kernel_form(dev, tmp_path):
+    """The opt-in one-workgroup-per-head backward (MLA_ATTN_BWD_FUSED=8, attn_bwd_fused_kernel: five products, every operand read once,
+    S <= 576) against the default two-kernel, seven-product backward: tools/exp_attn_bits.py dumps dq | dk | dv, their transposes, o^T
+    and the RoPE-fused forms for full, ragged and padding-only shapes in two child processes (the variant is read once per process);
+    the reduction orders are the same by construction, so the comparison is bit for bit. Shapes above 576 fall back to the two-kernel form."""
+    a, b = str(tmp_path / "two.pt"), str(tmp_path / "fused.pt")
+    tool = os.path.join("tools", "exp_attn_bits.py")
+    r0 = _child({"MLA_ATTN_BWD_FUSED": "0"}, [tool, a], timeout=600)
+    r1 = _child({"MLA_ATTN_BWD_FUSED": "8"}, [tool, b], timeout=600)
+    assert r0.returncode == 0 and r1.returncode == 0, (r0.stderr[-500:], r1.stderr[-500:])
+    x, y = torch.load(a), torch.load(b)
+    assert x.keys() == y.keys() and len(x) >= 40
+    bad = [k for k in x if not torch.equal(x[k], y[k])]
+    assert not bad, bad
