@@ -1646,9 +1646,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 // With one workgroup per CU nothing hides any of it. Kept opt-in (MLA_ATTN_BWD_FUSED=8) as the starting point for the next round.
 constexpr int FB_MAXT = 9;
 constexpr int FB_KV = 4 * TILE_BYTES;            // K tile, V tile
-constexpr int FB_PT = 6 * TILE_BYTES;            // P  [64 keys][64 q] bf16 (8 KiB)
-constexpr int FB_DST = FB_PT + 8192;             // dS [64 keys][64 q] bf16
-constexpr int FB_EPI = FB_DST + 8192;            // epilogue images: rows 16 KiB + transposed 16 KiB
+constexpr int FB_PSTR = 144;                     // bytes per key row of the P / dS images: 64 q x 2 B + 16 B of padding (a 128-B pitch
+                                                 // puts every second row on the same banks; 144 B = 36 banks spreads 16 rows over all 64)
+constexpr int FB_PT = 6 * TILE_BYTES;            // P  [64 keys][64 q] bf16, q order within a row: ks2 * 32 + g * 8 + jj * 4 + r for
+constexpr int FB_DST = FB_PT + 64 * FB_PSTR;     // dS     q = ks2 * 32 + jj * 16 + g * 4 + r  (the 8 q of one MFMA k-group are 16 contiguous bytes)
+constexpr int FB_EPI = FB_DST + 64 * FB_PSTR;    // epilogue images: rows 16 KiB + transposed 16 KiB
 constexpr int FB_STAT = FB_EPI + 2 * TILE_BYTES; // lse * log2(e) [576] | delta [576]
 constexpr int FB_LDS = FB_STAT + 2 * FB_MAXT * 64 * 4;
 
@@ -1769,9 +1771,9 @@ template <int NW>
 struct FbOff {
   unsigned R[4];        // frag_rows<ASW>(tile, 0, ks, lane): + rb * 4096
   unsigned T[8 / NW];   // frag_tr<ASW>(tile, fd, 0, lane) first read: + ks2 * 8192 + jj * 4096
-  unsigned P[2][2];     // fb_pfrag(img, 0, ks2, lane) read jj: + kf * 2048
-  unsigned Q4[4];       // frag_tr64(img, qf, 0, lane) first read: + ks2 * 4096 + jj * 2048
-  unsigned W;           // producer write into PT / DST for key fragment 0: + kf * 2048
+  unsigned P;           // B operand of dV^T / dK^T from a P / dS image: one 16-B read at + kf * 16 * FB_PSTR + ks2 * 64
+  unsigned Q4;          // B operand of dQ^T (dS^T, transposing read): + (ks2 * 32 + jj * 16) * FB_PSTR (key rows) + (qf >> 1) * 64 + (qf & 1) * 8
+  unsigned W;           // producer write into PT / DST for key fragment 0: + kf * 16 * FB_PSTR
   unsigned ST;          // stats: (qg * 16 + g * 4) * 4 bytes: + qt * 256
 };
 template <int NW>
@@ -1784,21 +1786,13 @@ __device__ __forceinline__ void fb_offsets(FbOff<NW>& o, int wave, int lane) {
     const int fd = wave * (8 / NW) + df, row = g * 4 + (i >> 2);
     o.T[df] = (unsigned)((row * 16 + swz<ASW>(row, fd * 2 + ((i & 3) >> 1))) * 16 + (i & 1) * 8);
   }
-#pragma unroll
-  for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) o.P[ks2][jj] = (unsigned)((i * 8 + swz64(i, ks2 * 4 + jj * 2 + (g >> 1))) * 16 + (g & 1) * 8);
-#pragma unroll
-  for (int qf = 0; qf < 4; ++qf) {
-    const int row = g * 4 + (i >> 2);
-    o.Q4[qf] = (unsigned)((row * 8 + swz64(row, qf * 2 + ((i & 3) >> 1))) * 16 + (i & 1) * 8);
-  }
-  o.W = (unsigned)((i * 8 + swz64(i, qg * 2 + (g >> 1))) * 16 + (g & 1) * 8);
+  o.P = (unsigned)(i * FB_PSTR + g * 16);                                  // lane (key i, k-group g): 8 q at ks2 * 32 + g * 8 .. + 7
+  o.Q4 = (unsigned)((g * 4 + (i >> 2)) * FB_PSTR + (i & 3) * 16);           // transposing read: source lane (key row g * 4 + (i >> 2), 4-q group i & 3)
+  o.W = (unsigned)(i * FB_PSTR + (qg >> 1) * 64 + g * 16 + (qg & 1) * 8);   // this wave's 16 q (group qg = 2 ks2 + jj), 4 of them (r) per lane
   o.ST = (unsigned)((qg * 16 + g * 4) * 4);
 }
-// (the swizzles only look at row & 7 / (row >> 1) & 3, so adding rb * 16 or ks2 * 32 + jj * 16 rows leaves the chunk index unchanged:
+// (the tile swizzles only look at row & 7 / row & 15, so adding rb * 16 or ks2 * 32 + jj * 16 rows leaves the chunk index unchanged:
 // the constants above are exact)
-static_assert(ASW == 1 || ASW == 0, "fb_offsets: frag_tr's row term assumes a swizzle of the low 3 / 4 row bits");
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_bwd_fused_kernel(AttnArgs p) {
@@ -1912,7 +1906,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_bwd_fused_kerne
   const int qg = wave & 3, kh = NW == 8 ? (wave >> 2) : 0;
   for (int kb = 0; kb < NT_; ++kb) {
     f32x4_t dkt[DF][4], dvt[DF][4];
-    bf16x8_t kT[DF][2];
 #pragma unroll
     for (int df = 0; df < DF; ++df)
 #pragma unroll
@@ -1939,32 +1932,44 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_bwd_fused_kerne
           stage_rows64<ASW, NW>(dob_, p.ld_o, nqt * 64, p.S, nx + TILE_BYTES, wave, lane_s);
         }
       }
-      if (qt == kb) {
-#pragma unroll
-        for (int df = 0; df < DF; ++df)
-#pragma unroll
-          for (int ks2 = 0; ks2 < 2; ++ks2) {
-            union { bf16x8_t v; short4_t hh[2]; } u;
-            u.hh[0] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192);
-            u.hh[1] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192 + 4096);
-            kT[df][ks2] = u.v;
-          }
-      }
       // phase 1: S, dP for 16 queries (group qg) x NKF key fragments
       {
         f32x4_t s[NKF], dp[NKF];
 #pragma unroll
         for (int kk = 0; kk < NKF; ++kk) { s[kk] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kk] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks issue (the compiler's own order waits for every
+        // fragment right in front of its MFMA, and with one workgroup per CU nobody covers that latency)
+        __builtin_amdgcn_sched_barrier(0);
+        // 4 k-steps x NKF key fragments = 4 NKF (S, dP) MFMA pairs; A fragments (q, dO) are held one k-step ahead, the K | V fragments
+        // of MFMA pair j + 1 are requested before pair j issues (32 fragment registers in all -- a full double buffer is 48 and spills)
+        bf16x8_t fa[2][2], fb[2][2];
+        auto lda = [&](int ks, int slot) {
+          fa[slot][0] = *(const bf16x8_t*)(ring + fo.R[ks] + qg * 4096);
+          fa[slot][1] = *(const bf16x8_t*)(ring + fo.R[ks] + TILE_BYTES + qg * 4096);
+        };
+        auto ldb1 = [&](int j, int slot) {          // j = ks * NKF + kk
+          const int ks = j / NKF, kk = j % NKF;
+          fb[slot][0] = *(const bf16x8_t*)(kv + fo.R[ks] + (kh * NKF + kk) * 4096);
+          fb[slot][1] = *(const bf16x8_t*)(kv + fo.R[ks] + TILE_BYTES + (kh * NKF + kk) * 4096);
+        };
+        lda(0, 0);
+        ldb1(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8_t qa = *(const bf16x8_t*)(ring + fo.R[ks] + qg * 4096), da = *(const bf16x8_t*)(ring + fo.R[ks] + TILE_BYTES + qg * 4096);
-#pragma unroll
-          for (int kk = 0; kk < NKF; ++kk) {
-            const int kf = kh * NKF + kk;
-            s[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, *(const bf16x8_t*)(kv + fo.R[ks] + kf * 4096), s[kk], 0, 0, 0);
-            dp[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, *(const bf16x8_t*)(kv + fo.R[ks] + TILE_BYTES + kf * 4096), dp[kk], 0, 0, 0);
-          }
+        for (int j = 0; j < 4 * NKF; ++j) {
+          const int ks = j / NKF, kk = j % NKF;
+          if (kk == 0 && ks + 1 < 4) lda(ks + 1, (ks + 1) & 1);
+          if (j + 1 < 4 * NKF) ldb1(j + 1, (j + 1) & 1);
+          s[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][0], fb[j & 1][0], s[kk], 0, 0, 0);
+          dp[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][1], fb[j & 1][1], dp[kk], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int j = 0; j < 4 * NKF; ++j) {
+          if (j % NKF == 0 && j / NKF + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          if (j + 1 < 4 * NKF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const f32x4_t l4 = *(const f32x4_t*)(smem + FB_STAT + fo.ST + qt * 256);
         const f32x4_t d4 = *(const f32x4_t*)(smem + FB_STAT + FB_MAXT * 256 + fo.ST + qt * 256);
         const int g = lane0 >> 4;
@@ -1981,19 +1986,34 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_bwd_fused_kerne
             pr[r] = pv;
             dsv[r] = pv * (dp[kk][r] - d4[r]);
           }
-          *(u32x2_t*)(smem + FB_PT + fo.W + kf * 2048) = u32x2_t{pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3])};
-          *(u32x2_t*)(smem + FB_DST + fo.W + kf * 2048) = u32x2_t{pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
+          *(u32x2_t*)(smem + FB_PT + fo.W + kf * 16 * FB_PSTR) = u32x2_t{pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3])};
+          *(u32x2_t*)(smem + FB_DST + fo.W + kf * 16 * FB_PSTR) = u32x2_t{pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
         }
       }
       __syncthreads();
       FBT(tp1);
+      bf16x8_t kT[DF][2];                          // K^T fragments of this wave's head-dim slice (A operand of dQ^T): re-read per pair
+#pragma unroll                                     // (8 registers that do not have to live across the key tile), before the next key
+      for (int df = 0; df < DF; ++df)              // tile's copies may overwrite the K tile
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          union { bf16x8_t v; short4_t hh[2]; } u;
+          u.hh[0] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192);
+          u.hh[1] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192 + 4096);
+          kT[df][ks2] = u.v;
+        }
       if (qt == NT_ - 1 && kb + 1 < NT_) {         // last pair of this key tile: its K | V rows are no longer read
+        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): the K^T reads above have landed before the copies overwrite the tile
         stage_rows64<ASW, NW>(kb_, p.ld, (kb + 1) * 64, p.S, smem + FB_KV, wave, lane_s);
         stage_rows64<ASW, NW>(vb_, p.ld, (kb + 1) * 64, p.S, smem + FB_KV + TILE_BYTES, wave, lane_s);
       }
-      // phase 2: this wave's head-dim slice of dV^T, dK^T (key tile kb) and dQ^T (query tile qt)
+      // phase 2: this wave's head-dim slice of dV^T, dK^T (key tile kb) and dQ^T (query tile qt), as a software pipeline over its
+      // 24 B-operand fragments per head-dim fragment: fragment i + PF2 is requested before MFMA i issues
 #pragma unroll
       for (int df = 0; df < DF; ++df) {
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PF2 = 4;
+        bf16x8_t afr[2][2];                      // [ks2][0 = dO^T, 1 = Q^T]
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           union { bf16x8_t v; short4_t hh[2]; } ado, aq;
@@ -2001,26 +2021,42 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_bwd_fused_kerne
           ado.hh[1] = lds_tr16_b64(ring + TILE_BYTES + fo.T[df] + ks2 * 8192 + 4096);
           aq.hh[0] = lds_tr16_b64(ring + fo.T[df] + ks2 * 8192);
           aq.hh[1] = lds_tr16_b64(ring + fo.T[df] + ks2 * 8192 + 4096);
+          afr[ks2][0] = ado.v;
+          afr[ks2][1] = aq.v;
+        }
+        // MFMA i: 0..15 = (ks2 = i >> 3, kf = (i >> 1) & 3, i & 1: 0 -> dV^T (P), 1 -> dK^T (dS)); 16..23 = dQ^T (ks2 = (i - 16) >> 2, qf = i & 3)
+        auto ldb = [&](int i) -> bf16x8_t {
+          if (i < 16) return *(const bf16x8_t*)(smem + ((i & 1) ? FB_DST : FB_PT) + fo.P + ((i >> 1) & 3) * 16 * FB_PSTR + (i >> 3) * 64);
+          const int ks2 = (i - 16) >> 2, qf = i & 3;
+          union { bf16x8_t v; short4_t hh[2]; } bt;
+          bt.hh[0] = lds_tr16_b64(smem + FB_DST + fo.Q4 + (ks2 * 32) * FB_PSTR + (qf >> 1) * 64 + (qf & 1) * 8);
+          bt.hh[1] = lds_tr16_b64(smem + FB_DST + fo.Q4 + (ks2 * 32 + 16) * FB_PSTR + (qf >> 1) * 64 + (qf & 1) * 8);
+          return bt.v;
+        };
+        bf16x8_t rb[PF2];
 #pragma unroll
-          for (int kf = 0; kf < 4; ++kf) {
-            union { bf16x8_t v; u32x2_t hh[2]; } bp, bs;
-            bp.hh[0] = *(const u32x2_t*)(smem + FB_PT + fo.P[ks2][0] + kf * 2048);
-            bp.hh[1] = *(const u32x2_t*)(smem + FB_PT + fo.P[ks2][1] + kf * 2048);
-            bs.hh[0] = *(const u32x2_t*)(smem + FB_DST + fo.P[ks2][0] + kf * 2048);
-            bs.hh[1] = *(const u32x2_t*)(smem + FB_DST + fo.P[ks2][1] + kf * 2048);
-            dvt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado.v, bp.v, dvt[df][kf], 0, 0, 0);
-            dkt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.v, bs.v, dkt[df][kf], 0, 0, 0);
+        for (int i = 0; i < PF2; ++i) rb[i] = ldb(i);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+          const bf16x8_t bfrag = rb[i % PF2];
+          if (i + PF2 < 24) rb[i % PF2] = ldb(i + PF2);
+          if (i < 16) {
+            const int ks2 = i >> 3, kf = (i >> 1) & 3;
+            if (i & 1) dkt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks2][1], bfrag, dkt[df][kf], 0, 0, 0);
+            else dvt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks2][0], bfrag, dvt[df][kf], 0, 0, 0);
+          } else {
+            const int ks2 = (i - 16) >> 2, qf = i & 3;
+            dqt[qt][df][qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[df][ks2], bfrag, dqt[qt][df][qf], 0, 0, 0);
           }
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8 + PF2, 0);          // A fragments (8 transposing reads) + the ring's first fill (16-B reads)
 #pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-          for (int qf = 0; qf < 4; ++qf) {
-            union { bf16x8_t v; short4_t hh[2]; } bt;
-            bt.hh[0] = lds_tr16_b64(smem + FB_DST + fo.Q4[qf] + ks2 * 4096);
-            bt.hh[1] = lds_tr16_b64(smem + FB_DST + fo.Q4[qf] + ks2 * 4096 + 2048);
-            dqt[qt][df][qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[df][ks2], bt.v, dqt[qt][df][qf], 0, 0, 0);
-          }
+        for (int i = 0; i < 24; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i + PF2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one 16-B read
+          else if (i + PF2 < 24) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // two transposing reads
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       FBT(tp2);
       ++n;
