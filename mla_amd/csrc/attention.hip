@@ -1638,12 +1638,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 //   transposed image -> whole-row stores), the same images as the two-kernel form.
 // Reduction orders match the two-kernel form (key tiles ascending for dQ, query tiles ascending for dK / dV, two 32-deep MFMA steps per
 // tile): results are compared bit for bit in tools/exp_attn_bits.py and tests/test_kernels_gpu.py.
-// STATUS (round 5): correct on the first GPU run and bit-identical on all 48 comparison tensors, but 1 212 us against 742 us for the
+// STATUS (round 5): correct on the first GPU run and bit-identical on all 48 comparison tensors, but 1 072 us against 742 us for the
 // two-kernel form at S = 548, B = 32 (8 waves; the 4-wave / 512-register variant spilled 700+ registers and is not instantiated).
-// Per head 640 k cycles (tools/exp_attn_fused_trace.py): prologue 57 k, phase 1 2.5 k x 45 pairs, phase 2 4.65 k x 45 (24 MFMAs behind
-// 64 un-pipelined LDS reads, ~50 cycles per instruction: the [key][q] images are read with bank conflicts and one fragment in
-// flight), key-tile epilogues 14 k x 9, dQ epilogues 8 k x 9 (each ends in stores whose acknowledgement the next vmcnt(0) waits for).
-// With one workgroup per CU nothing hides any of it. Kept opt-in (MLA_ATTN_BWD_FUSED=8) as the starting point for the next round.
+// Per head 518 k cycles (tools/exp_attn_fused_trace.py; first version 640 k): prologue 52 k, phase 1 2.1 k x 45 pairs (was 2.5 k),
+// phase 2 2.7 k x 45 (was 4.65 k: padded-stride [key][q] images read conflict-free with one 16-B read per fragment, 4 fragments in
+// flight), 1.7 k per pair outside the two phases (barriers, staging-copy issue, the scratch reload of dQ tiles 6-8), key-tile
+// epilogues 10.7 k x 9, dQ epilogues 8.4 k x 9. What is left is structural: all 8 waves are in the same phase at the same time, so the
+// two waves of a SIMD never put MFMA work next to LDS / VALU work; per pair the LDS reads alone are ~1.7 k cycles of the CU's 256 B/clk
+// against 1.3 k cycles of MFMA, and prologue + epilogues (224 k cycles of latency chains with nobody to cover them) are as large as the
+// whole pair loop. Beating 742 us needs both halved -- two wave groups in opposite phases (double-buffered P / dS images, LDS flags
+// instead of the single workgroup barrier) and the three outputs of a key tile leaving through one epilogue with the RoPE rows fetched
+// a pair earlier. Kept opt-in (MLA_ATTN_BWD_FUSED=8) as the starting point for that.
 constexpr int FB_MAXT = 9;
 constexpr int FB_KV = 4 * TILE_BYTES;            // K tile, V tile
 constexpr int FB_PSTR = 144;                     // bytes per key row of the P / dS images: 64 q x 2 B + 16 B of padding (a 128-B pitch
