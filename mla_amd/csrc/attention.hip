@@ -13,6 +13,9 @@
 // K/V (or Q/dO) tiles of 64 rows are staged with global_load_lds_dwordx4 into a double-buffered, source-swizzled
 // LDS image. One block = 4 waves x 16 rows.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 // staging copies are issued untracked (see glds16_untracked): every loop orders them itself with `s_waitcnt vmcnt(0)` + barrier
 #ifndef MLA_ATTN_GLDS_ASM
 #define MLA_ATTN_GLDS_ASM 1
@@ -932,16 +935,29 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
     }
 }
 
-template <int RB, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(AttnArgs p) {   // 2nd argument = waves per SIMD
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// ---- merged launch (round 5): the dQ blocks of a head publish "delta is in memory" through a per-head counter, the dK / dV blocks of
+// the same head -- later workgroup ids of the SAME launch, on the same XCD -- wait for it. delta itself travels through agent-scope
+// atomic stores / loads (write-through, L1-bypassing), the counter is bumped once per wave after the wave's stores are acknowledged.
+__device__ __forceinline__ void bwd_publish(int* ready, int lane) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's delta stores have been performed
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void bwd_wait_ready(int* ready, int target) {
+  int spins = 0;
+  while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1 << 22)) __builtin_trap();     // seconds: the producers have lower workgroup ids and never wait -- a hang here is a bug
+  }
+  asm volatile("" ::: "memory");
+}
+
+// qb = row block counted from the END of the sequence's blocks already resolved by the caller (heaviest first)
+template <int RB, int NW, bool MERGED>
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs p, char* smem, int qb, int h, int b, int* ready) {
   constexpr int BQ = 16 * NW * RB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nqb = (p.S + BQ - 1) / BQ;
-  int qb, h, b;
-  if (!decode_block(nqb, p.H, p.B, qb, h, b)) return;
-  qb = nqb - 1 - qb;                               // heaviest (most key tiles) first
   const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
   const int row_lim = seqlen < p.S ? seqlen : p.S;
   const int q0 = qb * BQ - (((BQ - p.S % BQ) % BQ) & ~63);      // row blocks shifted towards the end of the sequence, see the forward kernel
@@ -961,6 +977,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   if (nkt > kt_lim) nkt = kt_lim;
   if (nkt <= 0 || q0 >= row_lim) {
     dq_pad_block<RB>(p, myq, b, h, lane);
+    if (MERGED) bwd_publish(ready, lane);          // (its rows are >= row_lim: no dK / dV block reads their delta)
     return;
   }
   BT(0, 0);
@@ -1037,7 +1054,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
           for (int j = 0; j < 4; ++j) acc += bflo(a.w[j]) * bflo(d.w[j]) + bfhi(a.w[j]) * bfhi(d.w[j]);
         }
         dlt[rb] = group_sum(acc);
-        if (g == 0 && myq[rb] >= 0 && myq[rb] < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myq[rb]] = dlt[rb];
+        if (g == 0 && myq[rb] >= 0 && myq[rb] < p.S) {
+          float* dst = (float*)p.delta + ((long long)b * p.H + h) * p.S + myq[rb];
+          if (MERGED) __hip_atomic_store(dst, dlt[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dst = dlt[rb];
+        }
       } else {
         dlt[rb] = dlt_raw[rb];
       }
@@ -1065,6 +1086,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
         }
       }
       __syncthreads();
+      if (MERGED) bwd_publish(ready, lane);          // the delta stores have had the image writes + a barrier to be acknowledged
       constexpr int NT = 64 * NW;
       const int j = threadIdx.x & 31;                       // 8-B chunk = queries q0 + 4 j .. + 3 (q0 and S are multiples of 4)
       const bool jv = q0 + j * 4 >= 0 && q0 + j * 4 < p.S;
@@ -1074,6 +1096,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
         const int c = ps * (NT / 32) + (threadIdx.x >> 5);
         if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + c * 256 + ((j ^ ((c & 7) << 2)) * 8));
       }
+    } else if (MERGED) {
+      bwd_publish(ready, lane);
     }
   }
   const float sc2 = p.scale * LOG2E;
@@ -1110,6 +1134,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   BT(0, 3);
   dq_epilogue<RB, NW>(p, smem, dqt, myq, padq, b, h, q0, wave, lane);
   BT(0, 5);
+}
+
+template <int RB, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(AttnArgs p) {   // 2nd argument = waves per SIMD
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nqb = (p.S + 16 * NW * RB - 1) / (16 * NW * RB);
+  int qb, h, b;
+  if (!decode_block(nqb, p.H, p.B, qb, h, b)) return;
+  attn_bwd_dq_body<RB, NW, false>(p, smem, nqb - 1 - qb /* heaviest (most key tiles) first */, h, b, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ 5-product backward (round 3)
@@ -1322,14 +1355,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq5_kernel(AttnArgs p) {
 #ifndef MLA_ATTN_DKV_PF
 #define MLA_ATTN_DKV_PF 6        // transposed fragments in flight in the dV^T / dK^T phase (0 = compiler order, one in flight)
 #endif
-template <bool STORE_DS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 tiles + 2 x (64 lse + 64 delta) floats
+template <bool STORE_DS, bool MERGED>
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /* 4 tiles + 2 x (64 lse + 64 delta) floats */, int kb, int h, int b,
+                                                  int* ready, int ready_target) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nkb = (p.S + 63) / 64;
-  int kb, h, b;
-  if (!decode_block(nkb, p.H, p.B, kb, h, b)) return;
   const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
   const int mykey = kb * 64 + wave * 16 + (lane & 15);
   const int g = lane >> 4;
@@ -1363,6 +1394,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   auto load_stat = [&](int qt) -> float {
     const int qi = qt * 64 + (threadIdx.x & 63);
     if (threadIdx.x < 64) return (qi < qend) ? lse_p[qi] * LOG2E : INFINITY;
+    if (MERGED) return (qi < qend) ? __hip_atomic_load((float*)dl_p + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     return (qi < qend) ? dl_p[qi] : 0.f;
   };
   float nstat = 0.f;
@@ -1374,6 +1406,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     stage_rows64<ASW>(dob_, p.ld_o, qt0 * 64, p.S, smem + TILE_BYTES, wave, lane);
     stage_rows64<ASW>(p.k + (long long)b * p.S * p.ld + h * D, p.ld, kb * 64, p.S, smem + 2 * TILE_BYTES, wave, lane);
     stage_rows64<ASW>(p.v + (long long)b * p.S * p.ld + h * D, p.ld, kb * 64, p.S, smem + 3 * TILE_BYTES, wave, lane);
+    // merged launch: wave 1 (the delta lanes) waits until every dQ block of this head has published -- under the copies just issued
+    if (MERGED && threadIdx.x >= 64 && threadIdx.x < 128) bwd_wait_ready(ready, ready_target);
     if (threadIdx.x < 128) nstat = load_stat(qt0);
     ATTN_WAIT_VM0();
     __syncthreads();
@@ -1621,6 +1655,59 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
   (void)nkb;
   BT(1, 5);
+}
+
+template <bool STORE_DS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int kb, h, b;
+  if (!decode_block((p.S + 63) / 64, p.H, p.B, kb, h, b)) return;
+  attn_bwd_dkv_body<STORE_DS, false>(p, smem, kb, h, b, nullptr, 0);
+}
+
+// ONE launch for both backward kernels (round 5; default MLA_ATTN_BWD_MERGED=105 = lag 5 + interleaved order, 0 = two launches): per XCD
+// the workgroup ids walk
+//   dQ(head 0) .. dQ(head lag - 1) | dQ(head j + lag), dK.dV(head j) for j = 0 .. | dK.dV of the last lag heads
+// (dQ(h) = its nqb row blocks heaviest first, dK.dV(h) = its nkb key blocks heaviest first). What it is for: (1) one ramp-up and one
+// drain instead of two -- per-sample backward time falls from 23.1 to 21.6 us between B = 32 and B = 64, i.e. ~7 % of a B = 32 launch
+// pair is fixed cost; (2) the second read of q, k, v, dO (0.57 GB of the pair's 2.46 GB per layer) comes ~20 k cycles after the first,
+// from the same XCD's L2; (3) both block types share a CU. The dK / dV blocks need delta = rowsum(O o dO), which the dQ blocks of the
+// same head form in their prologue: producers have LOWER workgroup ids on the same XCD (dispatched earlier, never waiting on anything),
+// so a consumer that spins on the head's counter cannot starve them; `lag` heads of distance make the wait a formality.
+// Same block bodies, same arithmetic: bit-identical to the two-launch form.
+__global__ __launch_bounds__(256, 2) void attn_bwd_merged_kernel(AttnArgs p, int* ready, int ready_target, int lag, int interleave) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BQ = 16 * DQ_NW * DQ_RB;
+  const int nqb = (p.S + BQ - 1) / BQ, nkb = (p.S + 63) / 64, per = nqb + nkb;
+  const int n = (p.H * p.B + 7) / 8;                 // heads per XCD (grid padded to a multiple of 8 heads)
+  const int L = blockIdx.x, xcd = L & 7;
+  int idx = L >> 3, j, blk;
+  bool is_dq;
+  if (lag > n) lag = n;
+  if (idx < lag * nqb) { is_dq = true; j = idx / nqb; blk = idx % nqb; }
+  else {
+    idx -= lag * nqb;
+    const int jj = idx / per, r = idx % per;
+    if (jj < n - lag) {
+      if (interleave) {                              // the nqb dQ blocks spread evenly between the nkb dK.dV blocks (each type still heaviest first)
+        const int a0 = (r * nqb) / per, a1 = ((r + 1) * nqb) / per;
+        is_dq = a1 > a0;
+        blk = is_dq ? a0 : r - a0;
+      } else {
+        is_dq = r < nqb;
+        blk = is_dq ? r : r - nqb;
+      }
+      j = is_dq ? jj + lag : jj;
+    } else {
+      idx -= (n - lag) * per;
+      is_dq = false; j = n - lag + idx / nkb; blk = idx % nkb;
+    }
+  }
+  const int group = j * 8 + xcd;
+  if (group >= p.H * p.B) return;
+  const int h = group % p.H, b = group / p.H;
+  if (is_dq) attn_bwd_dq_body<DQ_RB, DQ_NW, true>(p, smem, nqb - 1 - blk, h, b, ready + group);
+  else attn_bwd_dkv_body<false, true>(p, smem, blk, h, b, ready + group, ready_target);
 }
 
 // ------------------------------------------------------------------------------------------------ fused backward (round 5 experiment)
@@ -2130,6 +2217,36 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 // delta: workspace [B,H,S] fp32 (caller-allocated)
+// Per-stream head counters of the merged backward launch (grown on demand, never freed: a few KiB per stream). Every launch adds
+// exactly `per_head` to each of the first `groups` (= B * H) counters, so in steady state (same head count and blocks per head as the
+// previous launch on this stream) the wait target just advances by per_head and nothing has to be cleared; any change, or a counter
+// near overflow, clears the buffer first.
+struct BwdReady { int* buf = nullptr; int cap = 0, groups = -1, per_head = -1, epoch = 0; };
+static int* bwd_ready_buffer(hipStream_t stream, int groups, int per_head, int* target) {
+  static std::mutex mu;
+  static std::map<hipStream_t, BwdReady> bufs;
+  std::lock_guard<std::mutex> lk(mu);
+  BwdReady& e = bufs[stream];
+  if (groups < 0) { e.groups = -1; return nullptr; }   // invalidate (a launch failed after the epoch was advanced)
+  if (e.cap < groups + 8) {
+    int* nb = nullptr;
+    const int cap = groups + 8 < 4096 ? 4096 : groups + 8;
+    if (hipMalloc(&nb, (size_t)cap * sizeof(int)) != hipSuccess) return nullptr;
+    e.buf = nb;        // (an outgrown buffer may still be read by a queued launch: it is left allocated)
+    e.cap = cap;
+    e.groups = -1;
+  }
+  if (e.groups != groups || e.per_head != per_head || e.epoch >= (1 << 24)) {
+    if (hipMemsetAsync(e.buf, 0, (size_t)e.cap * sizeof(int), stream) != hipSuccess) return nullptr;
+    e.groups = groups;
+    e.per_head = per_head;
+    e.epoch = 0;
+  }
+  ++e.epoch;
+  *target = e.epoch * per_head;
+  return e.buf;
+}
+
 static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                          const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
                          int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
@@ -2171,6 +2288,29 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
       fattr = true;
     }
     hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(B * H), dim3(512), FB_LDS, stream, p);
+    MLA_LAUNCH_CHECK();
+  }
+  // Both backward kernels as ONE launch (attn_bwd_merged_kernel): MLA_ATTN_BWD_MERGED = lag + 100 * interleave, default 105; 0 = the
+  // two-launch form (bit-identical). Measured per layer: 742 -> 703 us at S = 548, 1 310 -> 1 258 us at S = 2048 / B = 8.
+  static const int merged = getenv("MLA_ATTN_BWD_MERGED") ? atoi(getenv("MLA_ATTN_BWD_MERGED")) : 105;
+  if (!ws && merged > 0) {
+    constexpr int BQm = 16 * DQ_NW * DQ_RB;
+    static_assert(DQ_NW == 4, "the merged launch runs both block types with 256 threads");
+    static bool mattr = false;
+    if (!mattr) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_merged_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024 + 32768);
+      mattr = true;
+    }
+    const int groups = ((H * B + 7) / 8) * 8;
+    const int nqb_m = (S + BQm - 1) / BQm;
+    int target = 0;
+    int* ready = bwd_ready_buffer(stream, H * B, nqb_m * DQ_NW, &target);   // keyed on the REAL head count: padding groups never publish
+    MLA_CHECK_ARG(ready != nullptr, "mla_attn_bwd: could not set up the merged launch's %d head counters", groups);
+    const int per = nqb_m + (S + 63) / 64;
+    static const int lds_extra_m = getenv("MLA_ATTN_BWD_LDS_EXTRA") ? (atoi(getenv("MLA_ATTN_BWD_LDS_EXTRA")) > 0 ? 32768 : 0) : 0;
+    hipLaunchKernelGGL(attn_bwd_merged_kernel, dim3(groups * per), dim3(256), 4 * TILE_BYTES + 1024 + lds_extra_m, stream, p, ready, target,
+                       merged % 100, merged / 100);
+    if (hipPeekAtLastError() != hipSuccess) (void)bwd_ready_buffer(stream, -1, 0, &target);   // the counters did not advance: clear them next time
     MLA_LAUNCH_CHECK();
   }
   if (ws) {

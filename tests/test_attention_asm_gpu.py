@@ -71,10 +71,73 @@ def test_fused_backward_is_bit_identical_to_the_two_kernel_form(dev, tmp_path):
     the reduction orders are the same by construction, so the comparison is bit for bit. Shapes above 576 fall back to the two-kernel form."""
     a, b = str(tmp_path / "two.pt"), str(tmp_path / "fused.pt")
     tool = os.path.join("tools", "exp_attn_bits.py")
-    r0 = _child({"MLA_ATTN_BWD_FUSED": "0"}, [tool, a], timeout=600)
+    r0 = _child({"MLA_ATTN_BWD_FUSED": "0", "MLA_ATTN_BWD_MERGED": "0"}, [tool, a], timeout=600)
     r1 = _child({"MLA_ATTN_BWD_FUSED": "8"}, [tool, b], timeout=600)
     assert r0.returncode == 0 and r1.returncode == 0, (r0.stderr[-500:], r1.stderr[-500:])
     x, y = torch.load(a), torch.load(b)
     assert x.keys() == y.keys() and len(x) >= 40
     bad = [k for k in x if not torch.equal(x[k], y[k])]
     assert not bad, bad
+
+
+def test_merged_backward_launch_is_bit_identical_to_two_launches(dev, tmp_path):
+    """The default backward is ONE launch (attn_bwd_merged_kernel: the dQ blocks of a head publish delta through a per-head counter, the
+    dK / dV blocks of the same head -- later workgroup ids on the same XCD -- wait for it) running the same block bodies as the two-launch
+    form (MLA_ATTN_BWD_MERGED=0). Compared bit for bit on every tensor tools/exp_attn_bits.py dumps (full / ragged / padding-only
+    shapes, RoPE-fused and transposed outputs; many launches of changing shape per process, which also drives the counters' epoch /
+    clear logic), for the default order, for lag 1 (the consumers really do spin) and for the non-interleaved order."""
+    tool = os.path.join("tools", "exp_attn_bits.py")
+    ref = str(tmp_path / "two.pt")
+    r0 = _child({"MLA_ATTN_BWD_MERGED": "0"}, [tool, ref], timeout=600)
+    assert r0.returncode == 0, r0.stderr[-500:]
+    x = torch.load(ref)
+    assert len(x) >= 40
+    for tag, env in (("default", {}), ("lag1", {"MLA_ATTN_BWD_MERGED": "1"}), ("lag3_plain", {"MLA_ATTN_BWD_MERGED": "3"})):
+        out = str(tmp_path / f"{tag}.pt")
+        r = _child(env, [tool, out], timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-500:])
+        y = torch.load(out)
+        assert x.keys() == y.keys()
+        bad = [k for k in x if not torch.equal(x[k], y[k])]
+        assert not bad, (tag, bad)
+
+
+SEQ = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from mla_amd import hip
+dev = torch.device("cuda:0")
+out = {}
+D = 128
+# same padded head-group count with different real head counts, repeats of one shape, shrinking and growing shapes, ragged rows
+shapes = [(2, 64, 2, None), (2, 100, 2, None), (2, 100, 3, [70, 100]), (2, 100, 3, [70, 100]), (1, 100, 3, None), (2, 100, 3, None),
+          (4, 200, 8, [200, 1, 0, 137]), (1, 548, 2, None), (1, 548, 2, None), (5, 132, 7, None), (2, 100, 3, [100, 3]), (1, 1100, 9, None)]
+for i, (B, S, H, lens) in enumerate(shapes):
+    g = torch.Generator().manual_seed(100 + i)
+    qkv = (torch.randn(B * S, 3 * H * D, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    do = torch.randn(B * S, H * D, generator=g).to(torch.bfloat16).to(dev)
+    sl = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, sl, D ** -0.5)
+    dqkv = torch.full_like(qkv, float("nan"))
+    hip.attn_bwd(q, k, v, o, do, lse, sl, dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:], B, S, H, D, 3 * H * D, D ** -0.5)
+    out[f"{i}_{B}_{S}_{H}"] = dqkv.cpu()
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_merged_launch_counters_survive_shape_changes(dev, tmp_path):
+    """The merged launch's per-head counters advance by a fixed amount per launch and are only cleared when the head count or the blocks
+    per head change: a sequence of launches whose PADDED head-group count stays the same while the real head count changes (the case that
+    left two heads' counters behind in the first version: the consumers of those heads spun until the watchdog trap), repeats, shrinking
+    and growing shapes, ragged and empty rows -- every gradient finite and bit-identical to the two-launch form."""
+    outs = {}
+    for tag, env in (("two", {"MLA_ATTN_BWD_MERGED": "0"}), ("merged", {})):
+        f = tmp_path / f"{tag}.pt"
+        r = _child(env, ["-c", SEQ, str(f), ROOT], timeout=600)
+        assert r.returncode == 0, (tag, r.stdout[-500:] + r.stderr[-1500:])
+        outs[tag] = torch.load(f)
+    assert outs["two"].keys() == outs["merged"].keys()
+    for key, a in outs["two"].items():
+        assert torch.isfinite(a.float()).all(), key
+        assert torch.equal(a, outs["merged"][key]), key
