@@ -11,7 +11,7 @@ def load(d):
     per = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        fam = next((k for k in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_delta") if k in n), None)
+        fam = next((k for k in ("attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_bwd_merged", "attn_delta") if k in n), None)
         if fam is None: continue
         d_ = per[fam][r["Dispatch_Id"]]
         d_[r["Counter_Name"]] = d_.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])

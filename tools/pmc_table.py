@@ -14,7 +14,7 @@ FAMILIES = [("gemm256<0,0,0> plain (>= 150 us)", r"gemm256_kernel<0, ?0, ?0(, ?(
             ("gemm256<0,0,1> gate|up+SwiGLU", r"gemm256_kernel<0, ?0, ?1(, ?(true|false))?>", 150.0),
             ("gemm256<0,0,2> dact+SwiGLU bwd", r"gemm256_kernel<0, ?0, ?2(, ?(true|false))?>", 150.0),
             ("attn_fwd", r"attn_fwd_kernel", 50.0), ("attn_bwd_dq", r"attn_bwd_dq_kernel", 50.0), ("attn_bwd_dkv", r"attn_bwd_dkv_kernel", 50.0),
-            ("attn_bwd (one pass)", r"attn_bwd_kernel", 50.0),
+            ("attn_bwd (one pass)", r"attn_bwd_kernel", 50.0), ("attn_bwd merged launch (dQ + dK.dV blocks)", r"attn_bwd_merged_kernel", 50.0),
             ("adamw", r"adamw_vec4_kernel", 50.0), ("rmsnorm_bwd", r"rmsnorm_bwd_kernel", 20.0), ("tile_transpose", r"tile_transpose_kernel", 10.0)]
 
 

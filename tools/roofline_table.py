@@ -17,10 +17,12 @@ ROWS = [   # (substring of the kernel symbol, label, bound, work per STEP, note)
     ("attn_bwd_dq_kernel", "attention backward: dQ kernel", "mfma", 2.5 * ATT * L * 3 / 7, "3 of the 7 executed products (algorithmic bwd = 2.5 x fwd over both kernels)"),
     ("attn_bwd_dkv_kernel", "attention backward: dK/dV kernel", "mfma", 2.5 * ATT * L * 4 / 7, "4 of the 7 executed products"),
     ("attn_bwd_kernel", "attention backward (one pass)", "mfma", 2.5 * ATT * L, "5 products"),
+    ("attn_bwd_merged_kernel", "attention backward (dQ + dK.dV, 1 launch)", "mfma", 2.5 * ATT * L, "algorithmic 5 products (7 executed), both block types in one launch (round 5)"),
     # round 5: at S = 548 the backward pair is nearer its HBM roof than its MFMA one -- algorithmic bytes of the TWO-kernel form, per layer:
     # dQ reads q, k, v, dO, o and writes dq, dq^T, o^T (8 x T x H x 2 B); dK dV reads q, k, v, dO and writes dk, dv, dk^T, dv^T (8 x ...)
     ("attn_bwd_dq_kernel#hbm", "  same kernel against the HBM roof", "hbm", 8.0 * T * H * 2 * L, "q k v dO o read once, dq dq^T o^T written (two-kernel form)"),
     ("attn_bwd_dkv_kernel#hbm", "  same kernel against the HBM roof", "hbm", 8.0 * T * H * 2 * L, "q k v dO read once, dk dv dk^T dv^T written"),
+    ("attn_bwd_merged_kernel#hbm", "  same kernel against the HBM roof", "hbm", 12.0 * T * H * 2 * L, "q k v dO o read ONCE, dq dk dv + 4 transposed operands written (the two-launch form's own minimum is 16 x)"),
     ("adamw_vec4_kernel", "fused AdamW (+ bf16 copy)", "hbm", 30.0 * PARAMS, "30 B / parameter: p, m, v read+write, g read, bf16 write"),
     ("tile_transpose_kernelINS_6CopyOp", "tile transposes (W^T, dy^T)", "hbm", (4.0 * (3 * I * H + 4 * H * H) + 8.0 * T * H) * L, "read + write, 2 B each"),
     ("tile_transpose_kernelINS_10RmsApplyOp", "RMSNorm re-apply, transposed out", "hbm", 4.0 * T * H * 2 * L, "read h, write xn^T"),
