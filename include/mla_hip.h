@@ -170,7 +170,12 @@ int mla_q_sample(const float* x0, const float* noise, const long long* t, const 
 int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B, int S, int H,
                  int head_dim, long long ld_qkv, long long ld_o, float scale, mla_stream_t stream);
 /* rope_cos / rope_sin ([S, 64] fp32, both or neither): when given, dq and dk are written with the backward of apply_rotary_pos_emb
- * (modeling_llama.py:184-208) already applied -- the same values mla_rope_inplace(backward = 1) would produce on them afterwards */
+ * (modeling_llama.py:184-208) already applied -- the same values mla_rope_inplace(backward = 1) would produce on them afterwards.
+ * Launch form (mla_attn_bwd and mla_attn_bwd_t; results are bit-identical either way): by default ONE launch runs the dQ and the
+ * dK / dV blocks, which hand delta over through B * H integer counters owned by the library -- 16 KiB allocated with hipMalloc on the
+ * FIRST call per stream (the one place this entry point is not launch-only: make that call outside a stream capture) and cleared on
+ * the stream whenever B * H or S changes. Concurrent calls must use different streams. MLA_ATTN_BWD_MERGED=0 selects two launches and
+ * touches no library-owned memory. `delta` is written by the call and only meaningful after it has completed. */
 int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
                  void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
                  float scale, const float* rope_cos, const float* rope_sin, mla_stream_t stream);
