@@ -34,6 +34,10 @@ int mla_query(int what); /* 0: ABI version, 1: compiled gfx arch (950), 2: wavef
 const char* mla_gemm_source_id(void);
 /* hardware-assumption self test (ds_read_b64_tr_b16 lane map, global_load_lds destination order) */
 int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_1k, mla_stream_t stream);
+/* dispatch probe for the one-launch attention backward (mla_attn_bwd with head_sync): `blocks` workgroups of that kernel's shape each
+ * take a start ticket from out[0] (caller zeroes `out`, 1 + 2 * blocks ints), stay resident ~hold_us, and record out[1 + 2 L] = ticket,
+ * out[2 + 2 L] = HW_REG_XCC_ID of workgroup L. The caller decides: 8 XCDs, XCC_ID == L & 7, start order == id order per XCD. */
+int mla_dispatch_probe(int* out, int blocks, int hold_us, mla_stream_t stream);
 
 /* ---- GEMM: every nn.Linear forward / dgrad / wgrad on the path --------------------------------------------------
  * transformers/models/llama/modeling_llama.py:240 (gate/up/down), :351-353 (q/k/v), :390 (o_proj), :1254 (lm_head);
@@ -171,22 +175,30 @@ int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
                  int head_dim, long long ld_qkv, long long ld_o, float scale, mla_stream_t stream);
 /* rope_cos / rope_sin ([S, 64] fp32, both or neither): when given, dq and dk are written with the backward of apply_rotary_pos_emb
  * (modeling_llama.py:184-208) already applied -- the same values mla_rope_inplace(backward = 1) would produce on them afterwards.
- * Launch form (mla_attn_bwd and mla_attn_bwd_t; results are bit-identical either way): by default ONE launch runs the dQ and the
- * dK / dV blocks, which hand delta over through B * H integer counters owned by the library -- 16 KiB allocated with hipMalloc on the
- * FIRST call per stream (the one place this entry point is not launch-only: make that call outside a stream capture) and cleared on
- * the stream whenever B * H or S changes. Concurrent calls must use different streams. MLA_ATTN_BWD_MERGED=0 selects two launches and
- * touches no library-owned memory. `delta` is written by the call and only meaningful after it has completed. */
+ * Launch form (mla_attn_bwd and mla_attn_bwd_t; results are bit-identical either way): with head_sync == NULL the dQ kernel and the
+ * dK / dV kernel are two launches. With head_sync given, ONE launch runs both block types and the dQ blocks hand delta to the dK / dV
+ * blocks of their head through two integer counters per head IN THE CALLER'S BUFFER: head_sync = mla_attn_bwd_sync_ints(B, H) ints
+ * (4-B aligned), zero before the first call; every launch leaves it zero again (the last consumer of a head resets its pair), so one
+ * buffer serves any sequence of shapes on a stream and a captured launch replays correctly. One buffer per stream in flight. The
+ * library allocates nothing and keeps nothing. The one-launch form assumes workgroup id L runs on XCD L & 7 and that workgroups
+ * start in id order per XCD (mla_dispatch_probe measures both; mla_amd/hip.py passes head_sync only on a device where they hold); a
+ * wait that lasts 30 s of wall clock traps. MLA_ATTN_BWD_MERGED=0 forces two launches whatever is passed.
+ * `delta` is written by the call and only meaningful after it has completed. */
+long long mla_attn_bwd_sync_ints(int B, int H);
 int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
                  void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
-                 float scale, const float* rope_cos, const float* rope_sin, mla_stream_t stream);
+                 float scale, const float* rope_cos, const float* rope_sin, int* head_sync, long long head_sync_ints,
+                 mla_stream_t stream);
 /* mla_attn_bwd + token-contiguous copies dqT / dkT / dvT / oT [H * head_dim, ldt] (column = b * S + s; columns >= B * S untouched)
  * of dq / dk / dv / o: the k-contiguous operands of the q|k|v and o projection wgrad GEMMs (autograd of modeling_llama.py:371-380),
  * written from the registers that hold the rows instead of by four transpose passes. All four or none; S % 4 == 0, ldt % 4 == 0. */
 int mla_attn_bwd_t(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
                    void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
                    float scale, const float* rope_cos, const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT,
-                   long long ldt, mla_stream_t stream);
-/* Five-product form of the backward (opt-in in mla_amd: measured no faster than the seven-product pair on MI355X):
+                   long long ldt, int* head_sync, long long head_sync_ints, mla_stream_t stream);
+/* Five-product form of the backward -- an EXPERIMENT kernel (measured no faster than the seven-product pair on MI355X):
+ * compiled only into the experiment build (build.sh MLA_EXPERIMENTAL=1, mla_query(3) == 1); the product library exports the symbol
+ * and rejects the call with a negative code.
  * the dK / dV kernel hands dS^T to a one-product dQ kernel through the
  * caller-owned workspace `ws` (mla_attn_bwd_ws_bytes(B, S, H) bytes, 16-B aligned) instead of both kernels recomputing Q K^T and
  * dO V^T; delta = rowsum(O o dO) is its own pass. Same outputs and argument meaning as mla_attn_bwd_t (dqT / dkT / dvT / oT: all or

@@ -64,3 +64,34 @@ extern "C" int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 8192, stream, (const uint32_t*)src_1k, out_tr_256, (uint32_t*)out_glds_1k);
   MLA_LAUNCH_CHECK();
 }
+
+// ---- dispatch probe (round 6): the two things attn_bwd_merged_kernel assumes about the hardware queue and HIP does not promise --
+//   (1) workgroup id L runs on XCD L & 7 (its per-head counters and the L2 reuse of q, k, v, dO are laid out for that), 8 XCDs;
+//   (2) workgroups start in id order per XCD: a consumer of a head (higher id) never holds a CU slot while one of its producers (lower
+//       id, same XCD) has not been given one -- the condition under which its wait cannot dead-lock.
+// `blocks` workgroups shaped like that kernel's (256 threads, 2 per CU by LDS) each take a ticket from out[0] when they start, stay
+// resident for ~hold_us (so the grid needs many dispatch rounds), and record out[1 + 2 L] = ticket, out[2 + 2 L] = XCC_ID. The caller
+// (mla_amd/hip.py: dispatch_probe) checks (1) literally and (2) as "no workgroup started more than one residency round (64 slots per
+// XCD) out of id order", and hands head counters to mla_attn_bwd only on a device where both hold -- the two-launch form otherwise.
+__global__ __launch_bounds__(256, 2) void dispatch_probe_kernel(int* __restrict__ out, int hold_ticks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  (void)smem;
+  if (threadIdx.x == 0) {
+    const int ticket = __hip_atomic_fetch_add(out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)hold_ticks) __builtin_amdgcn_s_sleep(16);
+    out[1 + 2 * blockIdx.x] = ticket;
+    out[2 + 2 * blockIdx.x] = xcc & 15;
+  }
+}
+
+extern "C" int mla_dispatch_probe(int* out, int blocks, int hold_us, hipStream_t stream) {
+  MLA_CHECK_ARG(out && blocks > 0 && blocks <= (1 << 20) && hold_us >= 0 && hold_us <= 10000, "mla_dispatch_probe: null pointer or bad shape");
+  static bool attr = false;
+  constexpr int LDS = 80 * 1024;                    // two workgroups per CU, like the attention backward
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dispatch_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+  hipLaunchKernelGGL(dispatch_probe_kernel, dim3(blocks), dim3(256), LDS, stream, out, hold_us * 100);   // s_memrealtime: 100 MHz
+  MLA_LAUNCH_CHECK();
+}

@@ -13,8 +13,6 @@
 // K/V (or Q/dO) tiles of 64 rows are staged with global_load_lds_dwordx4 into a double-buffered, source-swizzled
 // LDS image. One block = 4 waves x 16 rows.
 #include "common.h"
-#include <map>
-#include <mutex>
 #include <utility>
 // staging copies are issued untracked (see glds16_untracked): every loop orders them itself with `s_waitcnt vmcnt(0)` + barrier
 #ifndef MLA_ATTN_GLDS_ASM
@@ -935,21 +933,43 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
     }
 }
 
-// ---- merged launch (round 5): the dQ blocks of a head publish "delta is in memory" through a per-head counter, the dK / dV blocks of
-// the same head -- later workgroup ids of the SAME launch, on the same XCD -- wait for it. delta itself travels through agent-scope
-// atomic stores / loads (write-through, L1-bypassing), the counter is bumped once per wave after the wave's stores are acknowledged.
+// ---- merged launch (round 5; hand-off reworked in round 6): the dQ blocks of a head publish "delta is in memory" through a per-head
+// counter, the dK / dV blocks of the same head -- later workgroup ids of the SAME launch, on the same XCD -- wait for it. delta itself
+// travels through agent-scope atomic stores / loads (write-through, L1-bypassing), the counter is bumped once per wave after the wave's
+// stores are acknowledged. The counters are CALLER-OWNED (mla_attn_bwd's head_sync: 2 ints per head, zero before the first launch) and
+// the hand-off is SELF-RESETTING: every dK / dV block of a head waits for `target` = all producer waves of that head, then bumps the
+// head's second counter; the last of the head's nkb consumers stores 0 to both. So a launch finds zeros and leaves zeros -- no epoch,
+// no host-side state, nothing to clear between launches or shapes, and a captured launch replays correctly.
 __device__ __forceinline__ void bwd_publish(int* ready, int lane) {
   __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's delta stores have been performed
   asm volatile("" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Watchdog: the wait is bounded by the constant 100 MHz clock, not by a spin count -- MLA_ATTN_WATCHDOG_S seconds (default 30) is far
+// beyond any slow-producer case (debugger, serialising profiler, CUs shared with RCCL's kernels) and only a genuine dead-lock (the
+// dispatch-order assumption of attn_bwd_merged_kernel violated: hip.py probes it once per device and never selects the merged form
+// when the probe fails) ends in a trap instead of a hung queue.
+#ifndef MLA_ATTN_WATCHDOG_S
+#define MLA_ATTN_WATCHDOG_S 30
+#endif
 __device__ __forceinline__ void bwd_wait_ready(int* ready, int target) {
-  int spins = 0;
-  while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(8);
-    if (++spins > (1 << 22)) __builtin_trap();     // seconds: the producers have lower workgroup ids and never wait -- a hang here is a bug
+  if (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull * MLA_ATTN_WATCHDOG_S) __builtin_trap();
+    }
   }
   asm volatile("" ::: "memory");
+}
+// one lane per consumer block, after its wave has passed bwd_wait_ready: the head's last consumer returns both counters to zero
+// (every other consumer has passed its wait, every producer has published: nobody reads or bumps them again in this launch)
+__device__ __forceinline__ void bwd_consumer_done(int* ready, int* done, int nkb) {
+  const int old = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old == nkb - 1) {
+    __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // qb = row block counted from the END of the sequence's blocks already resolved by the caller (heaviest first)
@@ -1145,206 +1165,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_bwd_dq_kernel(A
   attn_bwd_dq_body<RB, NW, false>(p, smem, nqb - 1 - qb /* heaviest (most key tiles) first */, h, b, nullptr);
 }
 
-// ------------------------------------------------------------------------------------------------ 5-product backward (round 3)
-// The two-kernel backward above computes S = Q K^T and dP = dO V^T twice (dQ kernel: S, dP, dQ; dK / dV kernel: S, dP, dV, dK = 7 matrix
-// products). Here the dK / dV kernel, which holds dS^T = P^T o (dP^T - delta) of its 16 keys x 64 queries in registers anyway, also
-// stores it as bf16 tiles, and the dQ kernel shrinks to ONE product, dQ^T += K^T dS^T, with both operands gathered by transposing
-// LDS reads: 5 products, no atomics, no fp32 partial slabs (S^2 / 2 x 2 B per head of scratch instead of S^2 / 256 x 512 B), every
-// output bit-reproducible. dS^T reaches the second MFMA rounded to bf16 in both forms, so the results agree to fp32 rounding of delta.
-//   scratch: per (b, h) the lower-triangular 64 x 64 tiles (key block kb <= query tile qt), tile index qt (qt + 1) / 2 + kb, each tile
-//   4096 bf16 blocked as [key / 16][q / 16][16 keys][16 q]: what one wave's store instruction writes (16 keys x 16 q) is 512 contiguous
-//   bytes, and the dQ kernel's LDS-DMA staging re-assembles any 16-B piece (8 q of one key) wherever its image wants it.
-//   delta = rowsum(O o dO) comes from its own pass (the dK / dV kernel now runs first).
+// (the five-product backward of round 3 -- attn_delta_kernel, attn_bwd_dq5_kernel -- is an experiment kernel: attention_exp.inc)
 __device__ __forceinline__ long long ds_tile_off(int bh, int ntri, int kb, int qt) {
   return ((long long)bh * ntri + (qt * (qt + 1)) / 2 + kb) * 4096;
 }
 
-// delta[b, h, s] = sum_d O[b, s, h, d] * dO[b, s, h, d]  (fp32; padded rows give 0 because the forward wrote zeros there).
-// One wave per token: a 16-lane group covers one head's 128 channels per step (16 B per lane and operand); all of a token's loads are
-// issued before the first reduction (H / 4 steps x 2 operands in flight per lane).
-template <int HSTEPS>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
-                                                         int B, int S, int H, long long ld_o) {
-  const int lane = threadIdx.x & 63;
-  const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= (long long)B * S) return;
-  const int b = (int)(tok / S), sidx = (int)(tok % S);
-  const bf16_t* orow = o + tok * ld_o + (lane >> 4) * D + (lane & 15) * 8;
-  const bf16_t* drow = dout + tok * ld_o + (lane >> 4) * D + (lane & 15) * 8;
-  u32x4_t a[HSTEPS], d[HSTEPS];
-#pragma unroll
-  for (int st = 0; st < HSTEPS; ++st) {
-    const bool ok = st * 4 + (lane >> 4) < H;
-    a[st] = ok ? *(const u32x4_t*)(orow + st * 4 * D) : u32x4_t{0u, 0u, 0u, 0u};
-    d[st] = ok ? *(const u32x4_t*)(drow + st * 4 * D) : u32x4_t{0u, 0u, 0u, 0u};
-  }
-#pragma unroll
-  for (int st = 0; st < HSTEPS; ++st) {
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc += bflo(a[st][j]) * bflo(d[st][j]) + bfhi(a[st][j]) * bfhi(d[st][j]);
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    const int h = st * 4 + (lane >> 4);
-    if (h < H && (lane & 15) == 0) delta[((long long)b * H + h) * S + sidx] = acc;
-  }
-}
-
-// swizzle of the 16-B chunk index inside the 128-B rows of the dS^T image [64 keys][64 q]: conflict-free ds_read_b64_tr_b16 over 8
-// consecutive rows (two rows span the 64 banks; the four rows of one parity get four different chunk pairs)
-__device__ __forceinline__ int swz64(int row, int c) { return c ^ (((row >> 1) & 3) << 1); }
-// B fragment from the dS^T image: lane (i -> query fq * 16 + i, g) gets dS^T[key row(g, j)][q], the reduction mapping of frag_tr
-__device__ __forceinline__ bf16x8_t frag_tr64(const char* tile, int fq, int ks2, int lane) {
-  const int i = lane & 15, g = lane >> 4;
-  union { bf16x8_t v; short4_t h[2]; } u;
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int row = ks2 * 32 + jj * 16 + g * 4 + (i >> 2);
-    u.h[jj] = lds_tr16_b64(tile + (row * 8 + swz64(row, fq * 2 + ((i & 3) >> 1))) * 16 + (i & 1) * 8);
-  }
-  return u.v;
-}
-
-// dQ from the stored dS^T: block = 4 waves x 16 query rows = ONE query tile qt, key tiles kt = 0 .. qt. Per tile and wave: two B
-// fragments (this wave's 16 queries x 64 keys of dS^T, gathered the way the forward gathers V^T -- the tile is a [key][q] image and q
-// plays d's role) and 16 MFMAs against the K^T fragments. No softmax, no score recomputation: the kernel streams dS^T (64 flop / B),
-// so it is built for memory parallelism -- 48 KiB of LDS per block, three blocks (12 waves) per CU, every block one tile ahead.
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq5_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = TILE_BYTES + TILE_BYTES / 2;        // K tile 16 KiB + dS^T tile 8 KiB
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nqt = (p.S + 63) / 64;
-  int qt, h, b;
-  if (!decode_block(nqt, p.H, p.B, qt, h, b)) return;
-  qt = nqt - 1 - qt;                               // heaviest first
-  const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
-  const int row_lim = seqlen < p.S ? seqlen : p.S;
-  const int q0 = qt * 64;
-  const int g = lane >> 4;
-  int myq[1];
-  bool padq[1];
-  const int grow0 = q0 + wave * 16;
-  myq[0] = grow0 + (lane & 15);
-  padq[0] = (myq[0] >= seqlen) || (myq[0] >= p.S);
-  int nkt = qt + 1;
-  const int kt_lim = (seqlen + 63) / 64;
-  if (nkt > kt_lim) nkt = kt_lim;
-  if (nkt <= 0 || q0 >= row_lim) {
-    dq_pad_block<1>(p, myq, b, h, lane);
-    return;
-  }
-  const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
-  const bf16_t* ds_head = p.ds_ws + ds_tile_off(b * p.H + h, nqt * (nqt + 1) / 2, 0, qt);   // tiles (kt, qt), kt = 0 .. qt, are consecutive
-  int dsoff[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int pp = (wave * 2 + it) * 64 + lane;
-    const int row = pp >> 3, c = swz64(row, pp & 7);
-    dsoff[it] = (((row >> 4) * 4 + (c >> 1)) * 16 + (row & 15)) * 16 + (c & 1) * 8;
-  }
-  auto stage_ds = [&](int kt, char* tile) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) ATTN_GLDS(ds_head + (long long)kt * 4096 + dsoff[it], tile + (wave * 2 + it) * 1024);
-  };
-  f32x4_t dqt[1][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dqt[0][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  unsigned koff[4];
-  stage_offs<1>(p.ld, wave, lane, koff);
-  stage_rows64<1>(kb_, p.ld, 0, p.S, smem, wave, lane);
-  stage_ds(0, smem + TILE_BYTES);
-  const bool active = grow0 < row_lim;                   // wave-uniform: a row group of padding computes nothing
-  for (int kt = 0; kt < nkt; ++kt) {
-    ATTN_WAIT_VM0();
-    __syncthreads();
-    const char* kt_ = smem + (kt & 1) * STAGE;
-    const char* ds_ = kt_ + TILE_BYTES;
-    if (kt + 1 < nkt) {
-      char* nx = smem + ((kt + 1) & 1) * STAGE;
-      if ((kt + 2) * 64 <= p.S) stage_fast(kb_ + (long long)(kt + 1) * 64 * p.ld, koff, nx, wave);
-      else stage_rows64<1>(kb_, p.ld, (kt + 1) * 64, p.S, nx, wave, lane);
-      stage_ds(kt + 1, nx + TILE_BYTES);
-    }
-    if (active) {
-      const bf16x8_t b0 = frag_tr64(ds_, wave, 0, lane), b1 = frag_tr64(ds_, wave, 1, lane);
-#pragma unroll
-      for (int fd = 0; fd < 8; ++fd) {
-        dqt[0][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<1>(kt_, fd, 0, lane), b0, dqt[0][fd], 0, 0, 0);
-        dqt[0][fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<1>(kt_, fd, 1, lane), b1, dqt[0][fd], 0, 0, 0);
-      }
-    }
-  }
-  // ---- epilogue (the dK / dV kernel's, for one output): dq rows as 256 B, dq^T and then o^T as 128-B runs per channel row.
-  // Images: dq [64 q][128 ch] at 0 (8-B chunk index ^ (q & 15) << 1), dq^T / o^T [128 ch][64 q] at 16 KiB (chunk ^ ((ch >> 1) & 3) << 2).
-  const bool tr = p.dqT != nullptr;
-  const int pq = lane & 3;
-  const bool valid = myq[0] < p.S;
-  {
-    const float sc = padq[0] ? 0.f : p.scale;
-#pragma unroll
-    for (int fd = 0; fd < 8; ++fd) dqt[0][fd] *= sc;
-  }
-  if (p.rope_cos) rope_bwd_row(dqt[0], p.rope_cos, p.rope_sin, valid ? myq[0] : 0, g);
-  __syncthreads();
-  {
-    const int row = wave * 16 + (lane & 15);
-#pragma unroll
-    for (int fd = 0; fd < 8; ++fd) {
-      u32x2_t w;
-      w[0] = valid ? pack2bf(dqt[0][fd][0], dqt[0][fd][1]) : 0u;
-      w[1] = valid ? pack2bf(dqt[0][fd][2], dqt[0][fd][3]) : 0u;
-      *(u32x2_t*)(smem + row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8)) = w;
-      if (tr) {
-        const int c = fd * 16 + g * 4 + pq;
-        *(u32x2_t*)(smem + 16384 + c * 128 + (((wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(w[0], w[1], lane);
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int r = ps * 16 + (threadIdx.x >> 4);
-      if (q0 + r < p.S)
-        *(u32x4_t*)(p.dq + ((long long)b * p.S + q0 + r) * p.ld + h * D + j * 8) =
-            *(const u32x4_t*)(smem + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
-    }
-  }
-  if (tr) {
-    const int j = threadIdx.x & 15;                       // 8-B chunk = queries q0 + 4 j .. + 3
-    const bool jv = q0 + j * 4 < p.S;
-    const long long tok = (long long)b * p.S + q0 + j * 4;
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int c = ps * 16 + (threadIdx.x >> 4);
-      if (jv) *(u32x2_t*)(p.dqT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 16384 + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
-    }
-    __syncthreads();
-    {   // o^T: O is re-read here (L2) for its transposed copy
-      const int chunk0 = wave * 4 + ((lane & 15) >> 2);
-      bf16x8_t of[4];
-      load_row_frags(p.o + ((long long)b * p.S + (valid ? myq[0] : p.S - 1)) * p.ld_o + h * D, lane, of);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        union { bf16x8_t v; uint32_t u[4]; } f;
-        f.v = of[ks];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int c = ks * 32 + g * 8 + half * 4 + pq;
-          *(u32x2_t*)(smem + 16384 + c * 128 + ((chunk0 ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int c = ps * 16 + (threadIdx.x >> 4);
-      if (jv) *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tok) = *(const u32x2_t*)(smem + 16384 + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 #ifndef MLA_ATTN_DKV_RSTAGE
@@ -1357,7 +1182,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq5_kernel(AttnArgs p) {
 #endif
 template <bool STORE_DS, bool MERGED>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /* 4 tiles + 2 x (64 lse + 64 delta) floats */, int kb, int h, int b,
-                                                  int* ready, int ready_target) {
+                                                  int* ready, int* done, int ready_target) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nkb = (p.S + 63) / 64;
@@ -1416,6 +1241,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /
       kf[ks] = frag_rows<ASW>(smem + 2 * TILE_BYTES, wave, ks, lane);
       vf[ks] = frag_rows<ASW>(smem + 3 * TILE_BYTES, wave, ks, lane);
     }
+  }
+  else if (MERGED && threadIdx.x >= 64 && threadIdx.x < 128) {
+    // a key block no query sees (right padding): nothing to read, but the self-resetting hand-off counts every consumer of the head,
+    // and none may reset the counters before the producers have all published
+    bwd_wait_ready(ready, ready_target);
   }
   BT(1, 1);
   BTV(1, 6, nqt_end - qt0);
@@ -1570,6 +1400,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /
 #endif
   }
   BT(1, 3);
+  // (self-resetting hand-off: this block's wait is long past; the atomic's round trip hides under the epilogue's table loads)
+  if (MERGED && threadIdx.x == 64) bwd_consumer_done(ready, done, nkb);
   // ---- epilogue. Everything leaves through LDS (the Q / dO ring is free now) as whole row runs: dk / dv rows as 256 B (16 B per
   // lane, 4 rows per store instruction), dk^T / dv^T as 128-B runs per channel row. Stored straight from the MFMA layout it is
   // 8 B per lane = 32-B pieces of 16 different rows per instruction, and a workgroup keeps its CU until its last partial-line store
@@ -1662,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int kb, h, b;
   if (!decode_block((p.S + 63) / 64, p.H, p.B, kb, h, b)) return;
-  attn_bwd_dkv_body<STORE_DS, false>(p, smem, kb, h, b, nullptr, 0);
+  attn_bwd_dkv_body<STORE_DS, false>(p, smem, kb, h, b, nullptr, nullptr, 0);
 }
 
 // ONE launch for both backward kernels (round 5; default MLA_ATTN_BWD_MERGED=105 = lag 5 + interleaved order, 0 = two launches): per XCD
@@ -1675,7 +1507,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 // same head form in their prologue: producers have LOWER workgroup ids on the same XCD (dispatched earlier, never waiting on anything),
 // so a consumer that spins on the head's counter cannot starve them; `lag` heads of distance make the wait a formality.
 // Same block bodies, same arithmetic: bit-identical to the two-launch form.
-__global__ __launch_bounds__(256, 2) void attn_bwd_merged_kernel(AttnArgs p, int* ready, int ready_target, int lag, int interleave) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_merged_kernel(AttnArgs p, int* sync, int lag, int interleave) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BQ = 16 * DQ_NW * DQ_RB;
   const int nqb = (p.S + BQ - 1) / BQ, nkb = (p.S + 63) / 64, per = nqb + nkb;
@@ -1706,469 +1538,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_merged_kernel(AttnArgs p, int
   const int group = j * 8 + xcd;
   if (group >= p.H * p.B) return;
   const int h = group % p.H, b = group / p.H;
-  if (is_dq) attn_bwd_dq_body<DQ_RB, DQ_NW, true>(p, smem, nqb - 1 - blk, h, b, ready + group);
-  else attn_bwd_dkv_body<false, true>(p, smem, blk, h, b, ready + group, ready_target);
+  int* ready = sync + group;                         // head_sync = [ready: 8 n | done: 8 n] ints, zero between launches
+  if (is_dq) attn_bwd_dq_body<DQ_RB, DQ_NW, true>(p, smem, nqb - 1 - blk, h, b, ready);
+  else attn_bwd_dkv_body<false, true>(p, smem, blk, h, b, ready, ready + 8 * n, nqb * DQ_NW);
 }
 
-// ------------------------------------------------------------------------------------------------ fused backward (round 5 experiment)
-// ONE workgroup per (batch, head) for sequences of at most 9 key tiles (S <= 576: the benchmark's 548): every operand is read once and
-// S / dP are computed once (5 products instead of 7). Why: the block-phase stamps of the two-kernel form (profiles/r5_attn_bwd_block_trace_*)
-// put 40-60 % of a block's life at S = 548 into prologue / epilogue memory time, both kernels read q, k, v, dO, and a lone wave needs
-// ~9.4 cycles per instruction against ~5.9 per SIMD with two -- so the lever is fewer instructions and bytes per (query tile, key tile)
-// pair, not a better schedule of the same ones.
-//   outer loop: key tile kb;  inner: query tiles qt >= kb.  Per pair:
-//     phase 1  wave (qg = w & 3, key half) : S = Q K^T, dP = dO V^T for 16 queries x (64 or 32) keys -> P, dS (bf16) into two [key][q]
-//              LDS images (PT, DST)
-//     phase 2  wave w owns head-dim slice [w * 128/NW, ...): dV^T += dO^T P, dK^T += Q^T dS (this key tile), dQ^T[qt] += K^T dS^T
-//   dQ^T of ALL query tiles stays in registers for the whole head (9 x 16 registers per 16-wide slice), dK^T / dV^T for the key tile.
-//   Every output leaves through fb_epilogue (scale, RoPE backward with the (d, d + 64) partner fetched through LDS, row image +
-//   transposed image -> whole-row stores), the same images as the two-kernel form.
-// Reduction orders match the two-kernel form (key tiles ascending for dQ, query tiles ascending for dK / dV, two 32-deep MFMA steps per
-// tile): results are compared bit for bit in tools/exp_attn_bits.py and tests/test_kernels_gpu.py.
-// STATUS (round 5): correct on the first GPU run and bit-identical on all 48 comparison tensors, but 1 072 us against 742 us for the
-// two-kernel form at S = 548, B = 32 (8 waves; the 4-wave / 512-register variant spilled 700+ registers and is not instantiated).
-// Per head 518 k cycles (tools/exp_attn_fused_trace.py; first version 640 k): prologue 52 k, phase 1 2.1 k x 45 pairs (was 2.5 k),
-// phase 2 2.7 k x 45 (was 4.65 k: padded-stride [key][q] images read conflict-free with one 16-B read per fragment, 4 fragments in
-// flight), 1.7 k per pair outside the two phases (barriers, staging-copy issue, the scratch reload of dQ tiles 6-8), key-tile
-// epilogues 10.7 k x 9, dQ epilogues 8.4 k x 9. What is left is structural: all 8 waves are in the same phase at the same time, so the
-// two waves of a SIMD never put MFMA work next to LDS / VALU work; per pair the LDS reads alone are ~1.7 k cycles of the CU's 256 B/clk
-// against 1.3 k cycles of MFMA, and prologue + epilogues (224 k cycles of latency chains with nobody to cover them) are as large as the
-// whole pair loop. Beating 742 us needs both halved -- two wave groups in opposite phases (double-buffered P / dS images, LDS flags
-// instead of the single workgroup barrier) and the three outputs of a key tile leaving through one epilogue with the RoPE rows fetched
-// a pair earlier. Kept opt-in (MLA_ATTN_BWD_FUSED=8) as the starting point for that.
-constexpr int FB_MAXT = 9;
-constexpr int FB_KV = 4 * TILE_BYTES;            // K tile, V tile
-constexpr int FB_PSTR = 144;                     // bytes per key row of the P / dS images: 64 q x 2 B + 16 B of padding (a 128-B pitch
-                                                 // puts every second row on the same banks; 144 B = 36 banks spreads 16 rows over all 64)
-constexpr int FB_PT = 6 * TILE_BYTES;            // P  [64 keys][64 q] bf16, q order within a row: ks2 * 32 + g * 8 + jj * 4 + r for
-constexpr int FB_DST = FB_PT + 64 * FB_PSTR;     // dS     q = ks2 * 32 + jj * 16 + g * 4 + r  (the 8 q of one MFMA k-group are 16 contiguous bytes)
-constexpr int FB_EPI = FB_DST + 64 * FB_PSTR;    // epilogue images: rows 16 KiB + transposed 16 KiB
-constexpr int FB_STAT = FB_EPI + 2 * TILE_BYTES; // lse * log2(e) [576] | delta [576]
-constexpr int FB_LDS = FB_STAT + 2 * FB_MAXT * 64 * 4;
-
-// B operand of the dV^T / dK^T products from a [key][q] image: lane (key = kf * 16 + (lane & 15), g) gets the 8 queries
-// ks2 * 32 + jj * 16 + g * 4 + (0..3) -- the reduction mapping of frag_tr -- as two 8-byte reads
-__device__ __forceinline__ bf16x8_t fb_pfrag(const char* img, int kf, int ks2, int lane) {
-  const int key = kf * 16 + (lane & 15), g = lane >> 4;
-  union { bf16x8_t v; u32x2_t h[2]; } u;
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
-    u.h[jj] = *(const u32x2_t*)(img + (key * 8 + swz64(key, ks2 * 4 + jj * 2 + (g >> 1))) * 16 + (g & 1) * 8);
-  return u.v;
-}
-
-// acc[DF][4]: this wave's head-dim fragments fd = wave * DF + df of a 64-token tile, lane = (token tf * 16 + (lane & 15); d = fd * 16 + g * 4 + r).
-// Writes rows[tok0 + token][d] (bf16, ld_rows) and, when outT, outT[d][tokT0 + token]. RoPE backward pairs d with d + 64, which lives in
-// another wave: the bf16-rounded pre-rotation values go through the row image first.
-template <int NW>
-__device__ __forceinline__ void fb_epilogue(const AttnArgs& p, char* smem, f32x4_t (&acc)[8 / NW][4], bf16_t* __restrict__ rows, long long ld_rows,
-                                            bf16_t* __restrict__ outT, long long tokT0, int tok0, float scale, bool rope, int wave, int lane) {
-  constexpr int DF = 8 / NW, NT = 64 * NW;
-  asm volatile("" : "+v"(lane));
-  const int g = lane >> 4, pq = lane & 3;
-  char* img = smem + FB_EPI;
-  char* imgT = smem + FB_EPI + TILE_BYTES;
-  u32x2_t w[DF][4];
-  f32x4_t cs[DF][4], sn[DF][4];
-  if (rope) {
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-#pragma unroll
-      for (int tf = 0; tf < 4; ++tf) {
-        const int tok = tok0 + tf * 16 + (lane & 15);
-        const int pos = tok < p.S ? tok : 0;
-        const int fd = wave * DF + df;
-        cs[df][tf] = *(const f32x4_t*)(p.rope_cos + (size_t)pos * 64 + (fd & 3) * 16 + g * 4);
-        sn[df][tf] = *(const f32x4_t*)(p.rope_sin + (size_t)pos * 64 + (fd & 3) * 16 + g * 4);
-      }
-  }
-#pragma unroll
-  for (int df = 0; df < DF; ++df)
-#pragma unroll
-    for (int tf = 0; tf < 4; ++tf) {
-      const bool valid = tok0 + tf * 16 + (lane & 15) < p.S;
-      acc[df][tf] *= scale;
-      w[df][tf][0] = valid ? pack2bf(acc[df][tf][0], acc[df][tf][1]) : 0u;
-      w[df][tf][1] = valid ? pack2bf(acc[df][tf][2], acc[df][tf][3]) : 0u;
-    }
-  auto img_off = [&](int fd, int tf) { const int row = tf * 16 + (lane & 15); return row * 256 + (((fd * 4 + g) ^ ((lane & 15) << 1)) * 8); };
-  if (rope) {
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-#pragma unroll
-      for (int tf = 0; tf < 4; ++tf) *(u32x2_t*)(img + img_off(wave * DF + df, tf)) = w[df][tf];
-    __syncthreads();
-    u32x2_t part[DF][4];
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-#pragma unroll
-      for (int tf = 0; tf < 4; ++tf) part[df][tf] = *(const u32x2_t*)(img + img_off((wave * DF + df) ^ 4, tf));
-    __syncthreads();
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-#pragma unroll
-      for (int tf = 0; tf < 4; ++tf) {
-        const bool hi = ((wave * DF + df) & 4) != 0;          // this lane holds the second half (d >= 64) of the pair
-        const bool valid = tok0 + tf * 16 + (lane & 15) < p.S;
-        float o4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t ow = w[df][tf][r >> 1], pw = part[df][tf][r >> 1];
-          const float own = (r & 1) ? bfhi(ow) : bflo(ow), oth = (r & 1) ? bfhi(pw) : bflo(pw);
-          const float a = hi ? oth : own, b_ = hi ? own : oth;      // a = first half, b = second half (bf16-rounded, as rope_bwd_row)
-          const float s_ = -sn[df][tf][r], c = cs[df][tf][r];
-          o4[r] = hi ? fmaf(b_, c, a * s_) : fmaf(a, c, -(b_ * s_));
-        }
-        w[df][tf][0] = valid ? pack2bf(o4[0], o4[1]) : 0u;
-        w[df][tf][1] = valid ? pack2bf(o4[2], o4[3]) : 0u;
-      }
-  }
-#pragma unroll
-  for (int df = 0; df < DF; ++df)
-#pragma unroll
-    for (int tf = 0; tf < 4; ++tf) {
-      const int fd = wave * DF + df;
-      *(u32x2_t*)(img + img_off(fd, tf)) = w[df][tf];
-      if (outT) {
-        const int c = fd * 16 + g * 4 + pq;
-        *(u32x2_t*)(imgT + c * 128 + (((tf * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(w[df][tf][0], w[df][tf][1], lane);
-      }
-    }
-  __syncthreads();
-  {
-    const int j = threadIdx.x & 15;                       // 16-B chunk = channels 8 j .. + 7
-#pragma unroll
-    for (int ps = 0; ps < 64 / (NT / 16); ++ps) {
-      const int r = ps * (NT / 16) + (threadIdx.x >> 4);
-      if (tok0 + r < p.S) *(u32x4_t*)(rows + (long long)(tok0 + r) * ld_rows + j * 8) = *(const u32x4_t*)(img + r * 256 + (((2 * j) ^ ((r & 15) << 1)) * 8));
-    }
-  }
-  if (outT) {
-    const int j = threadIdx.x & 15;                       // 8-B chunk = tokens tok0 + 4 j .. + 3
-    if (tok0 + j * 4 < p.S) {
-#pragma unroll
-      for (int ps = 0; ps < 128 / (NT / 16); ++ps) {
-        const int c = ps * (NT / 16) + (threadIdx.x >> 4);
-        *(u32x2_t*)(outT + (long long)c * p.ldT + tokT0 + tok0 + j * 4) = *(const u32x2_t*)(imgT + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// Per-lane LDS byte offsets of every fragment form the pair body reads, computed ONCE: each accessor below is `base + offset + constant`,
-// so a pair costs a handful of address adds (the ring parity) instead of re-deriving ~60 swizzled addresses (first version: ~600 VALU
-// per pair and wave against 40 MFMAs -- 1 200-1 350 us) and the compiler has nothing lane-dependent left to hoist and spill.
-template <int NW>
-struct FbOff {
-  unsigned R[4];        // frag_rows<ASW>(tile, 0, ks, lane): + rb * 4096
-  unsigned T[8 / NW];   // frag_tr<ASW>(tile, fd, 0, lane) first read: + ks2 * 8192 + jj * 4096
-  unsigned P;           // B operand of dV^T / dK^T from a P / dS image: one 16-B read at + kf * 16 * FB_PSTR + ks2 * 64
-  unsigned Q4;          // B operand of dQ^T (dS^T, transposing read): + (ks2 * 32 + jj * 16) * FB_PSTR (key rows) + (qf >> 1) * 64 + (qf & 1) * 8
-  unsigned W;           // producer write into PT / DST for key fragment 0: + kf * 16 * FB_PSTR
-  unsigned ST;          // stats: (qg * 16 + g * 4) * 4 bytes: + qt * 256
-};
-template <int NW>
-__device__ __forceinline__ void fb_offsets(FbOff<NW>& o, int wave, int lane) {
-  const int i = lane & 15, g = lane >> 4, qg = wave & 3;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) o.R[ks] = (unsigned)((i * 16 + swz<ASW>(i, ks * 4 + g)) * 16);
-#pragma unroll
-  for (int df = 0; df < 8 / NW; ++df) {
-    const int fd = wave * (8 / NW) + df, row = g * 4 + (i >> 2);
-    o.T[df] = (unsigned)((row * 16 + swz<ASW>(row, fd * 2 + ((i & 3) >> 1))) * 16 + (i & 1) * 8);
-  }
-  o.P = (unsigned)(i * FB_PSTR + g * 16);                                  // lane (key i, k-group g): 8 q at ks2 * 32 + g * 8 .. + 7
-  o.Q4 = (unsigned)((g * 4 + (i >> 2)) * FB_PSTR + (i & 3) * 16);           // transposing read: source lane (key row g * 4 + (i >> 2), 4-q group i & 3)
-  o.W = (unsigned)(i * FB_PSTR + (qg >> 1) * 64 + g * 16 + (qg & 1) * 8);   // this wave's 16 q (group qg = 2 ks2 + jj), 4 of them (r) per lane
-  o.ST = (unsigned)((qg * 16 + g * 4) * 4);
-}
-// (the tile swizzles only look at row & 7 / row & 15, so adding rb * 16 or ks2 * 32 + jj * 16 rows leaves the chunk index unchanged:
-// the constants above are exact)
-
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_bwd_fused_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int DF = 8 / NW, NKF = 16 / NW, NST = 16 / NW;
-  const int lane0 = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
-  const int seqlen = p.seqlens ? p.seqlens[b] : p.S;
-  const int row_lim = seqlen < p.S ? seqlen : p.S;
-  const int NT_ = (p.S + 63) / 64;
-  const bf16_t* qb_ = p.q + (long long)b * p.S * p.ld + h * D;
-  const bf16_t* kb_ = p.k + (long long)b * p.S * p.ld + h * D;
-  const bf16_t* vb_ = p.v + (long long)b * p.S * p.ld + h * D;
-  const bf16_t* dob_ = p.dout + (long long)b * p.S * p.ld_o + h * D;
-  const bf16_t* ob_ = p.o + (long long)b * p.S * p.ld_o + h * D;
-  float* lse2s = (float*)(smem + FB_STAT);
-  float* dlts = lse2s + FB_MAXT * 64;
-  const float sc2 = p.scale * LOG2E;
-  const bool tr = p.dqT != nullptr;
-  const long long tokT0 = (long long)b * p.S;
-  BT(0, 0);
-#ifdef MLA_ATTN_BTRACE
-  unsigned long long tp1 = 0, tp2 = 0, tep = 0, tc = 0;
-#define FBT(acc) do { const unsigned long long now__ = __builtin_readcyclecounter(); acc += now__ - tc; tc = now__; } while (0)
-#else
-#define FBT(acc) ((void)0)
+#ifdef MLA_EXPERIMENTAL_KERNELS
+#include "attention_exp.inc"
 #endif
-
-  // ---- prologue: lse, delta = rowsum(O * dO) and o^T for the whole head, one 64-row tile at a time through the ring
-  for (int t = 0; t < NT_; ++t) {
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int g = lane >> 4;
-    char* ot = smem + (t & 1) * 2 * TILE_BYTES;
-    stage_rows64<ASW, NW>(ob_, p.ld_o, t * 64, p.S, ot, wave, lane);
-    stage_rows64<ASW, NW>(dob_, p.ld_o, t * 64, p.S, ot + TILE_BYTES, wave, lane);
-    float lse_raw = 0.f;
-    const int myrow = t * 64 + (wave & 3) * 16 + (lane & 15);
-    if (wave < 4) lse_raw = p.lse[((long long)b * p.H + h) * p.S + (myrow < p.S ? myrow : p.S - 1)];
-    ATTN_WAIT_VM0();
-    __syncthreads();
-    if (wave < 4) {
-      bf16x8_t of[4];
-      float acc = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        of[ks] = frag_rows<ASW>(ot, wave, ks, lane);
-        const bf16x8_t dfr = frag_rows<ASW>(ot + TILE_BYTES, wave, ks, lane);
-        union { bf16x8_t v; uint32_t w[4]; } a, d;
-        a.v = of[ks];
-        d.v = dfr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc += bflo(a.w[j]) * bflo(d.w[j]) + bfhi(a.w[j]) * bfhi(d.w[j]);
-      }
-      const float dl = group_sum(acc);
-      const bool pad = myrow >= row_lim;
-      if (g == 0) {
-        lse2s[myrow] = pad ? INFINITY : lse_raw * LOG2E;
-        dlts[myrow] = dl;
-        if (myrow < p.S) ((float*)p.delta)[((long long)b * p.H + h) * p.S + myrow] = dl;
-      }
-      if (tr) {
-        char* imgT = smem + FB_EPI + TILE_BYTES;
-        const int pq = lane & 3;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          union { bf16x8_t v; uint32_t u[4]; } f;
-          f.v = of[ks];
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const int c = ks * 32 + g * 8 + half * 4 + pq;
-            *(u32x2_t*)(imgT + c * 128 + (((wave * 4 + ((lane & 15) >> 2)) ^ (((c >> 1) & 3) << 2)) * 8)) = quad_transpose_bf16(f.u[2 * half], f.u[2 * half + 1], lane);
-          }
-        }
-      }
-    }
-    if (tr) {
-      __syncthreads();
-      const char* imgT = smem + FB_EPI + TILE_BYTES;
-      const int j = threadIdx.x & 15;
-      if (t * 64 + j * 4 < p.S) {
-#pragma unroll
-        for (int ps = 0; ps < 128 / (4 * NW); ++ps) {
-          const int c = ps * (4 * NW) + (threadIdx.x >> 4);
-          *(u32x2_t*)(p.oT + ((long long)h * D + c) * p.ldT + tokT0 + t * 64 + j * 4) = *(const u32x2_t*)(imgT + c * 128 + ((j ^ (((c >> 1) & 3) << 2)) * 8));
-        }
-      }
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-
-  BT(0, 1);
-  // ---- main loop
-  FbOff<NW> fo;
-  fb_offsets<NW>(fo, wave, lane0);
-  const int li = lane0 & 15;
-  f32x4_t dqt[FB_MAXT][DF][4];
-#pragma unroll
-  for (int t = 0; t < FB_MAXT; ++t)
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-#pragma unroll
-      for (int qf = 0; qf < 4; ++qf) dqt[t][df][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  stage_rows64<ASW, NW>(kb_, p.ld, 0, p.S, smem + FB_KV, wave, lane0);
-  stage_rows64<ASW, NW>(vb_, p.ld, 0, p.S, smem + FB_KV + TILE_BYTES, wave, lane0);
-  stage_rows64<ASW, NW>(qb_, p.ld, 0, p.S, smem, wave, lane0);
-  stage_rows64<ASW, NW>(dob_, p.ld_o, 0, p.S, smem + TILE_BYTES, wave, lane0);
-  int n = 0;                                       // pair counter: ring buffer n & 1 holds the pair's Q | dO tile
-  const int qg = wave & 3, kh = NW == 8 ? (wave >> 2) : 0;
-  for (int kb = 0; kb < NT_; ++kb) {
-    f32x4_t dkt[DF][4], dvt[DF][4];
-#pragma unroll
-    for (int df = 0; df < DF; ++df)
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf) { dkt[df][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[df][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int qt = 0; qt < FB_MAXT; ++qt) {
-      if (qt < kb || qt >= NT_) continue;
-      ATTN_WAIT_VM0();
-      __syncthreads();                             // pair n's tile landed; everybody is done with pair n - 1
-#ifdef MLA_ATTN_BTRACE
-      tc = __builtin_readcyclecounter();
-#endif
-      const char* ring = smem + (n & 1) * 2 * TILE_BYTES;      // Q tile, dO tile at + TILE_BYTES
-      const char* kv = smem + FB_KV;                           // K tile, V tile at + TILE_BYTES
-      // (staging addresses are re-derived from an opaque copy of the lane id: hoisted out of the key-tile loop they were spilled and
-      // reloaded inside it, and a scratch reload's vmcnt(0) waits for the copies just issued)
-      int lane_s = lane0;
-      asm volatile("" : "+v"(lane_s));
-      {                                            // next pair's Q | dO tile into the other ring buffer
-        const int nqt = qt + 1 < NT_ ? qt + 1 : kb + 1;
-        if (nqt < NT_) {
-          char* nx = smem + ((n + 1) & 1) * 2 * TILE_BYTES;
-          stage_rows64<ASW, NW>(qb_, p.ld, nqt * 64, p.S, nx, wave, lane_s);
-          stage_rows64<ASW, NW>(dob_, p.ld_o, nqt * 64, p.S, nx + TILE_BYTES, wave, lane_s);
-        }
-      }
-      // phase 1: S, dP for 16 queries (group qg) x NKF key fragments
-      {
-        f32x4_t s[NKF], dp[NKF];
-#pragma unroll
-        for (int kk = 0; kk < NKF; ++kk) { s[kk] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kk] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-        // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks issue (the compiler's own order waits for every
-        // fragment right in front of its MFMA, and with one workgroup per CU nobody covers that latency)
-        __builtin_amdgcn_sched_barrier(0);
-        // 4 k-steps x NKF key fragments = 4 NKF (S, dP) MFMA pairs; A fragments (q, dO) are held one k-step ahead, the K | V fragments
-        // of MFMA pair j + 1 are requested before pair j issues (32 fragment registers in all -- a full double buffer is 48 and spills)
-        bf16x8_t fa[2][2], fb[2][2];
-        auto lda = [&](int ks, int slot) {
-          fa[slot][0] = *(const bf16x8_t*)(ring + fo.R[ks] + qg * 4096);
-          fa[slot][1] = *(const bf16x8_t*)(ring + fo.R[ks] + TILE_BYTES + qg * 4096);
-        };
-        auto ldb1 = [&](int j, int slot) {          // j = ks * NKF + kk
-          const int ks = j / NKF, kk = j % NKF;
-          fb[slot][0] = *(const bf16x8_t*)(kv + fo.R[ks] + (kh * NKF + kk) * 4096);
-          fb[slot][1] = *(const bf16x8_t*)(kv + fo.R[ks] + TILE_BYTES + (kh * NKF + kk) * 4096);
-        };
-        lda(0, 0);
-        ldb1(0, 0);
-#pragma unroll
-        for (int j = 0; j < 4 * NKF; ++j) {
-          const int ks = j / NKF, kk = j % NKF;
-          if (kk == 0 && ks + 1 < 4) lda(ks + 1, (ks + 1) & 1);
-          if (j + 1 < 4 * NKF) ldb1(j + 1, (j + 1) & 1);
-          s[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][0], fb[j & 1][0], s[kk], 0, 0, 0);
-          dp[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][1], fb[j & 1][1], dp[kk], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int j = 0; j < 4 * NKF; ++j) {
-          if (j % NKF == 0 && j / NKF + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          if (j + 1 < 4 * NKF) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4_t l4 = *(const f32x4_t*)(smem + FB_STAT + fo.ST + qt * 256);
-        const f32x4_t d4 = *(const f32x4_t*)(smem + FB_STAT + FB_MAXT * 256 + fo.ST + qt * 256);
-        const int g = lane0 >> 4;
-#pragma unroll
-        for (int kk = 0; kk < NKF; ++kk) {
-          const int kf = kh * NKF + kk;
-          const int key = kf * 16 + li;
-          float pr[4], dsv[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float sv = s[kk][r];
-            if (qt == kb && key > qg * 16 + g * 4 + r) sv = -INFINITY;     // diagonal tile: causal mask
-            const float pv = __builtin_amdgcn_exp2f(sv * sc2 - l4[r]);
-            pr[r] = pv;
-            dsv[r] = pv * (dp[kk][r] - d4[r]);
-          }
-          *(u32x2_t*)(smem + FB_PT + fo.W + kf * 16 * FB_PSTR) = u32x2_t{pack2bf(pr[0], pr[1]), pack2bf(pr[2], pr[3])};
-          *(u32x2_t*)(smem + FB_DST + fo.W + kf * 16 * FB_PSTR) = u32x2_t{pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
-        }
-      }
-      __syncthreads();
-      FBT(tp1);
-      bf16x8_t kT[DF][2];                          // K^T fragments of this wave's head-dim slice (A operand of dQ^T): re-read per pair
-#pragma unroll                                     // (8 registers that do not have to live across the key tile), before the next key
-      for (int df = 0; df < DF; ++df)              // tile's copies may overwrite the K tile
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-          union { bf16x8_t v; short4_t hh[2]; } u;
-          u.hh[0] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192);
-          u.hh[1] = lds_tr16_b64(kv + fo.T[df] + ks2 * 8192 + 4096);
-          kT[df][ks2] = u.v;
-        }
-      if (qt == NT_ - 1 && kb + 1 < NT_) {         // last pair of this key tile: its K | V rows are no longer read
-        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): the K^T reads above have landed before the copies overwrite the tile
-        stage_rows64<ASW, NW>(kb_, p.ld, (kb + 1) * 64, p.S, smem + FB_KV, wave, lane_s);
-        stage_rows64<ASW, NW>(vb_, p.ld, (kb + 1) * 64, p.S, smem + FB_KV + TILE_BYTES, wave, lane_s);
-      }
-      // phase 2: this wave's head-dim slice of dV^T, dK^T (key tile kb) and dQ^T (query tile qt), as a software pipeline over its
-      // 24 B-operand fragments per head-dim fragment: fragment i + PF2 is requested before MFMA i issues
-#pragma unroll
-      for (int df = 0; df < DF; ++df) {
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int PF2 = 4;
-        bf16x8_t afr[2][2];                      // [ks2][0 = dO^T, 1 = Q^T]
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-          union { bf16x8_t v; short4_t hh[2]; } ado, aq;
-          ado.hh[0] = lds_tr16_b64(ring + TILE_BYTES + fo.T[df] + ks2 * 8192);
-          ado.hh[1] = lds_tr16_b64(ring + TILE_BYTES + fo.T[df] + ks2 * 8192 + 4096);
-          aq.hh[0] = lds_tr16_b64(ring + fo.T[df] + ks2 * 8192);
-          aq.hh[1] = lds_tr16_b64(ring + fo.T[df] + ks2 * 8192 + 4096);
-          afr[ks2][0] = ado.v;
-          afr[ks2][1] = aq.v;
-        }
-        // MFMA i: 0..15 = (ks2 = i >> 3, kf = (i >> 1) & 3, i & 1: 0 -> dV^T (P), 1 -> dK^T (dS)); 16..23 = dQ^T (ks2 = (i - 16) >> 2, qf = i & 3)
-        auto ldb = [&](int i) -> bf16x8_t {
-          if (i < 16) return *(const bf16x8_t*)(smem + ((i & 1) ? FB_DST : FB_PT) + fo.P + ((i >> 1) & 3) * 16 * FB_PSTR + (i >> 3) * 64);
-          const int ks2 = (i - 16) >> 2, qf = i & 3;
-          union { bf16x8_t v; short4_t hh[2]; } bt;
-          bt.hh[0] = lds_tr16_b64(smem + FB_DST + fo.Q4 + (ks2 * 32) * FB_PSTR + (qf >> 1) * 64 + (qf & 1) * 8);
-          bt.hh[1] = lds_tr16_b64(smem + FB_DST + fo.Q4 + (ks2 * 32 + 16) * FB_PSTR + (qf >> 1) * 64 + (qf & 1) * 8);
-          return bt.v;
-        };
-        bf16x8_t rb[PF2];
-#pragma unroll
-        for (int i = 0; i < PF2; ++i) rb[i] = ldb(i);
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-          const bf16x8_t bfrag = rb[i % PF2];
-          if (i + PF2 < 24) rb[i % PF2] = ldb(i + PF2);
-          if (i < 16) {
-            const int ks2 = i >> 3, kf = (i >> 1) & 3;
-            if (i & 1) dkt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks2][1], bfrag, dkt[df][kf], 0, 0, 0);
-            else dvt[df][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks2][0], bfrag, dvt[df][kf], 0, 0, 0);
-          } else {
-            const int ks2 = (i - 16) >> 2, qf = i & 3;
-            dqt[qt][df][qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT[df][ks2], bfrag, dqt[qt][df][qf], 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8 + PF2, 0);          // A fragments (8 transposing reads) + the ring's first fill (16-B reads)
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (i + PF2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one 16-B read
-          else if (i + PF2 < 24) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // two transposing reads
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      FBT(tp2);
-      ++n;
-    }
-    // ---- key tile kb done: dv, dk (+ transposed copies)
-    fb_epilogue<NW>(p, smem, dvt, p.dv + ((long long)b * p.S) * p.ld + h * D, p.ld, tr ? p.dvT + (long long)h * D * p.ldT : nullptr, tokT0, kb * 64, 1.0f, false, wave, lane0);
-    fb_epilogue<NW>(p, smem, dkt, p.dk + ((long long)b * p.S) * p.ld + h * D, p.ld, tr ? p.dkT + (long long)h * D * p.ldT : nullptr, tokT0, kb * 64, p.scale, p.rope_cos != nullptr, wave, lane0);
-    FBT(tep);
-  }
-  BT(0, 2);
-#pragma unroll
-  for (int qt = 0; qt < FB_MAXT; ++qt) {
-    if (qt >= NT_) continue;
-    fb_epilogue<NW>(p, smem, dqt[qt], p.dq + ((long long)b * p.S) * p.ld + h * D, p.ld, tr ? p.dqT + (long long)h * D * p.ldT : nullptr, tokT0, qt * 64, p.scale, p.rope_cos != nullptr, wave, lane0);
-  }
-  BT(0, 3);
-  BTV(0, 4, tep);
-  BTV(0, 5, tp1);
-  BTV(0, 6, tp2);
-}
 
 int check_common(const AttnArgs& p, const char* who) {
   if (!(p.B > 0 && p.S > 0 && p.H > 0)) { mla_set_error("%s: bad shape", who); return -1; }
@@ -2217,41 +1594,18 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 // delta: workspace [B,H,S] fp32 (caller-allocated)
-// Per-stream head counters of the merged backward launch (grown on demand, never freed: a few KiB per stream). Every launch adds
-// exactly `per_head` to each of the first `groups` (= B * H) counters, so in steady state (same head count and blocks per head as the
-// previous launch on this stream) the wait target just advances by per_head and nothing has to be cleared; any change, or a counter
-// near overflow, clears the buffer first.
-struct BwdReady { int* buf = nullptr; int cap = 0, groups = -1, per_head = -1, epoch = 0; };
-static int* bwd_ready_buffer(hipStream_t stream, int groups, int per_head, int* target) {
-  static std::mutex mu;
-  static std::map<hipStream_t, BwdReady> bufs;
-  std::lock_guard<std::mutex> lk(mu);
-  BwdReady& e = bufs[stream];
-  if (groups < 0) { e.groups = -1; return nullptr; }   // invalidate (a launch failed after the epoch was advanced)
-  if (e.cap < groups + 8) {
-    int* nb = nullptr;
-    const int cap = groups + 8 < 4096 ? 4096 : groups + 8;
-    if (hipMalloc(&nb, (size_t)cap * sizeof(int)) != hipSuccess) return nullptr;
-    e.buf = nb;        // (an outgrown buffer may still be read by a queued launch: it is left allocated)
-    e.cap = cap;
-    e.groups = -1;
-  }
-  if (e.groups != groups || e.per_head != per_head || e.epoch >= (1 << 24)) {
-    if (hipMemsetAsync(e.buf, 0, (size_t)e.cap * sizeof(int), stream) != hipSuccess) return nullptr;
-    e.groups = groups;
-    e.per_head = per_head;
-    e.epoch = 0;
-  }
-  ++e.epoch;
-  *target = e.epoch * per_head;
-  return e.buf;
+// head_sync (merged launch): caller-owned, 2 ints per head rounded up to a multiple of 8 heads, zero before the first launch; the
+// kernel leaves it zero (bwd_consumer_done). The library keeps no state and allocates nothing.
+extern "C" long long mla_attn_bwd_sync_ints(int B, int H) {
+  if (B <= 0 || H <= 0) return -1;
+  return 2ll * (((long long)B * H + 7) / 8) * 8;
 }
 
 static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                          const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
                          int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
-                         const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, hipStream_t stream,
-                         void* ws = nullptr, long long ws_bytes = 0) {
+                         const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, int* head_sync,
+                         long long head_sync_ints, hipStream_t stream, void* ws = nullptr, long long ws_bytes = 0) {
   const int nT = (dqT != nullptr) + (dkT != nullptr) + (dvT != nullptr) + (oT != nullptr);
   MLA_CHECK_ARG(nT == 0 || nT == 4, "mla_attn_bwd_t: dqT / dkT / dvT / oT must all be given or all be null");
   MLA_CHECK_ARG(nT == 0 || (S % 4 == 0 && ldt % 4 == 0 && ldt >= (long long)B * S && ((uintptr_t)dqT & 7) == 0 &&
@@ -2274,12 +1628,12 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_RB, DQ_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 32768);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024 + 32768);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
     attr = true;
   }
   p.o = (bf16_t*)o;
-  // MLA_ATTN_BWD_FUSED=8: the one-workgroup-per-head backward (S <= 576; experiment, opt-in: bit-identical to the two-kernel form and
-  // 1.6 x SLOWER in its first, un-pipelined form -- see attn_bwd_fused_kernel and HISTORY.md "Round 5")
+#ifdef MLA_EXPERIMENTAL_KERNELS
+  // MLA_ATTN_BWD_FUSED=8: the one-workgroup-per-head backward (S <= 576; experiment build only: bit-identical to the two-kernel form and
+  // 1.45 x SLOWER -- see attention_exp.inc and HISTORY.md "Round 5")
   static const int fused = getenv("MLA_ATTN_BWD_FUSED") ? atoi(getenv("MLA_ATTN_BWD_FUSED")) : 0;
   if (!ws && fused == 8 && S <= 64 * FB_MAXT && S % 4 == 0) {
     static bool fattr = false;
@@ -2290,10 +1644,14 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(B * H), dim3(512), FB_LDS, stream, p);
     MLA_LAUNCH_CHECK();
   }
-  // Both backward kernels as ONE launch (attn_bwd_merged_kernel): MLA_ATTN_BWD_MERGED = lag + 100 * interleave, default 105; 0 = the
-  // two-launch form (bit-identical). Measured per layer: 742 -> 703 us at S = 548, 1 310 -> 1 258 us at S = 2048 / B = 8.
+#endif
+  // Both backward kernels as ONE launch (attn_bwd_merged_kernel) when the caller hands over its head counters (head_sync):
+  // MLA_ATTN_BWD_MERGED = lag + 100 * interleave, default 105, lag clamped to >= 1 (a consumer never sits in front of its own
+  // producers); 0 = the two-launch form (bit-identical), which is also what a NULL head_sync selects. Measured per layer: 742 -> 703 us
+  // at S = 548, 1 310 -> 1 258 us at S = 2048 / B = 8. Launch-only and stateless: graph-capturable, any device, any stream (one
+  // head_sync buffer per stream in flight).
   static const int merged = getenv("MLA_ATTN_BWD_MERGED") ? atoi(getenv("MLA_ATTN_BWD_MERGED")) : 105;
-  if (!ws && merged > 0) {
+  if (!ws && merged > 0 && head_sync) {
     constexpr int BQm = 16 * DQ_NW * DQ_RB;
     static_assert(DQ_NW == 4, "the merged launch runs both block types with 256 threads");
     static bool mattr = false;
@@ -2302,18 +1660,18 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
       mattr = true;
     }
     const int groups = ((H * B + 7) / 8) * 8;
+    MLA_CHECK_ARG(head_sync_ints >= 2ll * groups && (((uintptr_t)head_sync) & 3) == 0,
+                  "mla_attn_bwd: head_sync needs mla_attn_bwd_sync_ints(B, H) = %d ints (got %lld)", 2 * groups, head_sync_ints);
     const int nqb_m = (S + BQm - 1) / BQm;
-    int target = 0;
-    int* ready = bwd_ready_buffer(stream, H * B, nqb_m * DQ_NW, &target);   // keyed on the REAL head count: padding groups never publish
-    MLA_CHECK_ARG(ready != nullptr, "mla_attn_bwd: could not set up the merged launch's %d head counters", groups);
     const int per = nqb_m + (S + 63) / 64;
+    const int lag = merged % 100 < 1 ? 1 : merged % 100;
     static const int lds_extra_m = getenv("MLA_ATTN_BWD_LDS_EXTRA") ? (atoi(getenv("MLA_ATTN_BWD_LDS_EXTRA")) > 0 ? 32768 : 0) : 0;
-    hipLaunchKernelGGL(attn_bwd_merged_kernel, dim3(groups * per), dim3(256), 4 * TILE_BYTES + 1024 + lds_extra_m, stream, p, ready, target,
-                       merged % 100, merged / 100);
-    if (hipPeekAtLastError() != hipSuccess) (void)bwd_ready_buffer(stream, -1, 0, &target);   // the counters did not advance: clear them next time
+    hipLaunchKernelGGL(attn_bwd_merged_kernel, dim3(groups * per), dim3(256), 4 * TILE_BYTES + 1024 + lds_extra_m, stream, p, head_sync,
+                       lag, merged / 100);
     MLA_LAUNCH_CHECK();
   }
   if (ws) {
+#ifdef MLA_EXPERIMENTAL_KERNELS
     // 5-product form: delta pass -> dK / dV kernel (stores dS^T) -> one-product dQ kernel
     const long long nqt = (S + 63) / 64, need = (long long)B * H * (nqt * (nqt + 1) / 2) * 8192;
     MLA_CHECK_ARG(ws_bytes >= need && AL16(ws), "mla_attn_bwd_ws: workspace of %lld bytes needed (mla_attn_bwd_ws_bytes), got %lld", need, ws_bytes);
@@ -2321,13 +1679,21 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     p.ds_ws = (bf16_t*)ws;
     MLA_CHECK_ARG(H <= 64, "mla_attn_bwd_ws: at most 64 heads (got %d)", H);
     static bool attr5 = false;
-    if (!attr5) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TILE_BYTES); attr5 = true; }
+    if (!attr5) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TILE_BYTES);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES + 1024);
+      attr5 = true;
+    }
     const long long tokens = (long long)B * S;
     if (H <= 32) hipLaunchKernelGGL(attn_delta_kernel<8>, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta, B, S, H, ld_o);
     else hipLaunchKernelGGL(attn_delta_kernel<16>, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta, B, S, H, ld_o);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 4 * TILE_BYTES + 1024, stream, p);
     hipLaunchKernelGGL(attn_bwd_dq5_kernel, dim3(grid_blocks((S + 63) / 64, H, B)), dim3(256), 3 * TILE_BYTES, stream, p);
     MLA_LAUNCH_CHECK();
+#else
+    (void)ws_bytes;
+    MLA_CHECK_ARG(false, "mla_attn_bwd_ws: the five-product backward is an experiment kernel, not in this build (MLA_EXPERIMENTAL=1 build.sh; mla_query(3))");
+#endif
   }
   // delta = rowsum(O * dO) is computed by the dQ kernel's prologue (p.o set) and read by the dK / dV kernel launched behind it
   constexpr int BQ = 16 * DQ_NW * DQ_RB;
@@ -2342,9 +1708,9 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
 extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                             const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
                             int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
-                            const float* rope_sin, hipStream_t stream) {
+                            const float* rope_sin, int* head_sync, long long head_sync_ints, hipStream_t stream) {
   return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
-                       nullptr, nullptr, nullptr, nullptr, 0, stream);
+                       nullptr, nullptr, nullptr, nullptr, 0, head_sync, head_sync_ints, stream);
 }
 // + token-contiguous copies dqT / dkT / dvT / oT [H * head_dim, ldt] of dq / dk / dv / o (columns b * S + s; columns >= B * S are
 // not touched): the k-contiguous operands of the q|k|v and o projection wgrad GEMMs, written from the registers that hold the rows
@@ -2352,13 +1718,15 @@ extern "C" int mla_attn_bwd(const void* q, const void* k, const void* v, const v
 extern "C" int mla_attn_bwd_t(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                               const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
                               int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
-                              const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, hipStream_t stream) {
+                              const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, int* head_sync,
+                              long long head_sync_ints, hipStream_t stream) {
   return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
-                       dqT, dkT, dvT, oT, ldt, stream);
+                       dqT, dkT, dvT, oT, ldt, head_sync, head_sync_ints, stream);
 }
 
-// 5-product backward: same outputs as mla_attn_bwd_t (dqT / dkT / dvT / oT optional, all or none) with the
-// caller-owned workspace `ws` of mla_attn_bwd_ws_bytes(B, S, H) bytes carrying dS^T from the dK / dV kernel to the dQ kernel.
+// 5-product backward (experiment build only -- the product library rejects the call): same outputs as
+// mla_attn_bwd_t (dqT / dkT / dvT / oT optional, all or none) with the caller-owned workspace `ws` of mla_attn_bwd_ws_bytes(B, S, H)
+// bytes carrying dS^T from the dK / dV kernel to the dQ kernel.
 extern "C" long long mla_attn_bwd_ws_bytes(int B, int S, int H) {
   if (B <= 0 || S <= 0 || H <= 0) return -1;
   const long long nqt = (S + 63) / 64;
@@ -2370,5 +1738,5 @@ extern "C" int mla_attn_bwd_ws(const void* q, const void* k, const void* v, cons
                                void* dkT, void* dvT, void* oT, long long ldt, void* ws, long long ws_bytes, hipStream_t stream) {
   MLA_CHECK_ARG(ws != nullptr, "mla_attn_bwd_ws: null workspace");
   return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
-                       dqT, dkT, dvT, oT, ldt, stream, ws, ws_bytes);
+                       dqT, dkT, dvT, oT, ldt, nullptr, 0, stream, ws, ws_bytes);
 }

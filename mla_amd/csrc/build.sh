@@ -4,7 +4,8 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-# MLA_EXPERIMENTAL=1 adds the opt-in experiment kernels (gemm_asm.hip: assembly main loops, gemm256p: persistent walk); the product
+# MLA_EXPERIMENTAL=1 adds the opt-in experiment kernels (gemm_asm.hip: assembly main loops, gemm256p: persistent walk, attention_exp.inc:
+# the five-product and the one-workgroup-per-head attention backward); the product
 # library is built without them. Objects of the two flavours live in separate directories.
 EXP="${MLA_EXPERIMENTAL:-0}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC ${MLA_EXTRA_FLAGS:-} -Wno-unused-value -Wno-unused-result"
@@ -19,7 +20,7 @@ SRCS="api gemm gemm256 transpose elementwise attention loss pointcloud vision ge
 [ "$EXP" = 1 ] && SRCS="$SRCS gemm_asm"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue
-  if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/common.h" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$BUILD/$f.o" ] || { [ "$f" = gemm256 ] && { [ "$HERE/gemm256_kloop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm256_kloop_half1.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = attention ] && { [ "$HERE/attn_fwd32p_tile0.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile1.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile0c.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile1c.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_clobbers.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_8w_clobbers.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_clobbers.inc" -nt "$BUILD/$f.o" ]; }; }; then
+  if [ ! -f "$BUILD/$f.o" ] || [ "$HERE/$f.hip" -nt "$BUILD/$f.o" ] || [ "$HERE/common.h" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_args.h" -nt "$BUILD/$f.o" ] || { [ "$f" = gemm256 ] && { [ "$HERE/gemm256_kloop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm256_kloop_half1.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = attention ] && { [ "$HERE/attn_fwd32p_tile0.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile1.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile0c.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_tile1c.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attn_fwd32p_clobbers.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/attention_exp.inc" -nt "$BUILD/$f.o" ] || [ ! -f "$BUILD/$f.s" ]; }; } || { [ "$f" = gemm_asm ] && { [ "$HERE/gemm_asm_8w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_loop.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_8w_clobbers.inc" -nt "$BUILD/$f.o" ] || [ "$HERE/gemm_asm_4w_clobbers.inc" -nt "$BUILD/$f.o" ]; }; }; then
     XF=""; [ "$f" = api ] && XF="-DMLA_GEMM_SRC_ID=\"$GID\""
     $HIPCC $FLAGS $XF -c "$HERE/$f.hip" -o "$BUILD/$f.o" &
     pids+=($!)

@@ -157,7 +157,7 @@ def plan_sharded_layout(model: nn.Module, unit_policy: Callable[[nn.Module], boo
     model may live on the meta device): the audit the 8-GPU run is planned with. Bytes per rank and unit:
     bf16 replica (whole unit: the all-gathered weights stay resident), fp32 gradient buffer (whole trainable region: the in-place
     reduce-scatter leaves the rank's shard inside it), fp32 master + two AdamW moments (1/world of the trainable region), fp32
-    master of the frozen region (1/world). ``inplace_reduce=False`` adds the separate fp32 gradient shard of the gloo / AVG path."""
+    master of the frozen region (1/world). ``inplace_reduce=False`` adds the separate fp32 gradient shard of the gloo / out-of-place path."""
     units = []
     for name, mod, named in discover_units(model, unit_policy):
         params, n_decay, n_train, n_total = plan_flat_layout(named, world, no_decay)
@@ -425,12 +425,17 @@ class ShardedModel:
         self.ops = ops if ops is not None else HipLocalOps()
         # RCCL: in-place SUM reduce-scatter, mean folded into the scales (see FlatUnit). gloo (CPU tests) keeps separate mean shards.
         # (inplace_reduce=True with gloo is for the CPU tests: it runs the same SUM-shard bookkeeping over an in-place all-reduce)
-        # MLA_FSDP_INPLACE_RS=0: back to the out-of-place AVG reduce-scatter into separate shard buffers (the round-2 form) -- a pre-wired
-        # fallback for the first multi-GPU run, should RCCL's in-place SUM form misbehave on the node
+        # MLA_FSDP_INPLACE_RS=0: back to an out-of-place reduce-scatter into separate shard buffers (the round-2 layout; a SUM like the
+        # in-place form since round 6) -- a pre-wired fallback for the first multi-GPU run, should RCCL's in-place form misbehave there
         if inplace_reduce is None and os.environ.get("MLA_FSDP_INPLACE_RS") == "0":
             inplace_reduce = False
         self.inplace_reduce = bool(self.coll and (dist.get_backend(process_group) == "nccl" if inplace_reduce is None else inplace_reduce))
-        self.grad_div = float(self.world) if self.inplace_reduce else 1.0     # gshard holds grad_div x the mean gradient
+        # RCCL reduce-scatters are always SUMs, in place or not (round 6): ncclAvg is not used at all. The world-1 RCCL test
+        # (tests/test_fsdp_rccl_world1_gpu.py) caught this image's RCCL 2.26.6 dropping the last 8 elements of an out-of-place AVG
+        # reduce-scatter of 2^20 + 8 floats (output left untouched there; SUM of the same buffer is exact --
+        # profiles/r6_rccl_avg_tail.txt), which silently froze the last bias of the root unit under MLA_FSDP_INPLACE_RS=0.
+        self.sum_shards = bool(self.inplace_reduce or (self.coll and dist.get_backend(process_group) == "nccl"))
+        self.grad_div = float(self.world) if self.sum_shards else 1.0         # gshard holds grad_div x the mean gradient
         no_decay = no_decay or default_no_decay   # fsdp.py:236-256
         # ---- unit discovery (outermost matches of the policy; the remainder folds into the root unit); forward order: non-decoder
         # units and the root first (embeddings are needed first), decoder layers after -- discover_units()
@@ -535,10 +540,9 @@ class ShardedModel:
     def _reduce_scatter(self, u: FlatUnit):
         backend = dist.get_backend(self.pg)
         if backend == "nccl":
-            if u.inplace_reduce:
-                dist.reduce_scatter_tensor(u.gshard, u.grad32, op=dist.ReduceOp.SUM, group=self.pg)     # in place (gshard = own slice)
-            else:
-                dist.reduce_scatter_tensor(u.gshard, u.grad32, op=dist.ReduceOp.AVG, group=self.pg)
+            # SUM either way (in place: gshard = this rank's own slice of grad32; MLA_FSDP_INPLACE_RS=0: a separate shard buffer); the
+            # mean's 1 / world lives in grad_div. Never ncclAvg: see __init__.
+            dist.reduce_scatter_tensor(u.gshard, u.grad32, op=dist.ReduceOp.SUM, group=self.pg)
         else:  # gloo (CPU tests): all-reduce + slice
             dist.all_reduce(u.grad32, op=dist.ReduceOp.SUM, group=self.pg)
             if not u.inplace_reduce:            # (in place: gshard IS the rank's slice of grad32 and now holds the SUM)

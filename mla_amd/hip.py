@@ -29,6 +29,7 @@ GEMM_PROFILE = None
 _SIGNATURES = {
     "mla_query": [c_int],
     "mla_selftest": [c_void_p, c_void_p, c_void_p, c_void_p],
+    "mla_dispatch_probe": [c_void_p, c_int, c_int, c_void_p],
     "mla_gemm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "mla_gemm_bf16_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -76,10 +77,12 @@ _SIGNATURES = {
     "mla_attn_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong,
                      c_longlong, c_float, c_void_p],
     "mla_attn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                     c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p, c_void_p],
+                     c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_longlong,
+                     c_void_p],
     "mla_attn_bwd_t": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
-                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p],
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p],
+    "mla_attn_bwd_sync_ints": [c_int, c_int],                # returns long long (restype fixed up in lib())
     "mla_attn_bwd_ws_bytes": [c_int, c_int, c_int],          # returns long long (restype fixed up in lib())
     "mla_attn_bwd_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                         c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
@@ -129,6 +132,7 @@ def lib():
             fn.argtypes = argt
             fn.restype = c_int
         L.mla_attn_bwd_ws_bytes.restype = c_longlong
+        L.mla_attn_bwd_sync_ints.restype = c_longlong
         _lib = L
     return _lib
 
@@ -549,10 +553,66 @@ def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None):
 ATTN_BWD5 = os.environ.get("MLA_ATTN_BWD5", "0") == "1"
 
 
+# ---- one-launch backward: the head counters are OURS (the library keeps nothing), one zero-initialised int32 buffer per (device, stream),
+# handed over only on a device where the dispatch probe holds (mla_hip.h: mla_attn_bwd, mla_dispatch_probe).
+_HEAD_SYNC = {}          # (device index, stream handle) -> int32 tensor; the kernel leaves it zero after every launch
+_DISPATCH_OK = {}        # device index -> (bool, dict): result of dispatch_probe()
+ATTN_BWD_MERGED = os.environ.get("MLA_ATTN_BWD_MERGED", "105") != "0"
+
+
+def dispatch_probe(device="cuda", blocks=4096, hold_us=20):
+    """Measures what attn_bwd_merged_kernel assumes (include/mla_hip.h: mla_dispatch_probe). Returns (ok, info): ok iff there are 8
+    XCDs, workgroup L ran on XCD L & 7 for every L, and per XCD no workgroup started more than one residency round (64 slots: 32 CUs x
+    2 workgroups) away from its place in id order. Synchronises -- called once per device, outside any capture."""
+    dev = torch.device(device)
+    out = torch.zeros(1 + 2 * blocks, dtype=torch.int32, device=dev)
+    call("mla_dispatch_probe", _p(out), blocks, hold_us)
+    rec = out.cpu()[1:].view(blocks, 2)
+    ticket, xcc = rec[:, 0].long(), rec[:, 1].long()
+    ids = torch.arange(blocks)
+    n_xcd = int(xcc.unique().numel())
+    xcd_ok = bool((xcc == (ids & 7)).all())
+    worst = 0
+    for x in range(8):
+        t = ticket[ids % 8 == x]                       # start tickets of the workgroups with id = x mod 8, in id order
+        rank = torch.argsort(torch.argsort(t))          # place of each in start order
+        worst = max(worst, int((rank - torch.arange(t.numel())).abs().max()))
+    info = {"xcds": n_xcd, "xcc_is_id_mod_8": xcd_ok, "worst_start_displacement": worst, "blocks": blocks,
+            "tickets_complete": bool(torch.equal(torch.sort(ticket).values, ids))}
+    return (n_xcd == 8 and xcd_ok and worst <= 64 and info["tickets_complete"]), info
+
+
+def _head_sync(device, B, H):
+    """The caller-owned counter pair per head for the one-launch backward, or None (= two launches)."""
+    if not ATTN_BWD_MERGED:
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _DISPATCH_OK:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                  # first use inside a capture: the probe synchronises -- stay on two launches
+        with torch.cuda.device(idx):
+            _DISPATCH_OK[idx] = dispatch_probe(torch.device("cuda", idx))
+    if not _DISPATCH_OK[idx][0]:
+        return None
+    need = int(lib().mla_attn_bwd_sync_ints(B, H))
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    buf = _HEAD_SYNC.get(key)
+    if buf is None or buf.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        # (an outgrown buffer may still be read by queued launches: torch's stream-ordered allocator does not hand its memory to
+        # anything that could run before them)
+        buf = torch.zeros(max(need, 4096), dtype=torch.int32, device=torch.device("cuda", idx))
+        _HEAD_SYNC[key] = buf
+    return buf
+
+
 def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale, rope_cos=None, rope_sin=None, transposed=None,
-             five: Optional[bool] = None):
-    """five (default: off, see ATTN_BWD5): the five-product form -- the dK / dV kernel hands dS^T (bf16 tiles in a torch-owned scratch
-    buffer) to a one-product dQ kernel instead of both kernels recomputing Q K^T and dO V^T (mla_attn_bwd_ws).
+             five: Optional[bool] = None, merged: Optional[bool] = None):
+    """five (experiment build only, see ATTN_BWD5): the five-product form -- the dK / dV kernel hands dS^T (bf16 tiles in a torch-owned
+    scratch buffer) to a one-product dQ kernel instead of both kernels recomputing Q K^T and dO V^T (mla_attn_bwd_ws).
+    merged (default: on where the dispatch probe holds; MLA_ATTN_BWD_MERGED=0 turns it off): one launch for the dQ and dK / dV blocks
+    with this module's per-stream head counters; False = two launches. Bit-identical either way.
     rope_cos / rope_sin ([S, D/2] fp32): dq / dk come out with the RoPE backward already applied (no separate pass).
     transposed = (dqkvT [3*H*D, ldt], oT [H*D, ldt]) bf16: also filled with the token-contiguous copies of dq|dk|dv and o (columns
     b*S + s; columns >= B*S are left alone) -- the wgrad operands, without transpose passes. Needs S % 4 == 0, ldt % 4 == 0."""
@@ -579,13 +639,18 @@ def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, sca
         call("mla_attn_bwd_ws", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
              H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(tq), _p(tk), _p(tv), _p(to_), ldt, _p(ws), nbytes)
         return
+    sync = _head_sync(q.device, B, H) if merged is None or merged else None
+    if merged and sync is None:
+        raise RuntimeError("attn_bwd(merged=True): the one-launch backward is not available here "
+                           f"(MLA_ATTN_BWD_MERGED=0, a stream capture before the first use, or the dispatch probe failed: {_DISPATCH_OK})")
+    n_sync = sync.numel() if sync is not None else 0
     if transposed is not None:
         call("mla_attn_bwd_t", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
              H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(dqkvT[:H * D]), _p(dqkvT[H * D:2 * H * D]),
-             _p(dqkvT[2 * H * D:]), _p(oT), ldt)
+             _p(dqkvT[2 * H * D:]), _p(oT), ldt, _p(sync), n_sync)
         return
     call("mla_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
-         H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin))
+         H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(sync), n_sync)
 
 
 # --------------------------------------------------------------------------------------------- losses

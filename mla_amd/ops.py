@@ -49,13 +49,21 @@ def _is_touched(w) -> bool:
     return bool(getattr(w, "_mg_touched", False))
 
 
+def _assert_unlocked(*weights) -> None:
+    """Raises BEFORE anything is enqueued into main_grad of a parameter whose sharding unit's reduce-scatter has been launched in this
+    step (mla_amd/fsdp.py: zero_stale_and_lock): its gradient buffer is being read by the collective, or already holds the reduced
+    shard in place -- e.g. the same decoder layer run through backward twice in one step. (Advisor, round 5: the check used to sit only
+    in _mark_touched, i.e. AFTER the wgrad GEMM into the buffer had been queued.)"""
+    for w in weights:
+        region = getattr(w, "_mg_region", None)
+        owner = region[0] if region is not None else w
+        if getattr(owner, "_mg_locked", False):
+            raise RuntimeError("main_grad written after its sharding unit's reduce-scatter was launched in this step")
+
+
 def _mark_touched(w) -> None:
     region = getattr(w, "_mg_region", None)
-    owner = region[0] if region is not None else w
-    if getattr(owner, "_mg_locked", False):
-        # the owning unit's reduce-scatter has been launched (mla_amd/fsdp.py: zero_stale_and_lock): its gradient buffer is being read,
-        # or already holds the reduced shard in place -- e.g. the same decoder layer run through backward twice in one step
-        raise RuntimeError("main_grad written after its sharding unit's reduce-scatter was launched in this step")
+    _assert_unlocked(w)                                  # backstop: every writer checks before its launch
     if region is not None:
         region[0]._mg_regions[region[1]] = True
     else:
@@ -95,6 +103,7 @@ def deliver_wgrad(weights: Sequence[torch.Tensor], dy2: torch.Tensor, x2: torch.
     """dW_i = dy[:, slice_i]^T @ x for every weight; into main_grad when present, else returned as tensors."""
     grads: List[Optional[torch.Tensor]] = [None] * len(weights)
     mgs = [getattr(w, "main_grad", None) for w in weights]
+    _assert_unlocked(*[w for w, m, n in zip(weights, mgs, needs) if m is not None and n])
     if all(m is not None for m in mgs) and all(needs):
         mcat = cat_view(mgs)
         states = {_is_touched(w) for w in weights}
@@ -126,6 +135,7 @@ def _gemm_into_main_grad(weights, dyT, xT, out, accumulate: bool) -> None:
     """dW (+)= dyT xT^T into the fp32 gradient buffer. When the owner of the buffer collects the clipping norm itself (one process,
     no reduce-scatter: FlatUnit.sq_sink) the same launch also leaves sum(dW^2) of the final values as partial sums, so the norm
     never re-reads these 4 bytes per parameter (training/strategies/fsdp.py:308-310)."""
+    _assert_unlocked(*weights)
     sink = getattr(weights[0], "_sq_sink", None) if _WGRAD_SQ else None
     owner = getattr(sink, "__self__", None)      # (a bound method is a fresh object per access: compare the owners)
     if sink is not None and all(getattr(getattr(w, "_sq_sink", None), "__self__", None) is owner and
@@ -147,6 +157,7 @@ def deliver_wgrad_nt(weights: Sequence[torch.Tensor], dyT: torch.Tensor, xT: tor
     k-contiguous -> the fast NT kernel)."""
     grads: List[Optional[torch.Tensor]] = [None] * len(weights)
     mgs = [getattr(w, "main_grad", None) for w in weights]
+    _assert_unlocked(*[w for w, m, n in zip(weights, mgs, needs) if m is not None and n])
     if all(m is not None for m in mgs) and all(needs):
         mcat = cat_view(mgs)
         states = {_is_touched(w) for w in weights}

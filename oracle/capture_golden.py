@@ -92,6 +92,8 @@ def capture_e2e():
                   "vlm.llm_backbone.llm.coordinate_aware_contrastive_loss_module.image_projection_head.2.weight"):
             res[f"{mode}_grad::{k}"] = f(grads[k][:16, :64])
         res[f"{mode}_gradnorms"] = np.array([float(grads[k].float().norm()) for k in sorted(grads)], dtype=np.float64)
+        for k in sorted(grads):                        # round 6: an A and a C sample of EVERY parameter's gradient (recipe.grad_slice)
+            res[f"{mode}_gs::{k}"] = f(recipe.grad_slice(grads[k]))
         if mode == "A":
             res["grad_names"] = np.array(sorted(grads))
     np.savez_compressed(os.path.join(OUT, "mla_tiny_e2e.npz"), **res)

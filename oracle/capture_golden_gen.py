@@ -158,6 +158,8 @@ def capture_e2e_gen(R=2):
             res["param_names"] = np.array(sorted(shapes))
             res["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
         res[f"{mode}_gradnorms"] = np.array([float(grads[k].float().norm()) if k in grads else 0.0 for k in res["grad_names"]], dtype=np.float64)
+        for k in sorted(grads):                        # round 6: an A and a C sample of EVERY parameter's gradient (recipe.grad_slice)
+            res[f"{mode}_gs::{k}"] = f(recipe.grad_slice(grads[k]))
     np.savez_compressed(os.path.join(OUT, "mla_tiny_e2e_gen.npz"), **res)
     print("mla_tiny_e2e_gen.npz:", {k: float(v) for k, v in res.items() if k[:2] in ("A_", "C_") and np.ndim(v) == 0})
 

@@ -72,6 +72,8 @@ def main():
         for k, v in ld.items():
             res[f"{mode}_{k}"] = f(v)
         res[f"{mode}_gradnorms"] = np.array([float(grads[k].float().norm()) for k in sorted(grads)], dtype=np.float64)
+        for k in sorted(grads):                        # round 6: an A and a C sample of EVERY parameter's gradient (recipe.grad_slice)
+            res[f"{mode}_gs::{k}"] = f(recipe.grad_slice(grads[k]))
         for k in SLICES:
             g = grads[k]
             res[f"{mode}_grad::{k}"] = f(g.reshape(g.shape[0], -1)[:16, :64])

@@ -25,6 +25,31 @@ def test_library_exports_every_declared_symbol():
     assert set(hip.exported_symbols()) == set(syms), set(hip.exported_symbols()) ^ set(syms)
 
 
+def test_attention_object_allocates_nothing_and_keeps_no_state():
+    """kernels never allocate, no library-owned memory, no static scratch. Round 5's merged backward launch broke that in
+    one entry point (hipMalloc'ed per-stream counters behind a static std::map + mutex); round 6 made the counters caller-owned. Proved
+    on the object file: attention.o references no allocation / memset / memcpy entry point of the HIP runtime and no std::map / mutex."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    obj = os.path.join(ROOT, "mla_amd", "csrc", "build", "attention.o")
+    und = subprocess.run(["nm", "-u", "-C", obj], check=True, capture_output=True, text=True).stdout
+    bad = [ln.strip() for ln in und.splitlines()
+           if re.search(r"hipMalloc|hipFree|hipMemset|hipMemcpy|hipHostMalloc|std::_Rb_tree|pthread_mutex|std::mutex", ln)]
+    assert not bad, bad
+    # the product library does not carry the attention experiment kernels (attention_exp.inc is compiled with MLA_EXPERIMENTAL=1 only)
+    so = open(os.path.join(ROOT, "mla_amd", "libmla_hip.so"), "rb").read()
+    for name in (b"attn_bwd_fused_kernel", b"attn_bwd_dq5_kernel", b"attn_delta_kernel"):
+        assert name not in so, name
+    # argument validation of the caller-owned counters happens on the host
+    from mla_amd import hip
+    lib = hip.lib()
+    assert lib.mla_attn_bwd_sync_ints(32, 32) == 2048 and lib.mla_attn_bwd_sync_ints(1, 3) == 16 and lib.mla_attn_bwd_sync_ints(0, 3) == -1
+    P = ctypes.c_void_p(16)
+    rc = lib.mla_attn_bwd(P, P, P, P, P, P, None, P, P, P, P, 1, 64, 3, 128, 1152, 384, 0.1, None, None, ctypes.c_void_p(64), 8, None)
+    assert rc < 0 and b"head_sync needs" in lib.mla_last_error(), lib.mla_last_error()
+
+
 def test_query_and_error_plumbing():
     from mla_amd import hip
     lib = hip.lib()

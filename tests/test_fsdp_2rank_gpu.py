@@ -138,7 +138,7 @@ def _two_ranks(backend):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device (the 1-GPU box runs the gloo variant)")
 def test_two_rccl_ranks_match_single_process(dev):
     """The same comparison over the REAL collective path: two processes, one MI355X each, backend nccl (= RCCL over xGMI):
-    reduce_scatter_tensor(AVG) launched from the backward on the side stream, in-place all_gather_into_tensor behind the optimizer,
+    reduce_scatter_tensor(SUM, the mean folded into the scales) launched from the backward on the side stream, in-place all_gather_into_tensor behind the optimizer,
     scalar all-reduce of the gradient norm (training/strategies/fsdp.py:181-209, 308-310)."""
     r0, r1 = _two_ranks("nccl")
     _check_collective_exact(r0, r1)

@@ -200,6 +200,16 @@ def test_hook_launched_reduce_scatter_zeroes_stale_gradients_and_locks_the_unit(
     assert all(float(p.main_grad.abs().max()) == 0.0 and not p._mg_dirty for p in params[1:])
     with pytest.raises(RuntimeError, match="reduce-scatter was launched"):
         ops._mark_touched(params[1])
+    # (advisor, round 5) the writers check BEFORE enqueueing anything into the locked buffer: the wgrad entry points raise without
+    # having launched a GEMM -- with CPU tensors a launch would have raised a different error (no CPU path) first
+    w2 = next(p for p in params if p.dim() == 2)
+    before = w2.main_grad.clone()
+    dy, x = torch.zeros(4, w2.shape[0], dtype=torch.bfloat16), torch.zeros(4, w2.shape[1], dtype=torch.bfloat16)
+    for fn, args in ((ops.deliver_wgrad, ((w2,), dy, x, (True,))), (ops.deliver_wgrad_nt, ((w2,), dy.t().contiguous(), x.t().contiguous(), (True,))),
+                     (ops._gemm_into_main_grad, ((w2,), dy.t().contiguous(), x.t().contiguous(), w2.main_grad, False))):
+        with pytest.raises(RuntimeError, match="reduce-scatter was launched"):
+            fn(*args)
+    assert torch.equal(w2.main_grad, before)
     u.finish_backward(already_reduced=True)           # bookkeeping only; no stale-gradient error any more
     sm.begin_step()
     ops._mark_touched(params[1])                      # a new step unlocks the unit

@@ -9,7 +9,7 @@ Checks per N, tiny MLA, one sample per rank, two optimizer steps (the accumulati
       shards within 4 ulp (bit for bit at N = 2, where a sum has one order);
   (2) under RCCL every rank ends with bit-identical fp32 masters and bf16 replicas (the in-place all-gather delivered every slice);
   (3) RCCL vs gloo: fp32 masters after the first optimizer step to 1e-7 relative Frobenius, same gradient norms to 2e-5;
-  (4) MLA_FSDP_INPLACE_RS=0 (out-of-place AVG reduce-scatter, the fallback knob) gives the same shards within 4 ulp.
+  (4) MLA_FSDP_INPLACE_RS=0 (out-of-place SUM reduce-scatter into separate shard buffers, the fallback knob; ncclAvg is never used: round 6) gives the same shards within 4 ulp.
 Reference: training/strategies/fsdp.py:181-209 (FSDP full-shard wrapping), :308-310 (clip over the sharded gradients)."""
 import os
 import socket
@@ -85,7 +85,7 @@ def test_rccl_ranks_match_gloo_ranks(world):
         if world == 2:
             assert np.array_equal(got, _shards(gloo, name)), f"unit {name}: two-rank RCCL and gloo sums differ"
     print(f"RCCL x{world}: reduced shards vs float64 mean {worst['mean']:.2f} ulp, vs gloo {worst['gloo']:.2f} ulp, "
-          f"in-place SUM vs out-of-place AVG {worst['avg']:.2f} ulp")
+          f"in-place vs out-of-place SUM {worst['avg']:.2f} ulp")
     assert max(worst.values()) <= 4.0, worst
     for r in rccl[1:]:                                                     # (2)
         assert r["norms"] == rccl[0]["norms"]

@@ -380,8 +380,14 @@ def test_attention_bwd_five_product_form_matches_seven(dev, S, lens):
     """mla_attn_bwd_ws (delta pass -> dK / dV kernel storing dS^T -> one-product dQ kernel) against the two-kernel, seven-product
     backward on the same inputs, with the fused RoPE backward and the transposed copies: dk, dv (and their transposes, and o^T) come from
     the same dK / dV kernel and must be bit-equal up to what a last-bit difference of delta (another summation order) does through
-    dS; dq goes through bf16 dS^T in both forms. Ragged lengths, padding-only blocks, S not a multiple of 64 or 128."""
+    dS; dq goes through bf16 dS^T in both forms. Ragged lengths, padding-only blocks, S not a multiple of 64 or 128.
+    Round 6: the five-product pair is an experiment kernel (attention_exp.inc) -- the product library rejects the call."""
     from mla_amd import hip
+    if hip.lib().mla_query(3) != 1:
+        with pytest.raises(RuntimeError, match="experiment kernel"):
+            hip.attn_bwd(*([torch.zeros(64, 128, dtype=BF, device=dev)] * 5), torch.zeros(1, 1, 64, device=dev), None,
+                         *([torch.zeros(64, 128, dtype=BF, device=dev)] * 3), 1, 64, 1, 128, 128, 1.0, five=True)
+        pytest.skip("experiment kernels are not in the product build (mla_amd/csrc/build.sh with MLA_EXPERIMENTAL=1)")
     B, H, D = (4 if lens else 3), 3, 128
     g = torch.Generator().manual_seed(S)
     qkv = (torch.randn(B * S, 3 * H * D, generator=g) * 0.5).to(BF).to(dev)

@@ -7,7 +7,11 @@ transfer lasts about what a link-bound ring step would) exactly where ShardedMod
 layers' backward hooks, on a side stream, behind an event of the main stream, waited for before the gradient norm -- and measures the
 configs[1] step for k in {0, 8, 16, 32} CUs, with the workgroups either SHARING their CUs with GEMM workgroups or TAKING them (160 KiB
 of LDS each), and with the GEMMs planning their split-K tails for all 256 CUs or for the 256 - k that are left (mla_gemm_cus).
-Usage: python tools/contention_rehearsal.py [--steps 6] [--ms-per-layer 2.5]"""
+Round 6 (VERDICT r5 next #1c): --quick runs the six (k, sharing / taking) cases with the GEMMs planning for 256 CUs only and prints the
+loss and gradient norm of the last step of every case as hex floats: the one-launch attention backward (attn_bwd_merged_kernel, whose
+dK.dV workgroups WAIT for dQ workgroups of the same launch) runs next to the resident side-stream workgroups here for the first time.
+tools/contention_merged.sh runs it twice (default and MLA_ATTN_BWD_MERGED=0) and compares -> profiles/r6_contention_merged.txt.
+Usage: python tools/contention_rehearsal.py [--steps 6] [--ms-per-layer 2.5] [--quick]"""
 import argparse
 import json
 import os
@@ -27,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--ms-per-layer", type=float, default=2.5, help="target duration of one layer's stand-in transfer (80 ms / 32 layers)")
+    ap.add_argument("--quick", action="store_true", help="GEMM plan 256 only + hex loss / norm per case (merged-launch check)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -72,13 +77,15 @@ def main():
         inner_finish()
     sm.finish_backward = finish
 
+    last = {}
+
     def run(steps):
         spans.clear()
         strat.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            strat.train_step(batch)
+            last["out"] = strat.train_step(batch)
         strat.synchronize()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
@@ -117,11 +124,13 @@ def main():
     for lds, label in ((0, "sharing CUs"), (160 * 1024, "taking CUs (160 KiB LDS each)")):
         for k in (8, 16, 32):
             ticks, t_alone = calibrate(k, lds)
-            for plan in (0, 256 - k):
+            for plan in ((0,) if args.quick else (0, 256 - k)):
                 hip.gemm_cus(plan)
                 cfg.update(k=k, lds=lds, sleep=ticks)
                 ms, busy = run(args.steps)
                 hip.gemm_cus(0)
+                if args.quick:
+                    lines.append(f"    last step of this case: total_loss {float(last['out']['total_loss']).hex()} grad_norm {float(sm._norm).hex()}")
                 results.append(dict(k=k, mode=label, gemm_planned_cus=plan or 256, sleep_ticks=ticks, layer_transfer_alone_ms=round(t_alone, 2), ms_per_step=round(ms, 1),
                                     side_stream_busy_ms_per_step=round(busy, 1), slowdown_pct=round(100 * (ms / min(base) - 1), 2)))
                 lines.append(f"k = {k:2d} workgroups {label:30s} GEMMs planning for {plan or 256:3d} CUs: {ms:7.1f} ms per step ({100 * (ms / min(base) - 1):+5.2f} %), "
@@ -130,6 +139,8 @@ def main():
     tail = run(args.steps)[0]
     lines.append(f"baseline again: {tail:.1f} ms per step")
     print("\n".join(lines))
+    lines.append(f"attention backward form: {'one launch (merged), dispatch probe ' + str(hip._DISPATCH_OK) if hip.ATTN_BWD_MERGED else 'two launches (MLA_ATTN_BWD_MERGED=0)'}")
+    print(lines[-1])
     print(json.dumps(dict(baseline_ms=base + [tail], results=results, bytes_moved_per_layer=n_move * 4, note=__doc__.split("Usage")[0].strip()[:400])))
 
 

@@ -11,7 +11,7 @@
 #  2. tests/test_fsdp_2rank_gpu.py::test_two_rccl_ranks_match_single_process -- skipped on every 1-GPU box so far
 #  3. tests/test_fsdp_nrank_rccl_gpu.py -- N = 2 / 4 / 8 RCCL ranks vs the same ranks over gloo: drives the nccl branches of
 #     mla_amd/fsdp.py (_reduce_scatter: in-place SUM reduce_scatter_tensor; _all_gather: in-place all_gather_into_tensor), compares the
-#     reduced shards with gloo's bit for bit (N = 2) / within 4 fp32 ulp, and the out-of-place AVG fallback (MLA_FSDP_INPLACE_RS=0)
+#     reduced shards with gloo's bit for bit (N = 2) / within 4 fp32 ulp, and the out-of-place SUM fallback (MLA_FSDP_INPLACE_RS=0)
 #  4. bench.py --gpus 1, 2, 4, 8 (the driver's launch line) with the per-rank wait diagnostics in the JSON line
 #  5. the three knobs at N = 8: MLA_RCCL_MAX_CHANNELS (-> NCCL_MAX_NCHANNELS), MLA_FSDP_INPLACE_RS=0, MLA_GEMM_CUS
 #  6. the table (tools/first_node_table.py)
@@ -41,7 +41,7 @@ if [ -z "${SKIP_TESTS:-}" ]; then
   log "2. two RCCL ranks vs one process"
   (cd "$R" && timeout 1500 python -m pytest tests/test_fsdp_2rank_gpu.py -q -x -s -k rccl) > "$OUT/test_2rank_rccl.txt" 2>&1
   log "   rc=$? ($(tail -1 "$OUT/test_2rank_rccl.txt"))"
-  log "3. N = 2 / 4 / 8 RCCL ranks vs gloo ranks (in-place SUM reduce-scatter, in-place all-gather, AVG fallback)"
+  log "3. N = 2 / 4 / 8 RCCL ranks vs gloo ranks (in-place SUM reduce-scatter, in-place all-gather, out-of-place fallback)"
   (cd "$R" && timeout 3000 python -m pytest tests/test_fsdp_nrank_rccl_gpu.py -q -s) > "$OUT/test_nrank_rccl.txt" 2>&1
   rc=$?
   log "   rc=$rc ($(tail -1 "$OUT/test_nrank_rccl.txt"))"
