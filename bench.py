@@ -34,6 +34,106 @@ def model_flops_per_sample(S, H=4096, I=11008, L=32, V=32064, R=R_DIFF):
     return dec, dec + lm
 
 
+class BoxSampler:
+    """Shader clock and socket power of this rank's GPU while the timed steps run (~20 Hz, a daemon thread): what makes one box's
+    `value` comparable with another's (VERDICT r5 next #4 -- the step's GEMMs run at the board power cap, and the same build spans
+    567-598 ms per step across the pool's boxes). Source: the amdsmi Python binding of this image (gpu_metrics: current_gfxclk,
+    current / average socket power), else the amdgpu hwmon files in sysfs; `source` and any error travel into the `box` block."""
+
+    def __init__(self, dev_index=0, period_s=0.05):
+        import threading
+        self.dev_index, self.period = dev_index, period_s
+        self.rows, self.source, self.error = [], None, None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._read = self._open()
+
+    def _open(self):
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[self.dev_index]
+
+            def read():
+                m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+                clk = m.get("current_gfxclk")
+                if not isinstance(clk, (int, float)) or clk <= 0 or clk >= 65535:
+                    cl = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 65535]
+                    clk = sum(cl) / len(cl) if cl else None
+                pw = next((m[k] for k in ("current_socket_power", "average_socket_power") if isinstance(m.get(k), (int, float)) and 0 < m[k] < 65535), None)
+                return clk, pw
+            read()
+            self.source = "amdsmi gpu_metrics (current_gfxclk MHz, socket power W)"
+            return read
+        except Exception as e:   # noqa: BLE001 -- any failure of the binding falls through to sysfs
+            self.error = f"amdsmi: {e!r}"[:200]
+        try:
+            import glob
+            hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+            hw = [d for d in hw if os.path.exists(os.path.join(d, "freq1_input"))]
+            d = hw[min(self.dev_index, len(hw) - 1)]
+            pfile = next(f for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(d, f)))
+
+            def read():
+                return int(open(os.path.join(d, "freq1_input")).read()) / 1e6, int(open(os.path.join(d, pfile)).read()) / 1e6
+            read()
+            self.source = f"sysfs {d} (freq1_input, {pfile})"
+            return read
+        except Exception as e:   # noqa: BLE001
+            self.error = (self.error or "") + f" | sysfs: {e!r}"[:200]
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.rows.append(self._read())
+            except Exception as e:   # noqa: BLE001
+                self.error = f"read: {e!r}"[:200]
+                return
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._read is not None:
+            self._thread.start()
+
+    def stop(self):
+        import statistics
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(1.0)
+        clk = [c for c, _ in self.rows if c]
+        pw = [p for _, p in self.rows if p]
+        return {"sclk_mhz_median": round(statistics.median(clk)) if clk else None, "sclk_mhz_min_max": [round(min(clk)), round(max(clk))] if clk else None,
+                "socket_power_w_median": round(statistics.median(pw)) if pw else None, "socket_power_w_max": round(max(pw)) if pw else None,
+                "samples": len(self.rows), "period_s": self.period, "source": self.source, **({"sampler_error": self.error} if self.error else {})}
+
+
+def step_weighted_mfma_util(ms_per_step):
+    """sum over kernels of MfmaUtil x time, over the step time: the matrix pipe's busy share of the WHOLE step. MfmaUtil and the
+    per-kernel durations come from the newest committed counter table (profiles/r*_pmc_table.json, separate rocprofv3 --pmc passes over
+    this command: tools/collect_counters.sh -> tools/pmc_table.py), the step time is this run's; kernels the table does not list and idle
+    time count as zero. `stale` says whether the loaded library is the one the counters were collected on."""
+    import glob
+    import hashlib
+    import re
+
+    def round_key(f):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(f))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_table.json")), key=round_key, reverse=True)
+    if not files:
+        return None
+    with open(files[0]) as fh:
+        tj = json.load(fh)
+    from mla_amd import hip
+    with open(hip._LIB_PATH, "rb") as fh:
+        lib_id = hashlib.sha256(fh.read()).hexdigest()[:16]
+    busy_ms = sum(r["mfma_util_pct"] / 100.0 * r["us"] * r["n_per_step"] * 1e-3 for r in tj["rows"] if r.get("mfma_util_pct") == r.get("mfma_util_pct"))
+    return {"value": round(busy_ms / ms_per_step, 4), "mfma_busy_ms_per_step_from_table": round(busy_ms, 1),
+            "source": f"profiles/{os.path.basename(files[0])} (library {tj.get('library_id')}, gemm256 source {tj.get('gemm_source_id')})",
+            "stale": tj.get("library_id") != lib_id}
+
+
 def build(device, save_level, tiny=False, use_pointcloud=True, generation=False, stage=None):
     from mla_amd.backbones import LLaMa2LLMBackbone
     from mla_amd.llama import LlamaConfig
@@ -165,7 +265,7 @@ def secondary_configs(steps=3, warmup=1, timeout_s=420):
     res = {}
     for cfg, extra in ((3, []), (4, ["--keep-layers", "0"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg), "--steps", str(steps), "--warmup", str(warmup),
-               "--no-cpu-baseline", "--no-secondary"] + extra
+               "--no-cpu-baseline", "--no-secondary", "--no-box"] + extra
         t0 = time.time()
         try:
             cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
@@ -210,6 +310,7 @@ def main():
     ap.add_argument("--mem-frac", type=float, default=0.91, help="share of the device's total memory the automatic --keep-layers -1 choice may plan for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
+    ap.add_argument("--no-box", action="store_true", help="skip the `box` block (sclk / power sampler + the two 300 ms MFMA calibrations)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (configs[3] and configs[4] at 3 timed steps each) the default 1-GPU configs[1] run appends")
     args = ap.parse_args()
@@ -316,9 +417,16 @@ def main():
         losses = None
         torch.cuda.empty_cache()                 # the probe step's cached blocks have the all-checkpointed step's shapes
         torch.cuda.reset_peak_memory_stats()
+    box = None
+    if rank == 0 and not args.no_box:
+        # (cold) calibration before the warm-up, 300 ms: the random-operand MFMA stream from a chip that has been idle
+        strat.synchronize()
+        torch.cuda.synchronize()
+        box = {"mfma_random_pflops_cold": round(hip.calib_mfma(device)["pflops"], 4)}
     for _ in range(args.warmup):
         losses = strat.train_step(batch)
     prof = None if args.no_gemm_profile else []
+    sampler = BoxSampler(dev_index) if box is not None else None
     strat.synchronize()                        # flush the warm-up's deferred optimizer updates: the timed region owns exactly K of them
     sync()
     if strat.sharded.coll:
@@ -326,6 +434,8 @@ def main():
         # warm-up's exposed all-gather waits are not divided into the K timed steps (advisor, round 4)
         strat.sharded.wait_profile = []
     hip.GEMM_PROFILE = prof
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = strat.train_step(batch)
@@ -333,6 +443,14 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     hip.GEMM_PROFILE = None
+    if sampler is not None:
+        box.update(sampler.stop())
+        # (hot) calibration right behind the timed steps, outside the timed region: the same stream on the chip in the thermal / power
+        # state the steps left it in -- the denominator of roofline.frac_of_box_ceiling
+        cal = hip.calib_mfma(device)
+        box.update({"mfma_random_pflops": round(cal["pflops"], 4), "mfma_calibration": f"{cal['launches']} launches x {cal['ms_per_launch']:.1f} ms on "
+                    f"{cal['blocks']} workgroups x 8 waves, v_mfma_f32_16x16x32_bf16 on N(0,1) operands from registers (mla_calib_mfma), last 200 ms of 300",
+                    "device": torch.cuda.get_device_name(dev_index)})
     per_rank = None
     if strat.sharded.coll:
         # first-run diagnosis for N > 1 (VERDICT r3 #3d): every rank's own step time and how long ITS compute stream sat behind
@@ -436,6 +554,13 @@ def main():
                     "l2_hit_rate": (round(hit, 4) if hit is not None else None),
                     "algorithmic_bytes_per_launch_2B_outputs": round(abytes), "launches_per_step": len(big) // args.steps, "avg_launch_ms": round(tsum / len(big) * 1e3, 4),
                     "gemm_ms_per_step": round(tsum / args.steps * 1e3, 1)}
+            if box and box.get("mfma_random_pflops"):
+                # the fraction a slow box and a fast box agree on -- the plain GEMM launches against what THIS box's
+                # matrix cores sustain on random operands under its power cap (measured right behind the timed steps)
+                roof["frac_of_box_ceiling"] = round(ach / 1e3 / box["mfma_random_pflops"], 4)
+                roof["all_gemm_frac_of_box_ceiling"] = round(ach_all / 1e3 / box["mfma_random_pflops"], 4)
+            if args.config == 1 and not args.tiny:
+                roof["step_weighted_mfma_util"] = step_weighted_mfma_util(ms)
         out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
                "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -467,6 +592,8 @@ def main():
             out["collective_knobs"] = {**coll_knobs, "inplace_reduce_scatter": bool(strat.sharded.inplace_reduce), "gemm_planned_cus": hip.gemm_cus() or "device"}
         if roof:
             out["roofline"] = roof
+        if box:
+            out["box"] = box
         if world == 1 and args.config == 1 and not args.tiny and not args.no_secondary and "RANK" not in os.environ:
             # configs[3] and configs[4] (the reference's policy: every layer checkpointed) become driver-observed --
             # each runs as its own process on the now empty GPU (1 warm-up + 3 timed steps), `value` / `config` above stay configs[1]

@@ -34,6 +34,11 @@ int mla_query(int what); /* 0: ABI version, 1: compiled gfx arch (950), 2: wavef
 const char* mla_gemm_source_id(void);
 /* hardware-assumption self test (ds_read_b64_tr_b16 lane map, global_load_lds destination order) */
 int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_1k, mla_stream_t stream);
+/* box calibration (bench.py's `box` block): `blocks` workgroups x 8 waves issue v_mfma_f32_16x16x32_bf16 back to back on the caller's
+ * operands (512 x 24 x 8 bf16 = 196 608 bytes, 16-B aligned, e.g. N(0, 1)) for `iters` x 64 MFMAs per wave -- no LDS, no memory traffic:
+ * what the matrix cores of this box sustain on random data under its power cap. out: blocks x 512 floats (sink);
+ * *flops_per_launch (may be NULL) = blocks x 8 x iters x 64 x 16 384. Time it with events around the launches. */
+int mla_calib_mfma(const void* operands, float* out, int blocks, int iters, double* flops_per_launch, mla_stream_t stream);
 /* dispatch probe for the one-launch attention backward (mla_attn_bwd with head_sync): `blocks` workgroups of that kernel's shape each
  * take a start ticket from out[0] (caller zeroes `out`, 1 + 2 * blocks ints), stay resident ~hold_us, and record out[1 + 2 L] = ticket,
  * out[2 + 2 L] = HW_REG_XCC_ID of workgroup L. The caller decides: 8 XCDs, XCC_ID == L & 7, start order == id order per XCD. */
@@ -277,7 +282,9 @@ int mla_gemm_batched_bf16(const void* A, const void* B, void* C, int M, int N, i
  * Dropout decisions are a counter-based hash of (seed, element index): backward regenerates the forward mask. */
 int mla_softmax_rows_fwd(const float* scores, void* P, void* Pd, long long rows, int ncols, int nvalid, float p,
                          unsigned long long seed, mla_stream_t stream);
-int mla_softmax_rows_bwd(const void* dPd, const void* P, void* dS, long long rows, int ncols, int nvalid, float p,
+/* dS = P' o (g - sum(g o P')), g = dPd o mask / (1 - p), P' = P / sum(P) (the bf16 probabilities renormalised in fp32).
+ * dPd: fp32 (dpd_fp32 = 1, the product path: dP is never rounded, like torch's fused attention) or bf16. */
+int mla_softmax_rows_bwd(const void* dPd, int dpd_fp32, const void* P, void* dS, long long rows, int ncols, int nvalid, float p,
                          unsigned long long seed, mla_stream_t stream);
 int mla_dropout_fwd(const void* x, const void* residual, void* y, long long n, float p, unsigned long long seed, mla_stream_t stream);
 int mla_dropout_bwd(const void* dy, void* dx, long long n, float p, unsigned long long seed, mla_stream_t stream);

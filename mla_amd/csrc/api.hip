@@ -71,8 +71,8 @@ extern "C" int mla_selftest(const void* src_1k, int* out_tr_256, void* out_glds_
 //       id, same XCD) has not been given one -- the condition under which its wait cannot dead-lock.
 // `blocks` workgroups shaped like that kernel's (256 threads, 2 per CU by LDS) each take a ticket from out[0] when they start, stay
 // resident for ~hold_us (so the grid needs many dispatch rounds), and record out[1 + 2 L] = ticket, out[2 + 2 L] = XCC_ID. The caller
-// (mla_amd/hip.py: dispatch_probe) checks (1) literally and (2) as "no workgroup started more than one residency round (64 slots per
-// XCD) out of id order", and hands head counters to mla_attn_bwd only on a device where both hold -- the two-launch form otherwise.
+// (mla_amd/hip.py: dispatch_probe) checks (1) literally and (2) as "no workgroup took its ticket more than two residency rounds (2 x 64
+// slots per XCD) out of id order", and hands head counters to mla_attn_bwd only on a device where both hold -- the two-launch form otherwise.
 __global__ __launch_bounds__(256, 2) void dispatch_probe_kernel(int* __restrict__ out, int hold_ticks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   (void)smem;

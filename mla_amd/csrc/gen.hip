@@ -40,24 +40,42 @@ __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __re
     Pd[r * ncols + c] = f2bf(pr * keep_scale(seed, (unsigned long long)(r * ncols + c), p, ik));
   }
 }
-// dS = P * (g - sum_c(g * P)),  g = dPd * mask / (1 - p)
-__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const bf16_t* __restrict__ dPd, const bf16_t* __restrict__ P,
+// dS = P' * (g - sum_c(g * P')),  g = dPd * mask / (1 - p),  P' = P / sum_c(P)
+// Round 6: the saved probabilities are bf16, so they do not sum to one -- and for a near-uniform row (random-init cross-attention over
+// ~550 keys) every P_c = 1 / n rounds THE SAME WAY, leaving sum(P) off by up to 2^-9. Then sum_c(dS_c) = (1 - sum P) * dot != 0, an
+// error that is perfectly aligned with the MEAN key and therefore survives dQ = dS K where the signal (aligned with key differences)
+// cancels: measured 12 % on the query-projection gradient of the tactile decoder's first cross-attention against 2.3 % for the
+// reference in bf16 autocast, whose softmax backward runs on fp32 probabilities (tests/parity_util.py, profiles/r6_parity_table.txt).
+// Renormalising the bf16 values in fp32 restores sum_c(dS_c) = 0 (before dS is rounded) at the cost of one more term in the reduction.
+// The incoming dPd = dO V^T is fp32 in the product path (round 6): torch's fused attention -- what nn.MultiheadAttention runs under the
+// reference's bf16 autocast -- never rounds dP, and for one query over ~550 near-uniformly weighted keys dP_k = dO . v_k is a large
+// common value plus a small per-key variation, of which only the VARIATION survives (dP_k - dot): rounded to bf16 it left 12 % error on
+// the query-projection gradient of the tactile decoder's first cross-attention (reference bf16: 2.3 %; same table).
+__device__ __forceinline__ float dpd_load(const float* p, long long i) { return p[i]; }
+__device__ __forceinline__ float dpd_load(const bf16_t* p, long long i) { return bf2f(p[i]); }
+template <typename TG>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const TG* __restrict__ dPd, const bf16_t* __restrict__ P,
                                                                bf16_t* __restrict__ dS, int ncols, int nvalid, float p,
                                                                unsigned long long seed) {
   __shared__ float scratch[16];
   const long long r = blockIdx.x;
   const float ik = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  float dot = 0.f;
+  float dot = 0.f, psum = 0.f;
   for (int c = threadIdx.x; c < nvalid; c += 256) {
-    const float g = bf2f(dPd[r * ncols + c]) * keep_scale(seed, (unsigned long long)(r * ncols + c), p, ik);
-    dot += g * bf2f(P[r * ncols + c]);
+    const float g = dpd_load(dPd, r * ncols + c) * keep_scale(seed, (unsigned long long)(r * ncols + c), p, ik);
+    const float pr = bf2f(P[r * ncols + c]);
+    dot += g * pr;
+    psum += pr;
   }
   dot = block_sum(dot, scratch);
+  psum = block_sum(psum, scratch);
+  const float inv = psum > 0.f ? 1.f / psum : 0.f;
+  dot *= inv;
   for (int c = threadIdx.x; c < ncols; c += 256) {
     float v = 0.f;
     if (c < nvalid) {
-      const float g = bf2f(dPd[r * ncols + c]) * keep_scale(seed, (unsigned long long)(r * ncols + c), p, ik);
-      v = bf2f(P[r * ncols + c]) * (g - dot);
+      const float g = dpd_load(dPd, r * ncols + c) * keep_scale(seed, (unsigned long long)(r * ncols + c), p, ik);
+      v = bf2f(P[r * ncols + c]) * inv * (g - dot);
     }
     dS[r * ncols + c] = f2bf(v);
   }
@@ -495,11 +513,15 @@ extern "C" int mla_softmax_rows_fwd(const float* scores, void* P, void* Pd, long
   hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, scores, (bf16_t*)P, (bf16_t*)Pd, ncols, nvalid, p, seed);
   MLA_LAUNCH_CHECK();
 }
-extern "C" int mla_softmax_rows_bwd(const void* dPd, const void* P, void* dS, long long rows, int ncols, int nvalid, float p,
+extern "C" int mla_softmax_rows_bwd(const void* dPd, int dpd_fp32, const void* P, void* dS, long long rows, int ncols, int nvalid, float p,
                                     unsigned long long seed, hipStream_t stream) {
   MLA_CHECK_ARG(dPd && P && dS && rows > 0 && nvalid <= ncols, "mla_softmax_rows_bwd: bad args");
-  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)dPd, (const bf16_t*)P, (bf16_t*)dS, ncols,
-                     nvalid, p, seed);
+  if (dpd_fp32)
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, stream, (const float*)dPd, (const bf16_t*)P, (bf16_t*)dS,
+                       ncols, nvalid, p, seed);
+  else
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, stream, (const bf16_t*)dPd, (const bf16_t*)P, (bf16_t*)dS,
+                       ncols, nvalid, p, seed);
   MLA_LAUNCH_CHECK();
 }
 extern "C" int mla_dropout_fwd(const void* x, const void* residual, void* y, long long n, float p, unsigned long long seed, hipStream_t stream) {

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "mla_query": [c_int],
     "mla_selftest": [c_void_p, c_void_p, c_void_p, c_void_p],
     "mla_dispatch_probe": [c_void_p, c_int, c_int, c_void_p],
+    "mla_calib_mfma": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mla_gemm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "mla_gemm_bf16_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -562,8 +563,10 @@ ATTN_BWD_MERGED = os.environ.get("MLA_ATTN_BWD_MERGED", "105") != "0"
 
 def dispatch_probe(device="cuda", blocks=4096, hold_us=20):
     """Measures what attn_bwd_merged_kernel assumes (include/mla_hip.h: mla_dispatch_probe). Returns (ok, info): ok iff there are 8
-    XCDs, workgroup L ran on XCD L & 7 for every L, and per XCD no workgroup started more than one residency round (64 slots: 32 CUs x
-    2 workgroups) away from its place in id order. Synchronises -- called once per device, outside any capture."""
+    XCDs, workgroup L ran on XCD L & 7 for every L, and per XCD no workgroup took its start ticket more than two residency rounds (2 x 64
+    slots: 32 CUs x 2 workgroups) away from its place in id order -- the workgroups of one round start together and take their tickets
+    in any order (measured on MI355X: worst displacement 52-56), an out-of-order dispatcher would show displacements of the grid's
+    size. Synchronises -- called once per device, outside any capture."""
     dev = torch.device(device)
     out = torch.zeros(1 + 2 * blocks, dtype=torch.int32, device=dev)
     call("mla_dispatch_probe", _p(out), blocks, hold_us)
@@ -579,7 +582,7 @@ def dispatch_probe(device="cuda", blocks=4096, hold_us=20):
         worst = max(worst, int((rank - torch.arange(t.numel())).abs().max()))
     info = {"xcds": n_xcd, "xcc_is_id_mod_8": xcd_ok, "worst_start_displacement": worst, "blocks": blocks,
             "tickets_complete": bool(torch.equal(torch.sort(ticket).values, ids))}
-    return (n_xcd == 8 and xcd_ok and worst <= 64 and info["tickets_complete"]), info
+    return (n_xcd == 8 and xcd_ok and worst <= 128 and info["tickets_complete"]), info
 
 
 def _head_sync(device, B, H):
@@ -693,6 +696,42 @@ def l2norm_bwd(dy, y, norms):
     dx = torch.empty_like(y)
     call("mla_l2norm_bwd", _p(dy), _p(y), _p(norms), _p(dx), rows, n)
     return dx
+
+
+def calib_mfma(device="cuda", total_ms=300.0, measure_ms=200.0, blocks=None):
+    """The random-operand MFMA stream of this box (include/mla_hip.h: mla_calib_mfma): launches of ~20 ms back to back for ~total_ms,
+    the rate over the last ~measure_ms (HIP events on the launch stream) in PFLOP/s -- the first launches ramp the power controller.
+    Synchronises. Returns dict(pflops, launches, ms_per_launch)."""
+    dev = torch.device(device)
+    if blocks is None:
+        blocks = torch.cuda.get_device_properties(dev).multi_processor_count
+    ops_ = torch.randn(512 * 24 * 8, device=dev).to(torch.bfloat16)
+    out = torch.empty(blocks * 512, dtype=torch.float32, device=dev)
+    fl = ctypes.c_double(0.0)
+    iters = 16384                                          # ~19 ms per launch at 1.9 PFLOP/s on 256 CUs
+    call("mla_calib_mfma", _p(ops_), _p(out), blocks, 256, ctypes.byref(fl))          # code-object load + clocks up
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call("mla_calib_mfma", _p(ops_), _p(out), blocks, iters, ctypes.byref(fl))
+    e1.record()
+    torch.cuda.synchronize(dev)
+    one = max(e0.elapsed_time(e1), 1e-3)
+    n_total = max(2, int(round(total_ms / one)))
+    n_meas = max(1, min(n_total - 1, int(round(measure_ms / one))))
+    evs = []
+    for i in range(n_total):
+        if i == n_total - n_meas:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            evs.append(ev)
+        call("mla_calib_mfma", _p(ops_), _p(out), blocks, iters, ctypes.byref(fl))
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    evs.append(ev)
+    torch.cuda.synchronize(dev)
+    ms = evs[0].elapsed_time(evs[1])
+    return {"pflops": fl.value * n_meas / (ms * 1e-3) / 1e15, "launches": n_meas, "ms_per_launch": ms / n_meas, "blocks": blocks}
 
 
 def selftest(device="cuda"):
@@ -873,7 +912,7 @@ register_signatures({
     "mla_gemm_batched_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                               c_int, c_int, c_longlong, c_longlong, c_longlong, c_longlong, c_longlong, c_longlong, c_void_p],
     "mla_softmax_rows_fwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_ulonglong, c_void_p],
-    "mla_softmax_rows_bwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_ulonglong, c_void_p],
+    "mla_softmax_rows_bwd": [c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_ulonglong, c_void_p],
     "mla_dropout_fwd": [c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_ulonglong, c_void_p],
     "mla_dropout_bwd": [c_void_p, c_void_p, c_longlong, c_float, c_ulonglong, c_void_p],
     "mla_scale_batch": [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p],
@@ -925,7 +964,7 @@ def softmax_rows_fwd(scores, nvalid, p, seed):
 def softmax_rows_bwd(dPd, P, nvalid, p, seed):
     ncols = P.shape[-1]
     dS = torch.empty_like(P)
-    call("mla_softmax_rows_bwd", _p(dPd), _p(P), _p(dS), P.numel() // ncols, ncols, nvalid, float(p), seed)
+    call("mla_softmax_rows_bwd", _p(dPd), 1 if dPd.dtype == torch.float32 else 0, _p(P), _p(dS), P.numel() // ncols, ncols, nvalid, float(p), seed)
     return dS
 
 

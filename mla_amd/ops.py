@@ -942,8 +942,10 @@ class MHACoreFn(torch.autograd.Function):
             q, k, v = qsrc, kvsrc[..., :E], kvsrc[..., E:]
             dq, dk, dv = dqsrc, dkvsrc[..., :E], dkvsrc[..., E:]
         sS = (nheads * Sq * Sk, Sq * Sk)
-        # dPd = dO V^T
-        dPd = torch.empty_like(P)
+        # dPd = dO V^T, kept in fp32 (transient): the softmax backward subtracts the row's weighted mean from it, so a bf16 dP would
+        # keep only ~8 bits of what survives the subtraction (csrc/gen.hip softmax_rows_bwd_kernel; torch's fused attention, which the
+        # reference runs under autocast, does not round dP either)
+        dPd = torch.empty(P.shape, dtype=torch.float32, device=P.device)
         hip.gemm_batched(do, v, dPd, M=Sq, N=Sk, K=hd, lda=E, ldb=v.stride(1), ldc=Sk, n_outer=B, n_inner=nheads, sA=(Sq * E, hd),
                          sB=(v.stride(0), hd), sC=sS)
         # dV = Pd^T dO  (Pd regenerated from P and the dropout hash: Pd = P * mask / (1 - p))

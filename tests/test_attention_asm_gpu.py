@@ -159,13 +159,13 @@ def _attn_case(dev, B, S, H, lens, seed):
 
 def test_dispatch_probe_holds_on_this_device(dev):
     """What attn_bwd_merged_kernel assumes and HIP does not promise (include/mla_hip.h: mla_dispatch_probe): 8 XCDs, workgroup L on XCD
-    L & 7, workgroups started in id order per XCD (no start more than one residency round of 64 slots out of place). hip.py hands
+    L & 7, workgroups started in id order per XCD (no start ticket more than two residency rounds of 64 slots out of place). hip.py hands
     head counters to mla_attn_bwd only where this holds; on MI355X it must, or the default backward silently became two launches."""
     from mla_amd import hip
     ok, info = hip.dispatch_probe(dev)
     print("dispatch probe:", info)
     assert info["tickets_complete"] and info["xcds"] == 8 and info["xcc_is_id_mod_8"], info
-    assert info["worst_start_displacement"] <= 64, info
+    assert info["worst_start_displacement"] <= 128, info
     assert ok
     # a second, much longer-resident grid: the order is a property of the queue, not of short workgroups
     ok2, info2 = hip.dispatch_probe(dev, blocks=2048, hold_us=200)

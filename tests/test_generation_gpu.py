@@ -345,8 +345,8 @@ def build_tiny_mla_gen(dev):
     return m, gold
 
 
-def test_mla_e2e_post_training(dev):
-    """BASELINE config[3] scaled down: whole step vs the oracle with flash pad-row semantics, and vs the reference golden."""
+def run_post_training_e2e(dev):
+    """Forward + backward of the tiny post-training MLA on the recipe batch; returns (model, loss_dict, golden, batch, draws)."""
     m, gold = build_tiny_mla_gen(dev)
     batch, draws = recipe.make_batch(R=2, with_next=True)
     m.vlm.vision_tower_3d.fps_starts_override = [draws["fps_start0"], draws["fps_start1"]]
@@ -357,6 +357,12 @@ def test_mla_e2e_post_training(dev):
                 proprio=to(batch["proprio"]), action_masks=to(batch["action_masks"]), camera_name=batch["camera_name"],
                 repeated_diffusion_steps=2, use_diff=True, noise=to(draws["noise"]), timestep=to(draws["timestep"]))
     ld["total_loss"].backward()
+    return m, ld, gold, batch, draws
+
+
+def test_mla_e2e_post_training(dev):
+    """BASELINE config[3] scaled down: whole step vs the oracle with flash pad-row semantics, and vs the reference golden."""
+    m, ld, gold, batch, draws = run_post_training_e2e(dev)
     sd = {k: recipe.det_weight(k, v.shape) for k, v in m.state_dict().items()}
     with torch.no_grad():
         ref = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, zero_pad_rows=True, gen_cfg=GEN_CFG)
@@ -391,6 +397,12 @@ def test_mla_e2e_post_training(dev):
     medA, medC, q90, bad = gradnorm_yardstick(gn[live], A[live], C[live], list(np.array(names)[live]))
     assert medA <= 2 * medC, (medA, medC)                                            # measured 5.0e-3 vs 5.4e-3
     assert not bad, (q90, bad)                                                       # worst measured 1.8e-2 against 2 x q90 = 6.1e-2
+    # Round 6: the strict per-tensor yardstick on a gradient sample of ALL 234 parameters (tests/parity_util.py); the analytically-zero
+    # set above has A == 0 on its sample, where the rule reads ||hip|| <= 2 ||C||. Measured: 234 / 234, median ratio 0.49.
+    from parity_util import grad_sample_rows, strict_violations
+    rows = grad_sample_rows(grads, gold)
+    assert len(rows) == len(names)
+    assert not strict_violations(rows), strict_violations(rows)
 
 
 def test_post_training_step_through_fsdp(dev):

@@ -355,6 +355,13 @@ def test_mla_e2e_against_reference_golden(dev, e2e):
             g = grads[n].float().cpu()
             g = (g if tuple(g.shape) == A.shape else g[:16, :64]).numpy()
             assert err(g, A) <= 2 * err(C, A), (n, err(g, A), err(C, A))            # measured ratios 0.15 .. 0.53
+    # Round 6: the strict yardstick on EVERY parameter -- err(hip, A) <= 2 x err(C, A) on a 64 x 64 corner (or the
+    # whole tensor) of all 116 gradients, not on the 11 captured above; the percentile rule stays for the scalar norms only.
+    # Measured: 116 / 116 within 2 x mode C, median ratio 0.44 (profiles/r6_parity_table.txt); no exceptions.
+    from parity_util import grad_sample_rows, strict_violations
+    rows = grad_sample_rows(grads, e2e)
+    assert len(rows) == len(names) == 116
+    assert not strict_violations(rows), strict_violations(rows)
 
 
 def test_mla_e2e_against_oracle_flash_semantics(dev):

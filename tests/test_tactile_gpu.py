@@ -31,7 +31,8 @@ def test_bmm_nt_fwd_bwd(dev):
     assert fro_rel(ad.grad, ar.grad) < 1e-2 and fro_rel(bd.grad, br.grad) < 1e-2
 
 
-def test_mla_e2e_tactile(dev):
+def run_tactile_e2e(dev):
+    """Builds the tiny MLA with tactile + generation heads, runs forward + backward on the recipe batch; returns (model, loss_dict, golden)."""
     from mla_amd.backbones import LLaMa2LLMBackbone
     from mla_amd.llama import LlamaConfig
     from mla_amd.mla import MLA
@@ -61,6 +62,13 @@ def test_mla_e2e_tactile(dev):
                 camera_name=batch["camera_name"], repeated_diffusion_steps=2, use_diff=True, noise=to(draws["noise"]),
                 timestep=to(draws["timestep"]))
     ld["total_loss"].backward()
+    run_tactile_e2e.last_inputs = (batch, draws)
+    return m, ld, gold
+
+
+def test_mla_e2e_tactile(dev):
+    m, ld, gold = run_tactile_e2e(dev)
+    batch, draws = run_tactile_e2e.last_inputs
     for key in ("total_loss", "tactile_contrastive_loss", "tactile_gen_loss", "img_pc_contrastive_loss"):
         A, C = float(gold["A_" + key]), float(gold["C_" + key])
         assert abs(float(ld[key]) - A) < 2 * abs(C - A) + 3e-2, (key, float(ld[key]), A, C)
@@ -83,3 +91,29 @@ def test_mla_e2e_tactile(dev):
             g = grads[n].float().cpu()
             got = g.reshape(g.shape[0], -1)[:16, :64].numpy()
             assert err(got, Ag) < 2 * err(Cg, Ag) + 3e-2, (n, err(got, Ag), err(Cg, Ag))
+    # Round 6: the strict per-tensor yardstick, no floor, on a gradient sample of EVERY parameter (tests/parity_util.py). Its first run
+    # found one tensor at 5.3 x mode C -- the query rows of the tactile decoder's first cross-attention: bf16 probabilities of a
+    # near-uniform row do not sum to one, the softmax backward now renormalises them (csrc/gen.hip softmax_rows_bwd_kernel).
+    from parity_util import grad_sample_rows, strict_violations
+    rows = grad_sample_rows(grads, gold)
+    assert len(rows) == len(names)
+    # ONE named exception, measured and explained (profiles/r6_parity_table.txt): the query rows of the tactile decoder's first
+    # cross-attention. That layer's single learned query attends to ALL LLM states with no key-padding mask, and
+    # its query gradient is a covariance over the ~550 keys in which the 3 pad rows of the ragged samples weigh heavily. The golden was
+    # captured with the reference's eager attention (pad queries attend to earlier keys); the kernels have the flash / varlen semantics of
+    # the reference's GPU path (pad rows -> zero attention output). The fp32 oracle reproduces the golden to 1.8e-6 with eager semantics
+    # and sits at 1.25e-1 with flash semantics -- exactly where the HIP path sits (1.21e-1; tools/experiments/dbg_tactile_qgrad.py: an
+    # fp32 torch attention core in place of the kernels changes nothing). So this tensor is compared, under the same yardstick, with the
+    # oracle run with the kernels' own pad-row semantics.
+    KEY = "vlm.generation_manager.tactile_gen_module.decoder.layers.0.multihead_attn.in_proj_weight"
+    assert not strict_violations(rows, {KEY}), strict_violations(rows, {KEY})
+    from oracle import mla_oracle
+    sd = {k: recipe.det_weight(k, v.shape) for k, v in m.state_dict().items()}
+    sd[KEY].requires_grad_(True)
+    ref = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, zero_pad_rows=True, use_tactile=True, gen_tactile=True)
+    (gflash,) = torch.autograd.grad(ref["total_loss"], sd[KEY])
+    gflash = recipe.grad_slice(gflash).numpy()
+    mine = recipe.grad_slice(grads[KEY].float().cpu()).numpy()
+    yard = err(gold["C_gs::" + KEY], gold["A_gs::" + KEY])                 # the reference's own bf16 spread on this tensor: 2.3e-2
+    assert err(gflash, gold["A_gs::" + KEY]) > 5 * yard                     # the semantics really differ here (else drop the exception)
+    assert err(mine, gflash) <= 2 * yard, (err(mine, gflash), yard)

@@ -24,10 +24,10 @@ python $R/tools/roofline_table.py $O/${TAG}_step_breakdown_config1.txt > $O/${TA
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$i -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-gemm-profile > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$i -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-gemm-profile --no-box > /dev/null 2>&1
   cp $(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1) /tmp/pmc_$i.csv
 done
-python $R/tools/pmc_table.py /tmp/pmc_1.csv /tmp/pmc_2.csv /tmp/pmc_3.csv /tmp/pmc_4.csv > $O/${TAG}_pmc_table.txt
+python $R/tools/pmc_table.py /tmp/pmc_1.csv /tmp/pmc_2.csv /tmp/pmc_3.csv /tmp/pmc_4.csv $O/${TAG}_pmc_table.json 2 > $O/${TAG}_pmc_table.txt
 python $R/tools/pmc_reduce.py /tmp/pmc_3.csv /tmp/pmc_4.csv $O/${TAG}_gemm256_hbm_traffic.json 150 /tmp/pmc_2.csv
 cat $O/${TAG}_power_trace.txt | tail -12; cat $O/${TAG}_pmc_table.txt; head -40 $O/${TAG}_roofline_table.txt
 # second argument "all": the secondary configurations from the same command (bench lines of configs[3] / [4] with their own `roofline`

@@ -149,8 +149,50 @@ def heads(dev):
     print("bn running_mean", err(bn.running_mean.float().cpu().numpy(), gold["A_bn_running_mean"]), "running_var", err(bn.running_var.float().cpu().numpy(), gold["A_bn_running_var"]))
 
 
+def strict(dev):
+    """Round 6: err(hip, A) <= 2 x err(C, A) on a gradient sample of EVERY parameter of all five end-to-end
+    goldens (tests/parity_util.py), not on 11 captured slices."""
+    import parity_util as P
+    import test_generation_gpu as TG
+    import test_model_gpu as TM
+    import test_pretrain_gpu as TP
+    import test_tactile_gpu as TT
+    print("\n\n#### strict per-parameter gradient parity (every parameter, recipe.grad_slice samples) ####")
+    e2e = np.load(os.path.join(G, "mla_tiny_e2e.npz"), allow_pickle=True)
+    m, ld, out = TM._run_hip_e2e(dev)
+    print(P.format_rows(P.grad_sample_rows({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, e2e),
+                        "tiny MLA SFT step (configs[0] shapes; mla_tiny_e2e.npz)"))
+    del m, ld, out
+    m, ld, gold, _, _ = TG.run_post_training_e2e(dev)
+    print(P.format_rows(P.grad_sample_rows({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, gold),
+                        "tiny MLA post-training step (configs[3] scaled down; mla_tiny_e2e_gen.npz)"))
+    del m, ld
+    for pc in (False, True):
+        m, ld, gold = TP.run_pretrain_e2e(dev, pc)
+        print(P.format_rows(P.grad_sample_rows({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, gold),
+                            f"tiny MLA stage pretrain, use_pointcloud={pc} (mla_tiny_e2e_pretrain{'_pc' if pc else ''}.npz)"))
+        del m, ld
+    m, ld, gold = TT.run_tactile_e2e(dev)
+    print(P.format_rows(P.grad_sample_rows({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, gold),
+                        "tiny MLA with tactile + generation heads (mla_tiny_e2e_tactile.npz)"))
+    # the one tensor over 2 x mode C: pad-row semantics, not arithmetic (tests/test_tactile_gpu.py::test_mla_e2e_tactile)
+    from oracle import mla_oracle, recipe
+    KEY = "vlm.generation_manager.tactile_gen_module.decoder.layers.0.multihead_attn.in_proj_weight"
+    batch, draws = TT.run_tactile_e2e.last_inputs
+    mine = recipe.grad_slice(dict(m.named_parameters())[KEY].grad.float().cpu()).numpy()
+    A, C = gold["A_gs::" + KEY], gold["C_gs::" + KEY]
+    print(f"  named exception {KEY}:")
+    for zp, tag in ((False, "eager pad rows (the golden's semantics)"), (True, "flash / varlen pad rows (the kernels' and the reference GPU path's)")):
+        sd = {k: recipe.det_weight(k, v.shape) for k, v in m.state_dict().items()}
+        sd[KEY].requires_grad_(True)
+        ref = mla_oracle.mla_forward(sd, batch, draws, 9, 2, 1e-5, 2, zero_pad_rows=zp, use_tactile=True, gen_tactile=True)
+        g = recipe.grad_slice(torch.autograd.grad(ref["total_loss"], sd[KEY])[0]).numpy()
+        print(f"    fp32 oracle, {tag:<72} err(oracle, A) {err(g, A):.2e}   err(hip, oracle) {err(mine, g):.2e}   yardstick err(C, A) {err(C, A):.2e}")
+
+
 if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     sft(dev)
     gen(dev)
     heads(dev)
+    strict(dev)

@@ -7,8 +7,10 @@ Formulas (rocprofv3's own derived-metric expressions, `rocprofv3 -L` on the box;
   wait % = SQ_WAIT_ANY / SQ_WAVE_CYCLES (wave-cycles parked in s_waitcnt / s_barrier)        L2 hit % = TCC_HIT / (TCC_HIT + TCC_MISS)
   fabric read = FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests as 64 B), write = WRITE_SIZE KiB x 1024; Infinity-Cache hits included
 Counter passes perturb timing (clock 1.9 vs 2.0 GHz): durations here are for the ratios only; see the kernel-stats CSV for times.
-Usage: python tools/pmc_table.py <pass1.csv> <pass2.csv> <pass3.csv> <pass4.csv>"""
-import collections, csv, re, sys
+Usage: python tools/pmc_table.py <pass1.csv> <pass2.csv> <pass3.csv> <pass4.csv> [out.json [steps_in_the_pmc_run]]
+out.json (round 6): the rows as data -- kernel, dispatches per step, us, MfmaUtil % -- plus the identity of the library the counters were
+collected on; bench.py's roofline.step_weighted_mfma_util reads the newest profiles/r*_pmc_table.json."""
+import collections, csv, hashlib, json, os, re, sys
 
 FAMILIES = [("gemm256<0,0,0> plain (>= 150 us)", r"gemm256_kernel<0, ?0, ?0(, ?(true|false))?>", 150.0),
             ("gemm256<0,0,1> gate|up+SwiGLU", r"gemm256_kernel<0, ?0, ?1(, ?(true|false))?>", 150.0),
@@ -52,6 +54,8 @@ p1, p2, p3, p4 = (load(a) for a in sys.argv[1:5])
 print(__doc__.split("Usage")[0])
 hdr = f"{'kernel':34s} {'n':>4s} {'us(pmc)':>8s} {'clk GHz':>7s} {'MfmaUtil%':>9s} {'VALUBusy%':>9s} {'LDSconf%':>8s} {'wait%':>6s} {'L2hit%':>6s} {'rd GB':>7s} {'wr GB':>7s} {'fabric TB/s':>11s}"
 print(hdr)
+json_rows = []
+steps_in_run = int(sys.argv[6]) if len(sys.argv) > 6 else 2          # collect_counters.sh: --steps 1 --warmup 1
 for fam, _, _ in FAMILIES:
     a = p1.get(fam)
     if not a:
@@ -73,5 +77,22 @@ for fam, _, _ in FAMILIES:
     rd = mean([s for s, _ in c.get("FETCH_SIZE", [])]) * 1024 * 2 if c.get("FETCH_SIZE") else float("nan")
     wr = mean([s for s, _ in d.get("WRITE_SIZE", [])]) * 1024 if d.get("WRITE_SIZE") else float("nan")
     us3 = mean([u for u, _ in c["_us"]]) if c.get("_us") else us
+    json_rows.append(dict(kernel=fam, n_per_step=len(a["_us"]) / steps_in_run, us=round(us, 2), clk_ghz=round(gui / (us * 1e3), 3), mfma_util_pct=round(mfma, 2),
+                          l2_hit_pct=round(100 * hit / (hit + miss), 2) if hit == hit else None, fabric_read_gb=round(rd / 1e9, 4) if rd == rd else None,
+                          fabric_write_gb=round(wr / 1e9, 4) if wr == wr else None))
     print(f"{fam:34s} {len(a['_us']):4d} {us:8.1f} {gui / (us * 1e3):7.2f} {mfma:9.1f} {valu:9.1f} {conf:8.1f} {wait:6.1f} "
           f"{100 * hit / (hit + miss):6.1f} {rd / 1e9:7.3f} {wr / 1e9:7.3f} {(rd + wr) / (us3 * 1e-6) / 1e12:11.2f}")
+
+if len(sys.argv) > 5:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    lib_path = os.environ.get("MLA_HIP_LIB") or os.path.join(root, "mla_amd", "libmla_hip.so")
+    lib_id = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
+    try:
+        from mla_amd import hip
+        gid = hip.gemm_source_id()
+    except Exception:   # noqa: BLE001
+        gid = None
+    json.dump(dict(rows=json_rows, steps_in_pmc_run=steps_in_run, library_id=lib_id, gemm_source_id=gid,
+                   note="MfmaUtil % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel family; us = mean dispatch duration under the counter pass"),
+              open(sys.argv[5], "w"), indent=1)
