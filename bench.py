@@ -310,6 +310,9 @@ def main():
     ap.add_argument("--mem-frac", type=float, default=0.91, help="share of the device's total memory the automatic --keep-layers -1 choice may plan for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
+    ap.add_argument("--eager-lm-head", action="store_true",
+                    help="compute lm_head + cross entropy inside every forward like the reference (modeling_llama.py:1255-1269) instead of on "
+                         "first access of output.logits / output.loss (the default since round 6: the trainer discards `output`, SURVEY App. A #7)")
     ap.add_argument("--no-box", action="store_true", help="skip the `box` block (sclk / power sampler + the two 300 ms MFMA calibrations)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (configs[3] and configs[4] at 3 timed steps each) the default 1-GPU configs[1] run appends")
@@ -374,6 +377,7 @@ def main():
     torch.manual_seed(42)                      # identical initial weights on every rank (scripts/train.py:76 seed)
     stage = "post-training" if gen_on else ("pretrain" if args.config == 4 else "finetune")   # config 4: the vision tokenizer trains too
     mla = build(device, args.save_level, args.tiny, use_pointcloud=pc_on, generation=gen_on, stage=stage)
+    mla.vlm.llm_backbone.llm.config.lazy_lm_head = not args.eager_lm_head
     torch.manual_seed(42 + rank)               # rank-local noise / timesteps / FPS starts, like the reference's per-rank RNG
     strat = FSDPStrategy(mla, dev_index, stage=stage, global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
                          learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
@@ -475,13 +479,15 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B_PER_GPU * args.steps / elapsed
         dec_fl, tot_fl = model_flops_per_sample(S)
+        if not args.eager_lm_head:
+            tot_fl = dec_fl                    # lazy lm_head: the 2 H V flops per token are not executed in a training step, so not counted
         heads_fl = 0.0
         if prof and args.config == 3 and not args.tiny:
             # configs[3]: the generation heads' GEMM work is not in the decoder formula -- take it from the launches themselves:
             # (sum of 2MNK over every GEMM launch of a step) - (the decoder's + lm_head's linear layers, forward + backward)
             H_, I_, L_, V_ = 4096, 11008, 32, 32064
             tok = B_PER_GPU * R_DIFF * S
-            dec_gemm = 3.0 * (8 * H_ * H_ + 6 * H_ * I_) * L_ * tok + 2.0 * H_ * V_ * tok
+            dec_gemm = 3.0 * (8 * H_ * H_ + 6 * H_ * I_) * L_ * tok + (2.0 * H_ * V_ * tok if args.eager_lm_head else 0.0)
             heads_fl = max(0.0, sum(fl for _, _, fl, _ in prof) / args.steps - dec_gemm) / B_PER_GPU
             tot_fl += heads_fl
         roof = None
@@ -577,7 +583,11 @@ def main():
                                                     f"MIXED (opt-in, not the reference's policy): last {keep_layers} of 32 decoder layers keep "
                                                     f"activations (level {args.keep_level}), {32 - keep_layers} checkpointed (level 0)")}
                              if args.config == 4 and not args.tiny else {}),
-                          "optimizer": "fused AdamW + grad clip inside the timed region"},
+                          "optimizer": "fused AdamW + grad clip inside the timed region",
+                          "lm_head": ("eager: lm_head + shifted CE inside every forward, like the reference" if args.eager_lm_head else
+                                      "lazy: lm_head(h).float() + shifted CE (modeling_llama.py:1255-1269) run on first access of output.logits / "
+                                      "output.loss; the training loop never reads them (base_strategy_mla.py:307,334), so they are neither executed "
+                                      "in the timed steps nor counted in model_tflop_per_sample")},
                "model_tflop_per_sample": round(tot_fl / 1e12, 2),
                **({"heads_encoders_tflop_per_sample_from_gemm_launches": round(heads_fl / 1e12, 2)} if heads_fl else {}),
                "model_tflops_per_gpu": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12, 1),

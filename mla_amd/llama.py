@@ -50,6 +50,8 @@ class LlamaConfig:
     activation_save_levels: Optional[tuple] = None   # per-layer override (mixed policy: keep as many layers as fit in HBM, checkpoint the rest)
     contrastive_tap_layer: int = 8     # index into hidden_states (reference hard-codes 8, modeling_llama.py:1274)
     compute_lm_logits: bool = True     # reference always materialises fp32 logits + CE even when unused (:1255-1269)
+    lazy_lm_head: bool = True          # round 6: in training they are computed on first access of output.logits / output.loss
+                                       # (mla_amd/modeling_outputs.py); False = inside forward, like the reference
 
     def layer_save_level(self, layer_idx: int) -> int:
         lv = self.activation_save_levels
@@ -283,16 +285,25 @@ class LlamaForCausalLM(nn.Module):
                                                past_key_values=past_key_values, use_cache=use_cache,
                                                output_hidden_states=bool(output_hidden_states or need_tap))
         B, S, H = hidden_states.shape
-        logits, loss = None, None
+        logits, loss, lazy_lm = None, None, None
         if self.config.compute_lm_logits or labels is not None:
-            h2 = hidden_states.reshape(B * S, H)
-            logits = LMHeadFn.apply(h2, self.lm_head.weight).view(B, S, -1)  # fp32, = lm_head(h).float()  (:1254-1255)
-            if labels is not None:
-                # shift so that tokens < n predict n (:1258-1262): instead of slicing the 2.25 GB logits tensor the
-                # labels are shifted left and the last position ignored -- the same set of (row, label) pairs
-                shifted = torch.full_like(labels, -100)
-                shifted[:, :-1] = labels[:, 1:]
-                loss = ops.cross_entropy(logits.view(B * S, -1), shifted.reshape(-1))
+            def lm_and_ce(hidden_states=hidden_states, labels=labels):
+                h2 = hidden_states.reshape(B * S, H)
+                lg = LMHeadFn.apply(h2, self.lm_head.weight).view(B, S, -1)  # fp32, = lm_head(h).float()  (:1254-1255)
+                ce = None
+                if labels is not None:
+                    # shift so that tokens < n predict n (:1258-1262): instead of slicing the 2.25 GB logits tensor the
+                    # labels are shifted left and the last position ignored -- the same set of (row, label) pairs
+                    shifted = torch.full_like(labels, -100)
+                    shifted[:, :-1] = labels[:, 1:]
+                    ce = ops.cross_entropy(lg.view(B * S, -1), shifted.reshape(-1))
+                return lg, ce
+            if self.config.lazy_lm_head and self.training:
+                # Round 6: the diffusion objective never reads logits / CE and the trainer drops `output`
+                # (base_strategy_mla.py:307,334) -- they are produced on first access of output.logits / output.loss instead
+                lazy_lm = lm_and_ce
+            else:
+                logits, loss = lm_and_ce()
 
         img_pc_contrastive_loss = None
         if self.training and compute_token_contrastive_loss:
@@ -302,7 +313,8 @@ class LlamaForCausalLM(nn.Module):
             img_pc_contrastive_loss = self.coordinate_aware_contrastive_loss_module(
                 image_features=tap[:, img_start:img_end, :], pointcloud_features=tap[:, pc_start:pc_end, :],
                 patch_indices=patch_correspondence_indices, valid_mask=correspondence_valid_mask)
-            loss = loss + img_pc_contrastive_loss
+            if lazy_lm is None:
+                loss = loss + img_pc_contrastive_loss
         tactile_contrastive_loss = None
         if self.training and compute_tactile_contrastive_loss:
             tap = all_hidden[self.config.contrastive_tap_layer]
@@ -313,10 +325,11 @@ class LlamaForCausalLM(nn.Module):
                 tac_features=tap[:, tac_start:tac_end, :], pc_features=tap[:, pc_start:pc_end, :],
                 img_features=tap[:, img_start:img_end, :], positive_pc_indices=positive_pc_indices_for_tac,
                 linear_positive_img_indices=linear_positive_img_indices_for_tac)
-            loss = loss + tactile_contrastive_loss
+            if lazy_lm is None:
+                loss = loss + tactile_contrastive_loss
         return CausalLMOutputWithPast(loss=loss, logits=logits, img_pc_contrastive_loss=img_pc_contrastive_loss,
                                       tactile_contrastive_loss=tactile_contrastive_loss, past_key_values=None,
-                                      hidden_states=all_hidden if output_hidden_states else None, attentions=None)
+                                      hidden_states=all_hidden if output_hidden_states else None, attentions=None, lazy_lm=lazy_lm)
 
 
 class LMHeadFn(torch.autograd.Function):

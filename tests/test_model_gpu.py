@@ -293,8 +293,10 @@ def test_decoder_stack_mixed_activation_policy_is_bit_identical(dev, policy):
         assert torch.equal(a, b), (policy, i)
 
 
-def _run_hip_e2e(dev, save_level=2):
+def _run_hip_e2e(dev, save_level=2, lazy_lm_head=None):
     m = build_tiny_mla(dev, save_level)
+    if lazy_lm_head is not None:
+        m.vlm.llm_backbone.llm.config.lazy_lm_head = lazy_lm_head
     batch, draws = recipe.make_batch(R=2)
     m.vlm.vision_tower_3d.fps_starts_override = [draws["fps_start0"], draws["fps_start1"]]
     to = lambda v: v.to(dev)  # noqa: E731
@@ -362,6 +364,30 @@ def test_mla_e2e_against_reference_golden(dev, e2e):
     rows = grad_sample_rows(grads, e2e)
     assert len(rows) == len(names) == 116
     assert not strict_violations(rows), strict_violations(rows)
+
+
+def test_lazy_lm_head_is_the_eager_one_on_first_access(dev):
+    """Round 6: in training, lm_head(h).float() + the shifted cross entropy (modeling_llama.py:1255-1269) run on
+    the first access of output.logits / output.loss instead of inside every forward -- the trainer discards `output`
+    (base_strategy_mla.py:307,334). Same kernels on the same hidden states: logits, llm loss (CE + contrastive, added in the reference's
+    order), the loss dict and every gradient are BIT-identical to the eager form, and nothing is computed before the first access."""
+    res = {}
+    for lazy in (True, False):
+        m, ld, out = _run_hip_e2e(dev, lazy_lm_head=lazy)
+        assert out.lm_head_pending == lazy                                   # after forward + backward nobody has asked yet
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        logits, loss = out.logits, out.loss
+        assert not out.lm_head_pending and logits.dtype == torch.float32
+        if lazy:
+            assert torch.cuda.memory_allocated() - before >= logits.numel() * 4   # the fp32 logits did not exist until now
+        assert out.logits is logits and out.loss is loss                     # computed once
+        res[lazy] = (logits.detach().cpu(), loss.detach().cpu(), {k: float(v) for k, v in ld.items() if torch.is_tensor(v)},
+                     {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert res[True][2] == res[False][2]
+    assert res[True][3].keys() == res[False][3].keys()
+    assert all(torch.equal(res[True][3][k], res[False][3][k]) for k in res[True][3])
 
 
 def test_mla_e2e_against_oracle_flash_semantics(dev):
