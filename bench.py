@@ -287,6 +287,16 @@ def secondary_configs(steps=3, warmup=1, timeout_s=420):
             res[f"config{cfg}"] = {"error": f"timeout after {timeout_s} s"}
         except Exception as e:   # noqa: BLE001 -- the headline line must survive anything the secondary runs do
             res[f"config{cfg}"] = {"error": repr(e)}
+    # latency of MLA.predict_action_diff (8-step DDIM, batch 1, 7B) -- with the prefix computed once per action chunk
+    # (round 6, mla_amd/infer.py) and with the reference's control flow (a whole forward per DDIM step)
+    for tag, extra in (("inference_predict_action_diff", []), ("inference_whole_forward_per_step", ["--no-reuse-prefix"])):
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_infer.py"), "--iters", "5"] + extra, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            res[tag] = json.loads(line[-1]) if (cp.returncode == 0 and line) else {"error": f"rc {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
+        except Exception as e:   # noqa: BLE001
+            res[tag] = {"error": repr(e)}
     return res
 
 

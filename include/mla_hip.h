@@ -214,6 +214,26 @@ int mla_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, 
                     float scale, const float* rope_cos, const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt,
                     void* ws, long long ws_bytes, mla_stream_t stream);
 
+/* ---- inference with a cached prefix (mla_amd/infer.py; replaces 7 of the 8 whole forwards of MLA.predict_action_diff,
+ * models/mla/model_mla.py:742-775 + models/diffusion/gaussian_diffusion.py:608-688). HBM-bound: algorithmic bytes = the weight matrix /
+ * the head's cached K and V rows.
+ * mla_gemv_bf16: out row m = x[m] . W^T (+ residual[m]) for M <= 8 rows; W [N, K] k-contiguous is read exactly once (16 B per lane,
+ *   non-temporal), x is held in LDS (M x K x 2 bytes <= 160 KiB), fp32 accumulation. Row m of `out` is written at
+ *   out + (m / rows_per_batch) * out_batch_stride + (m % rows_per_batch) * ldo, so the q|k|v rows of the new tokens can land directly in
+ *   the per-sample cache slots. Replaces the nn.Linear calls of modeling_llama.py:240, 351-353, 390 for the suffix rows.
+ *   pre: what is applied to the input rows on their way into LDS -- 0 nothing; 1 LlamaRMSNorm with weight pre_w and eps
+ *   (modeling_llama.py:76-90, the arithmetic of mla_rmsnorm_fwd); 2 SwiGLU: x rows are packed gate|up [2 K], the input is
+ *   silu(gate) * up (modeling_llama.py:240, the arithmetic of mla_swiglu_fwd). */
+int mla_gemv_bf16(const void* x, long long ldx, const void* W, long long ldw, void* out, long long ldo, long long out_batch_stride,
+                  int rows_per_batch, const void* residual, long long ld_res, int M, int N, int K, int pre, const void* pre_w, float eps,
+                  mla_stream_t stream);
+/* mla_attn_decode: R <= 8 new query rows per (sample, head) -- rows [S_kv - R, S_kv) of the packed q|k|v cache (row stride ld, sample stride
+ *   batch_stride, q / k / v = the three slices' first elements) -- against keys / values [0, S_kv - R + r] (causal, scale applied to the
+ *   scores, fp32 softmax, P rounded to bf16 before P V like the flash kernel). o: [B * R, H * 128] bf16. head_dim 128.
+ *   Replaces the attention of modeling_llama.py:371-380 for the suffix rows. */
+int mla_attn_decode(const void* q, const void* k, const void* v, void* o, int B, int H, int head_dim, int S_kv, int R, long long ld,
+                    long long batch_stride, long long ld_o, float scale, mla_stream_t stream);
+
 /* ---- losses: CrossEntropyLoss modeling_llama.py:1258-1269; InfoNCE models/mla/fuser/contrastive.py:208-215 */
 int mla_ce_fwd(const void* logits, int logits_fp32, long long ld, const long long* labels, float* loss, float* lse, int rows,
                int ncols, long long ignore_index, mla_stream_t stream);

@@ -16,7 +16,7 @@ mkdir -p "$BUILD"
 GID=$(cat "$HERE/gemm256.hip" "$HERE/gemm256_kloop.inc" "$HERE/gemm256_kloop_half1.inc" "$HERE/gemm256_kloop_clobbers.inc" "$HERE/gemm_args.h" "$HERE/common.h" | sha256sum | cut -c1-16)
 if [ "$(cat "$BUILD/gemm_src_id.txt" 2>/dev/null)" != "$GID" ]; then echo "$GID" > "$BUILD/gemm_src_id.txt"; rm -f "$BUILD/api.o"; fi
 pids=()
-SRCS="api gemm gemm256 transpose elementwise attention loss pointcloud vision gen contention calib"
+SRCS="api gemm gemm256 transpose elementwise attention loss pointcloud vision gen contention calib infer"
 [ "$EXP" = 1 ] && SRCS="$SRCS gemm_asm"
 for f in $SRCS; do
   [ -f "$HERE/$f.hip" ] || continue

@@ -31,6 +31,10 @@ _SIGNATURES = {
     "mla_selftest": [c_void_p, c_void_p, c_void_p, c_void_p],
     "mla_dispatch_probe": [c_void_p, c_int, c_int, c_void_p],
     "mla_calib_mfma": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "mla_gemv_bf16": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_longlong, c_int, c_int,
+                      c_int, c_int, c_void_p, c_float, c_void_p],
+    "mla_attn_decode": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float,
+                        c_void_p],
     "mla_gemm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                       c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "mla_gemm_bf16_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -654,6 +658,42 @@ def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, sca
         return
     call("mla_attn_bwd", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
          H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(sync), n_sync)
+
+
+# --------------------------------------------------------------------------------------------- inference (mla_amd/infer.py)
+def gemv(x, W, out, ldo, out_batch_stride, rows_per_batch, residual=None, out_col=0, norm_weight=None, eps=0.0, swiglu=False):
+    """out row m (at out + (m // rows_per_batch) * out_batch_stride + (m % rows_per_batch) * ldo + out_col) = f(x[m]) @ W^T (+ residual[m]);
+    M <= 8 rows, every weight row read once (mla_gemv_bf16). `out` is a base tensor: only its data pointer is used.
+    f = identity; or LlamaRMSNorm(x; norm_weight, eps); or (swiglu=True, x = packed gate|up rows [M, 2 K]) silu(gate) * up."""
+    _req(x, torch.bfloat16, "gemv x")
+    _req(W, torch.bfloat16, "gemv W")
+    _req(out, torch.bfloat16, "gemv out")
+    M = x.shape[0]
+    K = x.shape[1] // 2 if swiglu else x.shape[1]
+    N = W.shape[0]
+    assert W.shape[1] == K and x.stride(1) == 1 and W.stride(1) == 1 and not (swiglu and norm_weight is not None)
+    pre = 2 if swiglu else (1 if norm_weight is not None else 0)
+    if norm_weight is not None:
+        _req(norm_weight, torch.bfloat16, "gemv norm weight")
+        assert norm_weight.numel() == K and norm_weight.is_contiguous()
+    if residual is not None:
+        _req(residual, torch.bfloat16, "gemv residual")
+        assert residual.shape[0] == M and residual.stride(1) == 1
+    call("mla_gemv_bf16", _p(x), x.stride(0), _p(W), W.stride(0), c_void_p(out.data_ptr() + 2 * out_col), ldo, out_batch_stride, rows_per_batch,
+         _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, pre, _p(norm_weight), float(eps))
+
+
+def attn_decode(cache, B, nheads, D, S_kv, R, scale):
+    """cache [B, S_cap >= S_kv, 3 * nheads * D] packed post-RoPE q|k|v rows; the R query rows are rows [S_kv - R, S_kv) of every sample,
+    query r attends to keys [0, S_kv - R + r] (mla_attn_decode). Returns o [B * R, nheads * D] bf16."""
+    _req(cache, torch.bfloat16, "attn_decode cache")
+    H = nheads * D
+    assert cache.shape[0] == B and cache.shape[2] == 3 * H and cache.stride(2) == 1 and cache.shape[1] >= S_kv
+    o = torch.empty((B * R, H), dtype=torch.bfloat16, device=cache.device)
+    base = cache.data_ptr()
+    call("mla_attn_decode", c_void_p(base), c_void_p(base + 2 * H), c_void_p(base + 4 * H), _p(o), B, nheads, D, S_kv, R, cache.stride(1),
+         cache.stride(0), H, float(scale))
+    return o
 
 
 # --------------------------------------------------------------------------------------------- losses

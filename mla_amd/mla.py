@@ -238,7 +238,7 @@ class MLA(nn.Module):
     def predict_action_diff(self, image=None, pointcloud=None, instruction: Optional[str] = None, cur_robot_state=None,
                             unnorm_key: Optional[str] = None, cfg_scale: float = 0.0, use_ddim: bool = True, num_ddim_steps: int = 8,
                             action_dim: int = 7, *, input_ids: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-                            camera_name: str = "rlbench_front", **kwargs) -> np.ndarray:
+                            camera_name: str = "rlbench_front", reuse_prefix: bool = True, **kwargs) -> np.ndarray:
         """model_mla.py:592-775: 8-step DDIM (eta = 0) over the action chunk with the VLM as the epsilon model, then
         un-normalisation.
         * ``image`` is a PIL image / uint8 HWC frame (pre-processed here like the reference does, :656-660) or an already
@@ -247,6 +247,9 @@ class MLA(nn.Module):
           (:626-632; the Llama tokenizer files are not in this image, so a tokenizer has to be attached), or arrives tokenised as
           ``input_ids`` [1, L]; [29871, 32001, 32002, 29871] is appended unless the last id already is 29871 and the last three ids
           are dropped again (:640-645, :711-713).
+        ``reuse_prefix`` (default, round 6): the encoders and the decoder rows in front of the [t, x] tokens are computed ONCE per action
+        chunk and every sampler step runs over the 1 + T suffix rows against the cached keys / values (mla_amd/infer.py: same function,
+        FPS start indices drawn once per chunk instead of once per step); False = the reference's control flow, a whole forward per step.
         ``noise`` optionally fixes the initial sample (the reference draws it with torch.randn, :707). ``camera_name``: the shipped
         method does not forward it, so the reference's get_camera_params(None) raises (camera.py:54-56); it is an explicit
         argument here (the evaluation scripts use the RLBench front camera)."""
@@ -291,13 +294,17 @@ class MLA(nn.Module):
         if noise is None:
             noise = torch.randn(1, self.future_action_window_size + 1, action_dim, device=device)
         _ = torch.randint(0, self.diffusion.num_timesteps, (self.future_action_window_size + 1,), device=device)  # drawn, unused (:708)
+        eps_model = self.vlm.forward
+        if reuse_prefix:
+            from .infer import PrefixCachedEps
+            eps_model = PrefixCachedEps.for_inputs(self.vlm, n_action_rows=self.future_action_window_size + 1, **model_kwargs)
         if use_ddim and num_ddim_steps is not None:
             if self.ddim_diffusion is None:
                 self.create_ddim(ddim_step=num_ddim_steps)
-            samples = self.ddim_diffusion.ddim_sample_loop(self.vlm.forward, noise.shape, noise.to(device).float(), clip_denoised=False,
+            samples = self.ddim_diffusion.ddim_sample_loop(eps_model, noise.shape, noise.to(device).float(), clip_denoised=False,
                                                            model_kwargs=model_kwargs, progress=False, device=device, eta=0.0)
         else:
-            samples = self.diffusion.p_sample_loop(self.vlm.forward, noise.shape, noise.to(device).float(), clip_denoised=False,
+            samples = self.diffusion.p_sample_loop(eps_model, noise.shape, noise.to(device).float(), clip_denoised=False,
                                                    model_kwargs=model_kwargs, progress=False, device=device)
         normalized = samples[0].float().cpu().numpy()
         return self.unnormalize_actions(normalized, unnorm_key) if self.norm_stats is not None else normalized

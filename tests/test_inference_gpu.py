@@ -139,3 +139,118 @@ def test_predict_action_diff_from_instruction(dev, model):
     assert np.allclose(a1, a2, rtol=1e-5, atol=1e-6)
     with pytest.raises(ValueError):
         m.predict_action_diff(image=image[0], pointcloud=pc[0], cur_robot_state=proprio[0, 0].numpy(), noise=noise)
+
+
+# ------------------------------------------------------------------------------------------------ prefix reuse (round 6, mla_amd/infer.py)
+@pytest.mark.parametrize("M,N,K,res", [(1, 4096, 4096, True), (2, 12288, 4096, False), (5, 1000, 11008, True), (8, 22016, 4096, False), (3, 7, 512, False)])
+def test_gemv_matches_fp32_reference(dev, M, N, K, res):
+    """mla_gemv_bf16: out[m] = x[m] @ W^T (+ residual) for M <= 8 rows, fp32 accumulation, incl. N not a multiple of the 4 rows a wave
+    keeps in flight, K not a multiple of 512, and the (rows per sample, sample stride) output addressing the cache slots use."""
+    from mla_amd import hip
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(BF)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(BF)
+    r = (torch.randn(M, N, generator=g)).to(BF) if res else None
+    want = x.float() @ W.float().t() + (r.float() if res else 0)
+    out = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+    hip.gemv(x.to(dev), W.to(dev), out, N, 0, M, r.to(dev) if res else None)
+    assert torch.isfinite(out.float()).all()
+    assert fro_rel(out, want) < 4e-3                                           # one bf16 rounding of the fp32 sums
+    if M % 2 == 0 and N % 8 == 0:
+        # rows of sample b land at out + b * batch_stride + r * ldo (+ column offset): the q|k|v cache addressing
+        rpb, S_cap, ld = 2, 5, N + 64
+        buf = torch.zeros((M // rpb, S_cap, ld), dtype=BF, device=dev)
+        hip.gemv(x.to(dev), W.to(dev), buf[:, 3:], ld, buf.stride(0), rpb, None, out_col=32)
+        got = buf[:, 3:5, 32:32 + N].reshape(M, N)
+        ref = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+        hip.gemv(x.to(dev), W.to(dev), ref, N, 0, M, None)
+        assert torch.equal(got, ref)
+        assert float(buf[:, :3].float().abs().max()) == 0 and float(buf[:, 3:, :32].float().abs().max()) == 0 and float(buf[:, 3:, 32 + N:].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(2, 4096, 512), (5, 256, 96), (7, 8192, 64)])
+def test_gemv_fused_rmsnorm_and_swiglu_inputs_match_the_separate_kernels(dev, M, K, N):
+    """mla_gemv_bf16 with pre = 1 / 2: LlamaRMSNorm resp. SwiGLU applied to the rows inside the kernel's input staging must be the
+    stand-alone kernels' arithmetic -- bit-identical outputs to rmsnorm_fwd / swiglu_fwd followed by the plain GEMV."""
+    from mla_amd import hip
+    g = torch.Generator().manual_seed(K + M)
+    x = (torch.randn(M, K, generator=g) * 1.3).to(BF).to(dev)
+    w = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(dev)
+    gu = torch.randn(M, 2 * K, generator=g).to(BF).to(dev)
+    a, b = (torch.full((M, N), float("nan"), dtype=BF, device=dev) for _ in range(2))
+    hip.gemv(hip.rmsnorm_fwd(x, w, 1e-5)[0], W, a, N, 0, M)
+    hip.gemv(x, W, b, N, 0, M, norm_weight=w, eps=1e-5)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    a.fill_(float("nan")); b.fill_(float("nan"))
+    hip.gemv(hip.swiglu_fwd(gu), W, a, N, 0, M)
+    hip.gemv(gu, W, b, N, 0, M, swiglu=True)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,S_kv,R", [(1, 32, 550, 2), (2, 4, 77, 5), (1, 2, 8, 8), (3, 3, 1030, 1)])
+def test_attn_decode_matches_fp32_reference(dev, B, H, S_kv, R):
+    """mla_attn_decode: the last R rows of the packed q|k|v cache are the queries; query r attends to keys [0, S_kv - R + r]."""
+    import math
+    from mla_amd import hip
+    D = 128
+    g = torch.Generator().manual_seed(S_kv + R)
+    cache = (torch.randn(B, S_kv + 3, 3 * H * D, generator=g) * 0.7).to(BF)
+    o = hip.attn_decode(cache.to(dev), B, H, D, S_kv, R, 1 / math.sqrt(D))
+    c = cache.float()[:, :S_kv]
+    q = c[:, S_kv - R:, :H * D].view(B, R, H, D).transpose(1, 2)
+    k = c[:, :, H * D:2 * H * D].view(B, S_kv, H, D).transpose(1, 2)
+    v = c[:, :, 2 * H * D:].view(B, S_kv, H, D).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / math.sqrt(D)
+    mask = torch.arange(S_kv)[None, :] > (S_kv - R + torch.arange(R))[:, None]
+    s = s.masked_fill(mask, float("-inf"))
+    want = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * R, H * D)
+    assert fro_rel(o, want) < 5e-3
+
+
+def test_prefix_cached_sampler_matches_the_whole_forward_sampler(dev, model):
+    """predict_action_diff with the cached prefix (one prefill + 8 passes over the 1 + T suffix rows, mla_amd/infer.py) against the
+    reference's control flow (8 whole forwards, reuse_prefix=False) on the same noise and FPS start indices: same function, other
+    summation order -> the two chunks agree far inside the bound either has against the reference golden; the epsilon of one call agrees
+    with the eval forward's; the captured HIP graph replays bit-identically to eager launches."""
+    from mla_amd import infer
+    m, gold = model
+    ids, image, pc, proprio, noise, _ = infer_inputs()
+    kw = dict(image=image[0], pointcloud=pc[0].numpy(), cur_robot_state=proprio[0, 0].numpy(), input_ids=ids, noise=noise, num_ddim_steps=8)
+    full = m.predict_action_diff(reuse_prefix=False, **kw)
+    cached = m.predict_action_diff(reuse_prefix=True, **kw)
+    ref = gold["mla_ddim8_actions"][0]
+    e_full, e_cached = np.linalg.norm(full - ref) / np.linalg.norm(ref), np.linalg.norm(cached - ref) / np.linalg.norm(ref)
+    d = np.linalg.norm(cached - full) / np.linalg.norm(full)
+    print(f"8-step DDIM chunk vs reference golden: whole forwards {e_full:.3e}, cached prefix {e_cached:.3e}; cached vs whole {d:.3e}")
+    assert e_full < 1e-1 and e_cached < 1e-1 and d < 3e-2
+    # one epsilon call
+    with torch.inference_mode():
+        _, eps_full = m.vlm(noise.to(dev), torch.tensor([91], device=dev), input_ids=ids.to(dev), images=image.to(dev), point_cloud=pc.to(dev),
+                            proprio=proprio.to(dev), camera_name="rlbench_front")
+    eps_model = infer.PrefixCachedEps.for_inputs(m.vlm, n_action_rows=4, input_ids=ids.to(dev), images=image.to(dev), point_cloud=pc.to(dev),
+                                                 proprio=proprio.to(dev), camera_name="rlbench_front")
+    _, eps_c = eps_model(noise.to(dev), torch.tensor([91], device=dev))
+    assert eps_model.graph is not None, "the suffix pass was not captured into a graph"
+    assert fro_rel(eps_c, eps_full.float().cpu()) < 2e-2
+    assert fro_rel(eps_c, torch.from_numpy(gold["mla_eps_t91"])) < 5e-2
+    _, eps_c2 = eps_model(noise.to(dev), torch.tensor([91], device=dev))        # replay
+    old = infer._USE_GRAPH
+    try:
+        infer._USE_GRAPH = False
+        _, eps_e = eps_model(noise.to(dev), torch.tensor([91], device=dev))     # eager launches on the same cache
+    finally:
+        infer._USE_GRAPH = old
+    assert torch.equal(eps_c, eps_c2) and torch.equal(eps_c, eps_e)
+    # the engine (cache buffers + captured graph) is reused for the next observation of the same shape: a new prefill, the same graph
+    g0 = eps_model.graph
+    image2 = image.clone()
+    image2[:, :3] *= 0.5                                                        # (the mask channel stays all ones)
+    again = infer.PrefixCachedEps.for_inputs(m.vlm, n_action_rows=4, input_ids=ids.to(dev), images=image2.to(dev), point_cloud=pc.to(dev),
+                                             proprio=proprio.to(dev), camera_name="rlbench_front")
+    assert again is eps_model and again.graph is g0
+    _, eps_other = again(noise.to(dev), torch.tensor([91], device=dev))
+    assert not torch.equal(eps_other, eps_c)                                    # another image -> another prefix -> another epsilon
+    back = infer.PrefixCachedEps.for_inputs(m.vlm, n_action_rows=4, input_ids=ids.to(dev), images=image.to(dev), point_cloud=pc.to(dev),
+                                            proprio=proprio.to(dev), camera_name="rlbench_front")
+    assert torch.equal(back(noise.to(dev), torch.tensor([91], device=dev))[1], eps_c)
