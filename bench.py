@@ -263,19 +263,21 @@ def secondary_configs(steps=3, warmup=1, timeout_s=420):
     A child that fails is reported as {"error": ...}; it never takes the headline line down."""
     import subprocess
     res = {}
-    for cfg, extra in ((3, []), (4, ["--keep-layers", "0"])):
+    for cfg, extra in ((3, []), (4, ["--keep-layers", "0"]), (4, ["--keep-layers", "0", "--share-prefix"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg), "--steps", str(steps), "--warmup", str(warmup),
                "--no-cpu-baseline", "--no-secondary", "--no-box"] + extra
         t0 = time.time()
         try:
             cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
             line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            key = f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "")
             if cp.returncode != 0 or not line:
-                res[f"config{cfg}"] = {"error": f"rc {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
+                res[key] = {"error": f"rc {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
                 continue
             j = json.loads(line[-1])
             r = j.get("roofline") or {}
-            res[f"config{cfg}"] = {
+            res[key] = {
+                **({"share_prefix": j["share_prefix"]} if "share_prefix" in j else {}),
                 "workload": j["config"]["workload"], "steps": j["steps"], "warmup": j["warmup"], "ms_per_step": j["ms_per_step"],
                 "value": j["value"], "unit": j["unit"], "seq_len": j["config"]["seq_len"],
                 **({"activation_policy": j["config"]["activation_policy"]} if "activation_policy" in j["config"] else {}),
@@ -284,9 +286,9 @@ def secondary_configs(steps=3, warmup=1, timeout_s=420):
                                                    "launches_per_step", "avg_launch_ms", "gemm_ms_per_step", "traffic")} if r else None,
                 "loss": j["loss"], "wall_s_incl_model_build": round(time.time() - t0, 1)}
         except subprocess.TimeoutExpired:
-            res[f"config{cfg}"] = {"error": f"timeout after {timeout_s} s"}
+            res[f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "")] = {"error": f"timeout after {timeout_s} s"}
         except Exception as e:   # noqa: BLE001 -- the headline line must survive anything the secondary runs do
-            res[f"config{cfg}"] = {"error": repr(e)}
+            res[f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "")] = {"error": repr(e)}
     # latency of MLA.predict_action_diff (8-step DDIM, batch 1, 7B) -- with the prefix computed once per action chunk
     # (round 6, mla_amd/infer.py) and with the reference's control flow (a whole forward per DDIM step)
     for tag, extra in (("inference_predict_action_diff", []), ("inference_whole_forward_per_step", ["--no-reuse-prefix"])):
@@ -320,6 +322,10 @@ def main():
     ap.add_argument("--mem-frac", type=float, default=0.91, help="share of the device's total memory the automatic --keep-layers -1 choice may plan for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true")
+    ap.add_argument("--share-prefix", action="store_true",
+                    help="config 4 only, OPT-IN (reported next to the reference-layout run, never instead of it): the 4 diffusion copies of a "
+                         "sample share one prefix -- [prefix 2045 | 4 x 3 suffix rows] = 2 057 executed rows per sample instead of 4 x 2 048 "
+                         "(mla_amd/prismatic.py: forward_shared_prefix; same mathematics, tests/test_pretrain_gpu.py)")
     ap.add_argument("--eager-lm-head", action="store_true",
                     help="compute lm_head + cross entropy inside every forward like the reference (modeling_llama.py:1255-1269) instead of on "
                          "first access of output.logits / output.loss (the default since round 6: the trainer discards `output`, SURVEY App. A #7)")
@@ -388,6 +394,10 @@ def main():
     stage = "post-training" if gen_on else ("pretrain" if args.config == 4 else "finetune")   # config 4: the vision tokenizer trains too
     mla = build(device, args.save_level, args.tiny, use_pointcloud=pc_on, generation=gen_on, stage=stage)
     mla.vlm.llm_backbone.llm.config.lazy_lm_head = not args.eager_lm_head
+    if args.share_prefix:
+        if args.config != 4:
+            raise SystemExit("--share-prefix applies to config 4 (use_pointcloud=False): with a point cloud the FPS start indices differ per copy")
+        mla.share_prefix = True
     torch.manual_seed(42 + rank)               # rank-local noise / timesteps / FPS starts, like the reference's per-rank RNG
     strat = FSDPStrategy(mla, dev_index, stage=stage, global_batch_size=B_PER_GPU * world, per_device_batch_size=B_PER_GPU,
                          learning_rate=2e-5, weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="constant",
@@ -462,6 +472,23 @@ def main():
         # (hot) calibration right behind the timed steps, outside the timed region: the same stream on the chip in the thermal / power
         # state the steps left it in -- the denominator of roofline.frac_of_box_ceiling
         cal = hip.calib_mfma(device)
+        # second yardstick: the step's own GEMM kernel on random operands, alone on the chip, at the step's dominant shape
+        # (tokens x 4096 x 4096): what the in-step launches lose against it is the step's doing (cache state, neighbours), not the box's
+        ga = torch.randn(B_PER_GPU * R_DIFF * S if not args.tiny else 1024, 4096, device=device).to(torch.bfloat16)
+        gb = torch.randn(4096, 4096, device=device).to(torch.bfloat16)
+        gc = torch.empty(ga.shape[0], 4096, dtype=torch.bfloat16, device=device)
+        for _ in range(20):
+            hip.gemm(ga, gb, out=gc)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_g = 400
+        g0.record()
+        for _ in range(n_g):
+            hip.gemm(ga, gb, out=gc)
+        g1.record()
+        torch.cuda.synchronize()
+        box["gemm256_standalone_pflops"] = round(2.0 * ga.shape[0] * 4096 * 4096 * n_g / (g0.elapsed_time(g1) * 1e-3) / 1e15, 4)
+        del ga, gb, gc
         box.update({"mfma_random_pflops": round(cal["pflops"], 4), "mfma_calibration": f"{cal['launches']} launches x {cal['ms_per_launch']:.1f} ms on "
                     f"{cal['blocks']} workgroups x 8 waves, v_mfma_f32_16x16x32_bf16 on N(0,1) operands from registers (mla_calib_mfma), last 200 ms of 300",
                     "device": torch.cuda.get_device_name(dev_index)})
@@ -491,6 +518,10 @@ def main():
         dec_fl, tot_fl = model_flops_per_sample(S)
         if not args.eager_lm_head:
             tot_fl = dec_fl                    # lazy lm_head: the 2 H V flops per token are not executed in a training step, so not counted
+        ref_layout_fl = tot_fl
+        if args.share_prefix:
+            # MFU figures are about EXECUTED work: one (S - 3) + 4 x 3 row sequence per sample (its causal attention priced as fully causal)
+            tot_fl = model_flops_per_sample((S - 3) + R_DIFF * 3, R=1)[0]
         heads_fl = 0.0
         if prof and args.config == 3 and not args.tiny:
             # configs[3]: the generation heads' GEMM work is not in the decoder formula -- take it from the launches themselves:
@@ -575,6 +606,7 @@ def main():
                 # matrix cores sustain on random operands under its power cap (measured right behind the timed steps)
                 roof["frac_of_box_ceiling"] = round(ach / 1e3 / box["mfma_random_pflops"], 4)
                 roof["all_gemm_frac_of_box_ceiling"] = round(ach_all / 1e3 / box["mfma_random_pflops"], 4)
+                roof["frac_of_standalone_gemm"] = round(ach / 1e3 / box["gemm256_standalone_pflops"], 4)
             if args.config == 1 and not args.tiny:
                 roof["step_weighted_mfma_util"] = step_weighted_mfma_util(ms)
         out = {"metric": "training samples/sec + step-time, MLA-Llama2-7B bf16", "value": round(value, 3), "unit": "samples/s",
@@ -599,6 +631,15 @@ def main():
                                       "output.loss; the training loop never reads them (base_strategy_mla.py:307,334), so they are neither executed "
                                       "in the timed steps nor counted in model_tflop_per_sample")},
                "model_tflop_per_sample": round(tot_fl / 1e12, 2),
+               **({"share_prefix": {"executed_rows_per_sample": (S - 3) + R_DIFF * 3, "reference_layout_rows_per_sample": R_DIFF * S,
+                                    "executed_tflop_per_sample": round(tot_fl / 1e12, 2),
+                                    "reference_layout_tflop_per_sample": round(ref_layout_fl / 1e12, 2),
+                                    "note": "opt-in: [prefix | 4 suffix groups] per sample (suffix rows attend to the prefix and their own copy, at the "
+                                            "reference's positions). `value` counts the same dataset samples per second as the reference-layout run; "
+                                            "model_tflop_per_sample / mfu / whole_step_mfu in THIS line are the EXECUTED work (the causal attention of "
+                                            "the 2 057-row sequence priced as fully causal), so the speed-up over config4 is an algorithmic saving, "
+                                            "not a kernel rate"}}
+                  if args.share_prefix else {}),
                **({"heads_encoders_tflop_per_sample_from_gemm_launches": round(heads_fl / 1e12, 2)} if heads_fl else {}),
                "model_tflops_per_gpu": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12, 1),
                "mfu_vs_2.5PF": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

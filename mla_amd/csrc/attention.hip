@@ -224,7 +224,14 @@ struct AttnArgs {
   bf16_t* ds_ws;                                       // backward, 5-product form: dS^T tiles handed from the dK / dV kernel to the dQ kernel
   bf16_t* dqT; bf16_t* dkT; bf16_t* dvT; bf16_t* oT;   // backward only, all or none: [H*D, ldT] token-contiguous copies of dq / dk / dv
   long long ldT;                                       // / o (the wgrad GEMM operands), written from the registers that hold the rows
+  int grp_start, grp_len;                              // suffix groups (round 6, shared-prefix sequences; 0 / 0 = plain causal): rows
+                                                       // >= grp_start form groups of grp_len rows; a query sees the prefix and, causally,
+                                                       // its OWN group only (mla_attn_fwd_g / mla_attn_bwd_g)
 };
+// key (>= grp_start, <= query) belongs to another suffix group than the query
+__device__ __forceinline__ bool other_group(int key, int query, int gs, int gl) {
+  return key >= gs && (key - gs) / gl != (query - gs) / gl;
+}
 
 // 4 x 4 transpose of bf16 values among the four lanes of a quad (lanes 4a .. 4a+3 hold four consecutive tokens).
 // in : w0 = channels (c, c+1), w1 = channels (c+2, c+3) of THIS lane's token
@@ -336,7 +343,7 @@ constexpr int DQ_RB = DQ_NW == 8 ? 1 : MLA_ATTN_RB;
 template <int RB, int MASK>
 __device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], f32x4_t (&ot)[RB][8],
                                          float (&m)[RB], f32x4_t (&l)[RB], const int (&myq)[RB], const int (&grow0)[RB], int kt,
-                                         int lane, float sc2) {
+                                         int lane, float sc2, int gs = 0, int gl = 0) {
   const int g = lane >> 4;
   f32x4_t st[RB][4];
 #pragma unroll
@@ -362,6 +369,13 @@ __device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
+    }
+    if (gl > 0 && kt * 64 + 63 >= gs) {   // wave-uniform: a tile that holds suffix rows (shared-prefix sequences) -- group mask
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (other_group(kt * 64 + f * 16 + g * 4 + r, myq[rb], gs, gl)) st[rb][f][r] = -INFINITY;
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -407,7 +421,9 @@ __device__ __forceinline__ void fwd_tile(const char* kt_, const char* vt_, const
     }
 }
 
-template <int RB, int NW>
+// GRP: the suffix-group mask of shared-prefix sequences (mla_attn_fwd_g) is its own instantiation -- compiled into the plain kernel it
+// cost 15 spilled registers at the 128-register budget of the 8-wave form.
+template <int RB, int NW, bool GRP = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(AttnArgs p) {   // 2nd argument = waves per SIMD
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BQ = 16 * NW * RB;
@@ -493,11 +509,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
     for (int rb = 0; rb < RB; ++rb)
       if (grow0[rb] < row_lim && kt * 64 <= grow0[rb] + 15) mask |= 1 << rb;
     if (RB == 2) {
-      if (mask == 3) fwd_tile<RB, 3>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
-      else if (mask == 2) fwd_tile<RB, 2>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
-      else if (mask == 1) fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
+      if (mask == 3) fwd_tile<RB, 3>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
+      else if (mask == 2) fwd_tile<RB, 2>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
+      else if (mask == 1) fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
     } else if (mask) {
-      fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2);
+      fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
     }
   }
   // ---- epilogue: O leaves through LDS (the K / V ring is free now) as whole 256-B rows, 16 B per lane, 4 rows per store
@@ -878,7 +894,7 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
 template <int RB, int MASK>
 __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const bf16x8_t (&qf)[RB][4], const bf16x8_t (&dof)[RB][4],
                                         f32x4_t (&dqt)[RB][8], const float (&lse2)[RB], const float (&dlt)[RB],
-                                        const int (&myq)[RB], const int (&grow0)[RB], int kt, int lane, float sc2) {
+                                        const int (&myq)[RB], const int (&grow0)[RB], int kt, int lane, float sc2, int gs = 0, int gl = 0) {
   const int g = lane >> 4;
   bf16x8_t ds[RB][2];
   {
@@ -910,6 +926,13 @@ __device__ __forceinline__ void dq_tile(const char* kt_, const char* vt_, const 
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (kt * 64 + f * 16 + g * 4 + r > myq[rb]) st[rb][f][r] = -INFINITY;
+      }
+      if (gl > 0 && kt * 64 + 63 >= gs) {   // a tile that holds suffix rows of a shared-prefix sequence: group mask
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (other_group(kt * 64 + f * 16 + g * 4 + r, myq[rb], gs, gl)) st[rb][f][r] = -INFINITY;
       }
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -1144,11 +1167,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs p, char* smem, i
     int lane_t = lane;
     asm volatile("" : "+v"(lane_t));
     if (RB == 2) {
-      if (mask == 3) dq_tile<RB, 3>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
-      else if (mask == 2) dq_tile<RB, 2>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
-      else if (mask == 1) dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
+      if (mask == 3) dq_tile<RB, 3>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
+      else if (mask == 2) dq_tile<RB, 2>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
+      else if (mask == 1) dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
     } else if (mask) {
-      dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2);
+      dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
     }
   }
   BT(0, 3);
@@ -1305,6 +1328,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /
     // two 32-query halves, each carried through S / dP -> P, dS -> bf16 before the next starts (see dq_tile): 16 score registers
     // instead of 32, and the second half's MFMAs overlap the first half's exp / pack VALU. Bit-identical.
     bf16x8_t ph[2], dsh[2];
+    // shared-prefix sequences: this block's keys include suffix rows and so do the queries of this tile -> group mask (block-uniform)
+    const bool grp_tile = p.grp_len > 0 && kb * 64 + 63 >= p.grp_start && qt * 64 + 63 >= p.grp_start;
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {
       f32x4_t s[2], dp[2];
@@ -1329,6 +1354,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /
         for (int r = 0; r < 4; ++r) {
           float sv = s[ff][r];
           if (qt == kb && mykey > qt * 64 + f * 16 + g * 4 + r) sv = -INFINITY;   // only the first query tile touches the diagonal
+          if (grp_tile && other_group(mykey, qt * 64 + f * 16 + g * 4 + r, p.grp_start, p.grp_len)) sv = -INFINITY;
           const float pv = __builtin_amdgcn_exp2f(sv * sc2 - l4[r]);
           pr[ff][r] = pv;
           s[ff][r] = pv * (dp[ff][r] - d4[r]);
@@ -1564,14 +1590,17 @@ extern "C" int mla_attn_trace(void* host, int bytes) { return (int)hipMemcpyFrom
 extern "C" int mla_attn_btrace(void* host, int bytes) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_btrace), bytes); }
 #endif
 
-extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
-                            int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, hipStream_t stream) {
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
+                         int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, int grp_start, int grp_len, hipStream_t stream) {
   MLA_CHECK_ARG(q && k && v && o && lse, "mla_attn_fwd: null pointer");
+  MLA_CHECK_ARG(grp_len >= 0 && (grp_len == 0 || (grp_start >= 0 && grp_start <= S && (S - grp_start) % grp_len == 0)),
+                "mla_attn_fwd_g: suffix groups need 0 <= grp_start <= S and (S - grp_start) %% grp_len == 0 (S %d, start %d, len %d)", S, grp_start, grp_len);
   MLA_CHECK_ARG(head_dim == D, "mla_attn_fwd: head_dim must be 128 (got %d)", head_dim);
   MLA_CHECK_ARG(AL16(q) && AL16(k) && AL16(v) && AL16(o), "mla_attn_fwd: 16-B alignment required");
   AttnArgs p{};
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
   p.seqlens = seqlens; p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
+  p.grp_start = grp_len > 0 ? grp_start : 0; p.grp_len = grp_len;
   if (check_common(p, "mla_attn_fwd")) return -1;
   static bool attr = false;
   constexpr int BQ = 16 * FWD_NW * FWD_RB;
@@ -1581,7 +1610,7 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
   // default (round 5): the assembly pipeline where it measures ahead of the compiler-scheduled kernel -- S >= 1024 (405-427 vs 452-471 us
   // at S = 2048; at S = 548 it is 8 % behind) -- MLA_ATTN_FWD=0 / 1 forces one of them for A/B runs
   static const int forced = getenv("MLA_ATTN_FWD") ? atoi(getenv("MLA_ATTN_FWD")) : -1;
-  const int variant = forced >= 0 ? forced : (S >= 1024 ? 1 : 0);
+  const int variant = grp_len > 0 ? 0 : (forced >= 0 ? forced : (S >= 1024 ? 1 : 0));   // (the assembly pipeline has the plain causal mask built in)
   if (variant == 1) {
     static bool attr3 = false;
     static const int lds_extra = getenv("MLA_ATTN_LDS_EXTRA") ? atoi(getenv("MLA_ATTN_LDS_EXTRA")) : 0;   // experiment (tools/exp_attn_trace.py): one block per CU
@@ -1589,8 +1618,25 @@ extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o
     hipLaunchKernelGGL(attn_fwd32p_kernel, dim3(grid_blocks((S + 127) / 128, H, B)), dim3(256), FWD32P_LDS + lds_extra, stream, p);
     MLA_LAUNCH_CHECK();
   }
+  if (grp_len > 0) {
+    static bool attrg = false;
+    if (!attrg) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_RB, FWD_NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS); attrg = true; }
+    hipLaunchKernelGGL((attn_fwd_kernel<FWD_RB, FWD_NW, true>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * FWD_NW), FWD_LDS, stream, p);
+    MLA_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<FWD_RB, FWD_NW>), dim3(grid_blocks((S + BQ - 1) / BQ, H, B)), dim3(64 * FWD_NW), FWD_LDS, stream, p);
   MLA_LAUNCH_CHECK();
+}
+extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
+                            int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, hipStream_t stream) {
+  return attn_fwd_impl(q, k, v, o, lse, seqlens, B, S, H, head_dim, ld_qkv, ld_o, scale, 0, 0, stream);
+}
+// Shared-prefix sequences (round 6): rows >= grp_start are (S - grp_start) / grp_len suffix groups of grp_len rows; a query attends to
+// the prefix [0, grp_start) and, causally, to its own group only. grp_len == 0: plain causal attention.
+extern "C" int mla_attn_fwd_g(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
+                              int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, int grp_start, int grp_len,
+                              hipStream_t stream) {
+  return attn_fwd_impl(q, k, v, o, lse, seqlens, B, S, H, head_dim, ld_qkv, ld_o, scale, grp_start, grp_len, stream);
 }
 
 // delta: workspace [B,H,S] fp32 (caller-allocated)
@@ -1605,7 +1651,10 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                          const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
                          int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
                          const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, int* head_sync,
-                         long long head_sync_ints, hipStream_t stream, void* ws = nullptr, long long ws_bytes = 0) {
+                         long long head_sync_ints, hipStream_t stream, void* ws = nullptr, long long ws_bytes = 0, int grp_start = 0,
+                         int grp_len = 0) {
+  MLA_CHECK_ARG(grp_len >= 0 && (grp_len == 0 || (!ws && grp_start >= 0 && grp_start <= S && (S - grp_start) % grp_len == 0)),
+                "mla_attn_bwd_g: suffix groups need 0 <= grp_start <= S and (S - grp_start) %% grp_len == 0 (S %d, start %d, len %d)", S, grp_start, grp_len);
   const int nT = (dqT != nullptr) + (dkT != nullptr) + (dvT != nullptr) + (oT != nullptr);
   MLA_CHECK_ARG(nT == 0 || nT == 4, "mla_attn_bwd_t: dqT / dkT / dvT / oT must all be given or all be null");
   MLA_CHECK_ARG(nT == 0 || (S % 4 == 0 && ldt % 4 == 0 && ldt >= (long long)B * S && ((uintptr_t)dqT & 7) == 0 &&
@@ -1623,6 +1672,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   p.dqT = (bf16_t*)dqT; p.dkT = (bf16_t*)dkT; p.dvT = (bf16_t*)dvT; p.oT = (bf16_t*)oT; p.ldT = ldt;
+  p.grp_start = grp_len > 0 ? grp_start : 0; p.grp_len = grp_len;
   if (check_common(p, "mla_attn_bwd")) return -1;
   static bool attr = false;
   if (!attr) {
@@ -1635,7 +1685,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   // MLA_ATTN_BWD_FUSED=8: the one-workgroup-per-head backward (S <= 576; experiment build only: bit-identical to the two-kernel form and
   // 1.45 x SLOWER -- see attention_exp.inc and HISTORY.md "Round 5")
   static const int fused = getenv("MLA_ATTN_BWD_FUSED") ? atoi(getenv("MLA_ATTN_BWD_FUSED")) : 0;
-  if (!ws && fused == 8 && S <= 64 * FB_MAXT && S % 4 == 0) {
+  if (!ws && fused == 8 && S <= 64 * FB_MAXT && S % 4 == 0 && grp_len == 0) {
     static bool fattr = false;
     if (!fattr) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
@@ -1722,6 +1772,16 @@ extern "C" int mla_attn_bwd_t(const void* q, const void* k, const void* v, const
                               long long head_sync_ints, hipStream_t stream) {
   return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
                        dqT, dkT, dvT, oT, ldt, head_sync, head_sync_ints, stream);
+}
+
+// mla_attn_bwd_t for shared-prefix sequences (see mla_attn_fwd_g); dqT / dkT / dvT / oT and head_sync optional as in mla_attn_bwd_t.
+extern "C" int mla_attn_bwd_g(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                              const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
+                              int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
+                              const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, int* head_sync,
+                              long long head_sync_ints, int grp_start, int grp_len, hipStream_t stream) {
+  return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
+                       dqT, dkT, dvT, oT, ldt, head_sync, head_sync_ints, stream, nullptr, 0, grp_start, grp_len);
 }
 
 // 5-product backward (experiment build only -- the product library rejects the call): same outputs as

@@ -88,6 +88,11 @@ _SIGNATURES = {
                        c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p],
     "mla_attn_bwd_sync_ints": [c_int, c_int],                # returns long long (restype fixed up in lib())
+    "mla_attn_fwd_g": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong,
+                       c_longlong, c_float, c_int, c_int, c_void_p],
+    "mla_attn_bwd_g": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                       c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "mla_attn_bwd_ws_bytes": [c_int, c_int, c_int],          # returns long long (restype fixed up in lib())
     "mla_attn_bwd_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                         c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
@@ -540,15 +545,19 @@ def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
 
 
 # --------------------------------------------------------------------------------------------- attention
-def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None):
+def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None, groups=None):
     """q/k/v: views into the packed [B*S, 3*H*D] buffer (first element of each slice). rows > B*S: the output gets that many rows,
-    the extra ones zero (row padding of the caller, ops.DecoderLayerFn)."""
+    the extra ones zero (row padding of the caller, ops.DecoderLayerFn). groups = (start, len): shared-prefix sequences -- rows >= start
+    are suffix groups of `len` rows, a query sees the prefix and (causally) its own group only (mla_attn_fwd_g)."""
     rows = B * S if rows is None else rows
     o = torch.empty((rows, H * D), dtype=torch.bfloat16, device=q.device)
     if rows > B * S:
         o[B * S:].zero_()
     lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
-    call("mla_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale))
+    if groups is not None:
+        call("mla_attn_fwd_g", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale), int(groups[0]), int(groups[1]))
+    else:
+        call("mla_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale))
     return o, lse
 
 
@@ -615,7 +624,7 @@ def _head_sync(device, B, H):
 
 
 def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, scale, rope_cos=None, rope_sin=None, transposed=None,
-             five: Optional[bool] = None, merged: Optional[bool] = None):
+             five: Optional[bool] = None, merged: Optional[bool] = None, groups=None):
     """five (experiment build only, see ATTN_BWD5): the five-product form -- the dK / dV kernel hands dS^T (bf16 tiles in a torch-owned
     scratch buffer) to a one-product dQ kernel instead of both kernels recomputing Q K^T and dO V^T (mla_attn_bwd_ws).
     merged (default: on where the dispatch probe holds; MLA_ATTN_BWD_MERGED=0 turns it off): one launch for the dQ and dK / dV blocks
@@ -651,6 +660,14 @@ def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, sca
         raise RuntimeError("attn_bwd(merged=True): the one-launch backward is not available here "
                            f"(MLA_ATTN_BWD_MERGED=0, a stream capture before the first use, or the dispatch probe failed: {_DISPATCH_OK})")
     n_sync = sync.numel() if sync is not None else 0
+    if groups is not None:                               # shared-prefix sequences (mla_attn_bwd_g; see attn_fwd)
+        tq = tk = tv = to_ = None
+        if transposed is not None:
+            tq, tk, tv, to_ = dqkvT[:H * D], dqkvT[H * D:2 * H * D], dqkvT[2 * H * D:], oT
+        call("mla_attn_bwd_g", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
+             H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(tq), _p(tk), _p(tv), _p(to_), ldt if transposed is not None else 0,
+             _p(sync), n_sync, int(groups[0]), int(groups[1]))
+        return
     if transposed is not None:
         call("mla_attn_bwd_t", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
              H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(dqkvT[:H * D]), _p(dqkvT[H * D:2 * H * D]),

@@ -95,6 +95,13 @@ class LlamaRotaryEmbedding(nn.Module):
         self.register_buffer("inv_freq", inv_freq, persistent=False)
         self._cache = {}
 
+    def tables_for_positions(self, positions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """cos / sin rows for explicit position ids [S] (shared-prefix sequences: the suffix groups repeat the same positions);
+        the arithmetic of `tables` (fp32 outer product, modeling_llama.py:131-145)."""
+        inv_freq = 1.0 / (self.base ** (torch.arange(0, self.dim, 2, dtype=torch.int64).float() / self.dim))
+        freqs = torch.outer(positions.detach().cpu().to(torch.float32), inv_freq)
+        return freqs.cos().contiguous().to(positions.device), freqs.sin().contiguous().to(positions.device)
+
     def tables(self, seq_len: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
         key = (seq_len, str(device))
         if key not in self._cache:
@@ -154,13 +161,13 @@ class LlamaDecoderLayer(nn.Module):
                 self.post_attention_layernorm.weight, m.gate_proj.weight, m.up_proj.weight, m.down_proj.weight)
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
-                use_cache=False, cache_position=None, seqlens: Optional[torch.Tensor] = None, **kwargs):
+                use_cache=False, cache_position=None, seqlens: Optional[torch.Tensor] = None, rope_tables=None, **kwargs):
         if past_key_value is not None or use_cache or output_attentions:
             raise NotImplementedError("KV cache / attention-weight output are inference features (SURVEY 8f rank 2)")
         B, S, _ = hidden_states.shape
         if seqlens is None and attention_mask is not None:
             seqlens = attention_mask.reshape(B, -1).sum(-1).to(torch.int32)
-        cos, sin = self.self_attn.rotary_emb.tables(S, hidden_states.device)
+        cos, sin = rope_tables if rope_tables is not None else self.self_attn.rotary_emb.tables(S, hidden_states.device)
         h = ops.unit_boundary(hidden_states, self._grad_hook)
         out = ops.decoder_layer(h, seqlens, cos, sin, self.config.num_attention_heads, self.config.rms_norm_eps,
                                 self.config.layer_save_level(self.layer_idx), self._weights())
@@ -184,7 +191,11 @@ class LlamaModel(nn.Module):
         return ops.embedding(input_ids, self.embed_tokens.weight)
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
-                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, cache_position=None):
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, cache_position=None,
+                attn_groups=None):
+        """attn_groups = (first suffix row, rows per group) with position_ids [S] (round 6, opt-in): one sequence per sample laid out
+        as [prefix | R suffix groups]; every suffix row attends to the prefix and, causally, to its own group, and carries the position
+        it has in the reference's R separate sequences (models/mla/model_mla.py:148-180 tiles the whole sample R times)."""
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time, and must specify either one")
         if past_key_values is not None or use_cache:
@@ -196,10 +207,16 @@ class LlamaModel(nn.Module):
         seqlens = None if attention_mask is None else attention_mask.reshape(B, S).sum(-1).to(torch.int32)
         hidden_states = inputs_embeds
         all_hidden = () if output_hidden_states else None
-        for layer in self.layers:
-            if output_hidden_states:
-                all_hidden += (hidden_states,)
-            hidden_states = layer(hidden_states, seqlens=seqlens)[0]
+        rope_tables = None
+        if attn_groups is not None:
+            if position_ids is None or seqlens is not None:
+                raise ValueError("attn_groups needs explicit position_ids [S] and an unpadded batch")
+            rope_tables = self.layers[0].self_attn.rotary_emb.tables_for_positions(position_ids.reshape(-1)[:S])
+        with ops.attn_groups(attn_groups):
+            for layer in self.layers:
+                if output_hidden_states:
+                    all_hidden += (hidden_states,)
+                hidden_states = layer(hidden_states, seqlens=seqlens, rope_tables=rope_tables)[0]
         hidden_states = self.norm(hidden_states)
         if output_hidden_states:
             all_hidden += (hidden_states,)
@@ -278,12 +295,13 @@ class LlamaForCausalLM(nn.Module):
                 cache_position=None, pc_token_indices=None, img_token_indices=None, tac_token_indices=None,
                 patch_correspondence_indices=None, correspondence_valid_mask=None, positive_pc_indices_for_tac=None,
                 linear_positive_img_indices_for_tac=None, compute_token_contrastive_loss: bool = False,
-                compute_tactile_contrastive_loss: bool = False):
+                compute_tactile_contrastive_loss: bool = False, attn_groups=None):
         output_hidden_states = (output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states)
         need_tap = self.training and (compute_token_contrastive_loss or compute_tactile_contrastive_loss)
         hidden_states, all_hidden = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
                                                past_key_values=past_key_values, use_cache=use_cache,
-                                               output_hidden_states=bool(output_hidden_states or need_tap))
+                                               output_hidden_states=bool(output_hidden_states or need_tap),
+                                               position_ids=position_ids if attn_groups is not None else None, attn_groups=attn_groups)
         B, S, H = hidden_states.shape
         logits, loss, lazy_lm = None, None, None
         if self.config.compute_lm_logits or labels is not None:

@@ -130,6 +130,8 @@ class MLA(nn.Module):
             raise NotImplementedError("the autoregressive branch is dead code in the reference (SURVEY Appendix A #15)")
         R = repeated_diffusion_steps
         rep = lambda v: v.repeat(R, *([1] * (v.ndimension() - 1)))  # noqa: E731
+        if getattr(self, "share_prefix", False) and R > 1 and self.training and self.vlm.shared_prefix_ok():
+            return self._forward_shared_prefix(input_ids, attention_mask, images, camera_name, labels, actions, proprio, R, noise, timestep)
         proprio = rep(proprio)
         actions = rep(actions)
         actions_future = actions[:, -(self.future_action_window_size + 1):, :]
@@ -187,6 +189,31 @@ class MLA(nn.Module):
                 total = total + output.tactile_contrastive_loss.float()
         # the reference's `total_loss` and `diff_loss` are one tensor mutated in place (model_mla.py:215-229), so the
         # reported diff_loss equals total_loss; the true diffusion MSE is kept in self.last_diff_mse
+        loss_dict["total_loss"] = total
+        loss_dict["diff_loss"] = total
+        return loss_dict, output
+
+    def _forward_shared_prefix(self, input_ids, attention_mask, images, camera_name, labels, actions, proprio, R, noise, timestep):
+        """Opt-in (`mla.share_prefix = True`; round 6): the diffusion branch without tiling the sample R times. Only the actions are
+        tiled -- noise and timesteps are drawn exactly like in forward() (randn_like(actions_future) then randint, :178-179), so the
+        same RNG stream gives the same x_t per copy -- and PrismaticVLM.forward_shared_prefix runs [prefix | R suffix groups] once per
+        sample. The loss dict is forward()'s for this configuration (no contrastive / generation terms); `output` is in the shared
+        layout."""
+        rep = lambda v: v.repeat(R, *([1] * (v.ndimension() - 1)))  # noqa: E731
+        actions_future = rep(actions)[:, -(self.future_action_window_size + 1):, :]
+        if noise is None:
+            noise = torch.randn_like(actions_future)
+        if timestep is None:
+            timestep = torch.randint(0, self.diffusion.num_timesteps, (actions_future.size(0),), device=actions.device)
+        x = self.diffusion.q_sample(actions_future, timestep, noise)
+        self.vlm.image_repeat_hint = 1
+        output, noise_pred = self.vlm.forward_shared_prefix(x, timestep, R, proprio, input_ids, attention_mask, images, camera_name, labels)
+        assert noise_pred.shape == noise.shape == actions_future.shape
+        zero = lambda: torch.tensor(0, dtype=torch.float32)  # noqa: E731
+        loss_dict = {"total_loss": zero(), "img_pc_contrastive_loss": zero(), "tactile_contrastive_loss": zero(),
+                     "diff_loss": zero(), "image_gen_loss": zero(), "point_cloud_gen_loss": zero(), "tactile_gen_loss": zero()}
+        total = ((noise_pred.float() - noise.float()) ** 2).mean()
+        self.last_diff_mse = total.detach().clone()
         loss_dict["total_loss"] = total
         loss_dict["diff_loss"] = total
         return loss_dict, output

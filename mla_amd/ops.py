@@ -10,6 +10,7 @@ Conventions
 from __future__ import annotations
 
 import math
+import threading
 import os
 from typing import List, Optional, Sequence
 
@@ -192,6 +193,13 @@ def deliver_vec_grad(param: torch.Tensor, compute):
 
 def _pad8(n: int) -> int:
     return (n + 7) // 8 * 8
+
+
+def _pad_tokens(n: int) -> int:
+    """Token rows of a decoder layer: a multiple of 8 (the tile transposes of the all-NT backward move 8 tokens per 16-B access) and, for
+    more than a tile of tokens, of 32 -- the token count is the REDUCTION dimension of every wgrad GEMM, and K % 32 != 0 sends a GEMM to
+    the SIMT fallback kernel (round 6: the shared-prefix layout has 8 x 2 057 = 16 456 rows; unpadded its step ran at 118 TFLOP/s)."""
+    return (n + 31) // 32 * 32 if n > 256 else (n + 7) // 8 * 8
 
 
 def _as2d(x: torch.Tensor) -> torch.Tensor:
@@ -526,6 +534,30 @@ _ATTN_BWD_T = os.environ.get("MLA_ATTN_BWD_T", "1") != "0"           # dqkv^T / 
 _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (tools): 0 = recompute act^T in the backward
 
 
+# Suffix groups of shared-prefix sequences (round 6, mla_hip.h: mla_attn_fwd_g): (first suffix row, rows per group) or None. Set by the
+# caller of the decoder stack for the duration of its forward (LlamaModel.forward(attn_groups=...)); every DecoderLayerFn.forward
+# records the value it saw in its ctx, so backward and checkpoint recomputation use the same grouping whatever is current then.
+_ATTN_GROUPS = threading.local()
+
+
+def current_attn_groups():
+    return getattr(_ATTN_GROUPS, "value", None)
+
+
+class attn_groups:
+    """with ops.attn_groups((start, length)): ... -- the decoder layers run inside see the suffix-group attention mask."""
+
+    def __init__(self, groups):
+        self.groups = groups
+
+    def __enter__(self):
+        self.prev = current_attn_groups()
+        _ATTN_GROUPS.value = self.groups
+
+    def __exit__(self, *a):
+        _ATTN_GROUPS.value = self.prev
+
+
 class DecoderLayerFn(torch.autograd.Function):
     """One whole LlamaDecoderLayer (transformers/models/llama/modeling_llama.py:695-767) as a single autograd node.
 
@@ -541,7 +573,7 @@ class DecoderLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False):
+    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False, groups=None):
         ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
         H = h2.shape[1]
         D = H // nheads
@@ -559,7 +591,7 @@ class DecoderLayerFn(torch.autograd.Function):
                     hip.gemm(xn1, wi, out=qkv[:, i * H:(i + 1) * H])
             hip.rope_inplace(qkv, cos, sin, S, nheads, D, 0, H)
         o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
-                              rows=h2.shape[0])
+                              rows=h2.shape[0], groups=groups)
         h1 = hip.gemm(o, wo, residual=h2)
         xn2, rstd2 = hip.rmsnorm_fwd(h1, ln2, eps)
         I = wg.shape[0]
@@ -592,7 +624,7 @@ class DecoderLayerFn(torch.autograd.Function):
         h2 = h.reshape(B * S, H)
         if not h2.is_contiguous():
             h2 = h2.contiguous()
-        T, Tp = B * S, _pad8(B * S)
+        T, Tp = B * S, _pad_tokens(B * S)
         if Tp != T:
             # the tile transposes of the all-NT backward move 8 tokens per 16-B access: an odd token count (per-device batch 1 with
             # an odd padded length) runs on zero rows appended here; they stay zero through every row-wise op, contribute zero to
@@ -601,8 +633,9 @@ class DecoderLayerFn(torch.autograd.Function):
         keep_t = save_level == 1 and ctx.needs_input_grad[7 + 8] and _SWIGLU_DUAL   # down_proj trainable: its wgrad wants act^T
         if save_level == 3:
             save_level = 1                         # "1-lean": same saved set as level 1 minus act^T
+        ctx.groups = current_attn_groups()
         out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w,
-                                                                                             save_t=keep_t)
+                                                                                             save_t=keep_t, groups=ctx.groups)
         out = out[:T]
         ctx.w, ctx.dims, ctx.save_level = w, (B, S, H, nheads, eps), save_level
         ctx.aux = (seqlens, cos, sin)
@@ -639,12 +672,13 @@ class DecoderLayerFn(torch.autograd.Function):
                 h2, rstd1, qkv, o, lse, h1, rstd2, gu = ctx.saved_tensors
         else:
             (h2,) = ctx.saved_tensors
-            _, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, _) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w)
+            _, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, _) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w,
+                                                                                            groups=ctx.groups)
         need = ctx.needs_input_grad[7:]
         d2 = dout.reshape(T, H)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
-        Tr, T = T, _pad8(T)                     # row padding of forward(): zero gradient rows
+        Tr, T = T, _pad_tokens(T)               # row padding of forward(): zero gradient rows
         if T != Tr:
             d2 = torch.cat([d2, d2.new_zeros(T - Tr, H)], 0)
         grads: List[Optional[torch.Tensor]] = [None] * 9
@@ -710,7 +744,7 @@ class DecoderLayerFn(torch.autograd.Function):
                 tr[1][:, Tr:].zero_()
         hip.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, seqlens, dqkv[:, :H], dqkv[:, H:2 * H],
                      dqkv[:, 2 * H:], B, S, nheads, D, 3 * H, 1.0 / math.sqrt(D), rope_cos=cos if fuse_rope else None,
-                     rope_sin=sin if fuse_rope else None, transposed=tr)
+                     rope_sin=sin if fuse_rope else None, transposed=tr, groups=ctx.groups)
         del do
         if not fuse_rope:
             hip.rope_inplace(dqkv, cos, sin, S, nheads, D, 0, H, backward=True)

@@ -307,6 +307,74 @@ class PrismaticVLM(nn.Module):
         losses["total_generation_loss"] = total
         return losses
 
+    # ------------------------------------------------------------------------------------------ shared-prefix forward (round 6, opt-in)
+    def shared_prefix_ok(self) -> bool:
+        """The R diffusion repeats of a sample can share their prefix only when everything in front of the [t, x] tokens is the same
+        function of the sample in all R copies: no point tokenizer (its FPS start indices are drawn per copy, Point_PN.py:10), and none
+        of the consumers of the R-tiled hidden states (contrastive tap, generation heads, tactile). That is the `scripts/pretrain.sh`
+        configuration (BASELINE configs[4]: use_pointcloud=False)."""
+        return not (self.use_pointcloud or self.use_contrastive or self.use_generation or self.use_tactile)
+
+    def forward_shared_prefix(self, x, t, repeats: int, proprio, input_ids, attention_mask, images, camera_name, labels=None):
+        """The diffusion-branch forward for R = `repeats` copies of every sample WITHOUT tiling the sample (models/mla/model_mla.py:148-180
+        tiles all inputs R times; models/vlm/prismatic.py:981-1038 then builds R identical prefixes). One sequence per sample:
+            [BOS | pc 256 (zeros) | img 256 | tac 1 (zero) | text[1:k] | proprio]   +   R x [t_r | x_r (T rows) | text[k:]]
+        with the suffix rows of copy r attending to the prefix and (causally) to their own copy only, at the positions they have in the
+        reference's layout. x [R * B, T, A], t [R * B] in the reference's tiled order (index r * B + i). Executes P + R s rows per sample
+        instead of R (P + s). Same mathematics (the prefix rows of the R copies are identical by construction); gradients reach the
+        prefix summed over the R copies inside the attention backward instead of through R separate sequences.
+        Returns (output, noise_pred [R * B, T, A]) -- output.hidden_states / logits are in the SHARED layout [B, P + R s, .]."""
+        assert self.training and self.shared_prefix_ok()
+        bf16 = torch.bfloat16
+        R = repeats
+        B, L = input_ids.shape
+        dev = input_ids.device
+        tag_0 = 2                                                                # prismatic.py:882-884 (train)
+        is_tag = input_ids == tag_0
+        k_all = L - 1 - torch.flip(is_tag, dims=[1]).int().argmax(dim=1)
+        ok = is_tag.any(dim=1).all() & (k_all == k_all[0]).all() & (attention_mask.bool().all() if attention_mask is not None else True)
+        parts, _, _, _, _, _ = self.get_fused_tokens(images, None, None, None, camera_name)
+        text_emb = self.llm_backbone.embed_input_ids(input_ids)                   # [B, L, H]
+        proprio_e = self.proprio_embedder(proprio.to(bf16))                      # [B, 1, H]
+        x_e = self.x_embedder(x.to(bf16))                                        # [R * B, T, H]
+        t_e = self.t_embedder(t.to(bf16)).unsqueeze(1)                           # [R * B, 1, H]
+        self.vision_tower_2d.assert_masks_ok()
+        if not bool(ok):                                                         # (one host sync, like the tag check of forward())
+            raise ValueError("shared-prefix forward needs an unpadded batch with the same splice position in every row "
+                             "(models/vlm/prismatic.py:983); use the tiled forward for ragged batches")
+        k = int(k_all[0])
+        T, H = x_e.shape[1], text_emb.shape[2]
+        n_fused = sum(p_.shape[1] for p_ in parts)
+        P, s_len = k + n_fused + 1, 1 + T + (L - k)
+        S = P + R * s_len
+        tail = text_emb[:, k:]
+        seq = [text_emb[:, :1]] + parts + [text_emb[:, 1:k], proprio_e]
+        for r in range(R):
+            seq += [t_e[r * B:(r + 1) * B], x_e[r * B:(r + 1) * B], tail]
+        fused_embeddings = torch.cat(seq, dim=1)                                 # [B, S, H]
+        assert fused_embeddings.shape[1] == S
+        positions = torch.cat([torch.arange(P), torch.arange(P, P + s_len).repeat(R)]).to(dev)
+        fused_labels = None
+        if labels is not None:
+            ign = lambda n: torch.full((B, n), -100, dtype=labels.dtype, device=dev)   # noqa: E731
+            lab = [labels[:, :1], ign(n_fused), labels[:, 1:k], ign(1)]
+            for _ in range(R):
+                lab += [ign(1 + T), labels[:, k:]]
+            fused_labels = torch.cat(lab, dim=1)
+        output: CausalLMOutputWithPast = self.llm_backbone(
+            input_ids=None, attention_mask=None, position_ids=positions, inputs_embeds=fused_embeddings, labels=fused_labels,
+            output_hidden_states=True, return_dict=True, attn_groups=(P, s_len))
+        last_hidden = output.hidden_states[-1]
+        # action read-out (:1115-1126): the x rows of copy r of sample i, in the reference's tiled order r * B + i
+        rr = torch.arange(R, device=dev)[:, None, None]
+        ii = torch.arange(B, device=dev)[None, :, None]
+        jj = torch.arange(T, device=dev)[None, None, :]
+        rows = (ii * S + P + rr * s_len + 1 + jj).reshape(-1)
+        picked = ops.gather_rows(last_hidden.reshape(B * S, H), rows)
+        noise_pred = self.final_layer(picked).view(R * B, T, -1)
+        output.shared_prefix_layout = dict(prefix_rows=P, suffix_rows=s_len, repeats=R, executed_rows_per_sample=S, tiled_rows_per_sample=R * (P + s_len))
+        return output, noise_pred
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x=None, t=None, z=None, proprio=None, gripper_xyz=None, input_ids=None, attention_mask=None, images=None,
                 camera_name=None, point_cloud=None, tactile=None, labels=None, inputs_embeds=None, past_key_values=None,

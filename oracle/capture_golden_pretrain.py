@@ -3,6 +3,9 @@ reference -- build container only.
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/capture_golden_pretrain.py          # -> mla_tiny_e2e_pretrain.npz
     PYTHONDONTWRITEBYTECODE=1 python oracle/capture_golden_pretrain.py --pc     # point tower trained too -> mla_tiny_e2e_pretrain_pc.npz
+    PYTHONDONTWRITEBYTECODE=1 python oracle/capture_golden_pretrain.py --eq R   # unpadded batch (equal text lengths), R diffusion repeats
+                                                                               #   -> mla_tiny_e2e_pretrain_eq.npz: the fixture of the
+                                                                               #   shared-prefix forward (round 6), which needs no padding
 
 Tiny MLA (recipe weights), freeze_backbones("pretrain"), one forward/backward in fp32 (mode A) and bf16 autocast (mode C):
 losses and every gradient norm, plus slices of the vision-tower gradients. Writes tests/golden/mla_tiny_e2e_pretrain.npz.
@@ -35,14 +38,14 @@ PC_VECS = ("vlm.vision_tower_3d.patch_embed.EncP.raw_point_embed.net.1.weight",
            "vlm.vision_tower_3d.patch_embed.EncP.LGA_list.1.linear2.0.net2.0.bias", "vlm.vision_tower_3d.proj.bias")
 
 
-def run(mode, R=2, pc=False):
+def run(mode, R=2, pc=False, ragged=True):
     mla = ref_import.build_reference_mla(recipe.TINY_LLAMA | {"vocab_size": recipe.TINY_LLAMA["vocab_size"] + 1}, recipe.TOKEN_SIZE,
                                          use_pointcloud=pc, use_contrastive=pc)
     shapes = {k: tuple(v.shape) for k, v in mla.state_dict().items()}
     mla.load_state_dict(recipe.make_state_dict(shapes), strict=True)
     mla.freeze_backbones("pretrain")
     mla.train()
-    batch, draws = recipe.make_batch(R=R)
+    batch, draws = recipe.make_batch(R=R, ragged=ragged)
     kw = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"],
               point_cloud=batch["point_cloud"] if pc else None, actions=batch["actions"], proprio=batch["proprio"], action_masks=batch["action_masks"],
               camera_name=batch["camera_name"], gripper_xyz=None, output_hidden_states=True, repeated_diffusion_steps=R, use_diff=True)
@@ -72,9 +75,11 @@ def run(mode, R=2, pc=False):
 
 def main():
     pc = "--pc" in sys.argv
-    res = {}
+    eq = "--eq" in sys.argv
+    R = int(sys.argv[sys.argv.index("--eq") + 1]) if eq else 2
+    res = {"R": np.array(R)} if eq else {}
     for mode in ("A", "C"):
-        shapes, ld, grads = run(mode, pc=pc)
+        shapes, ld, grads = run(mode, R=R, pc=pc, ragged=not eq)
         f = lambda t: t.detach().float().numpy()  # noqa: E731
         res[f"{mode}_total_loss"] = f(ld["total_loss"])
         res[f"{mode}_gradnorms"] = np.array([float(grads[k].float().norm()) for k in sorted(grads)], dtype=np.float64)
@@ -89,7 +94,7 @@ def main():
             res["grad_names"] = np.array(sorted(grads))
             res["param_names"] = np.array(sorted(shapes))
             res["param_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
-    name = "mla_tiny_e2e_pretrain_pc.npz" if pc else "mla_tiny_e2e_pretrain.npz"
+    name = "mla_tiny_e2e_pretrain_eq.npz" if eq else "mla_tiny_e2e_pretrain_pc.npz" if pc else "mla_tiny_e2e_pretrain.npz"
     np.savez_compressed(os.path.join(OUT, name), **res)
     vt = [n for n in res["grad_names"] if "vision_tower_" in str(n)]
     print(name, ": A loss", res["A_total_loss"], "C loss", res["C_total_loss"], "| vision-tower params with grad:", vt)

@@ -261,6 +261,68 @@ def test_attention_fwd_bwd(dev, B, S, H, lens):
             assert float(dqkv[rows].float().abs().max() if int(seqlens[b_]) < S else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("P,s,R,B", [(61, 3, 4, 2), (130, 3, 4, 1), (64, 5, 2, 2), (200, 1, 8, 1), (2045, 3, 4, 1), (20, 4, 3, 3)])
+def test_attention_suffix_groups_match_masked_reference_and_separate_sequences(dev, P, s, R, B):
+    """mla_attn_fwd_g / mla_attn_bwd_g (round 6, shared-prefix sequences): one sequence [prefix P | R suffix groups of s rows]; a suffix
+    row attends to the prefix and, causally, to its own group. Checked (a) against the fp32 reference with that mask (forward and all
+    three gradients, with the transposed copies, the fused RoPE backward and the one-launch backward), for prefixes that end inside a
+    64-row tile, on a tile boundary and two tiles before the end; (b) against what it replaces -- R separate causal sequences
+    [prefix | suffix_r] through the plain kernels: same suffix outputs, and dK / dV of the prefix = the SUM over the R sequences."""
+    from mla_amd import hip
+    H, D = 3, 128
+    S = P + R * s
+    g = torch.Generator().manual_seed(P * 7 + s)
+    qkv = (torch.randn(B * S, 3 * H * D, generator=g) * 0.7).to(BF)
+    do = (torch.randn(B * S, H * D, generator=g) * 0.5).to(BF)
+    dq_ = qkv.to(dev)
+    q, k, v = dq_[:, :H * D], dq_[:, H * D:2 * H * D], dq_[:, 2 * H * D:]
+    o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, None, 1 / math.sqrt(D), groups=(P, s))
+    idx = torch.arange(S)
+    grp = torch.where(idx >= P, (idx - P) // s, torch.full_like(idx, -1))
+    allowed = (idx[None, :] <= idx[:, None]) & ((idx[None, :] < P) | (grp[None, :] == grp[:, None]))
+    qf, kf, vf = (qkv[:, i * H * D:(i + 1) * H * D].float().view(B, S, H, D).transpose(1, 2).requires_grad_(True) for i in range(3))
+    sc = (qf @ kf.transpose(-1, -2)) / math.sqrt(D)
+    ref = (torch.softmax(sc.masked_fill(~allowed, float("-inf")), -1) @ vf).transpose(1, 2).reshape(B * S, H * D)
+    e_o = fro_rel(o, ref)
+    assert e_o < 5e-3, e_o
+    ref.backward(do.float())
+    gq, gk, gv = (t.grad.transpose(1, 2).reshape(B * S, H * D) for t in (qf, kf, vf))
+    outs = {}
+    for merged in (False, True):
+        dqkv = torch.full_like(dq_, float("nan"))
+        tr = (torch.full((3 * H * D, B * S), float("nan"), dtype=BF, device=dev), torch.full((H * D, B * S), float("nan"), dtype=BF, device=dev)) if S % 4 == 0 else None
+        hip.attn_bwd(q, k, v, o, do.to(dev), lse, None, dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:], B, S, H, D, 3 * H * D,
+                     1 / math.sqrt(D), transposed=tr, merged=merged, groups=(P, s))
+        outs[merged] = dqkv
+        assert torch.isfinite(dqkv.float()).all()
+        if tr is not None:
+            assert torch.equal(tr[0], dqkv.t().contiguous()) and torch.equal(tr[1], o.t().contiguous())
+    assert torch.equal(outs[True], outs[False])                                # one launch == two launches, with groups too
+    e = [fro_rel(outs[True][:, i * H * D:(i + 1) * H * D], gr) for i, gr in enumerate((gq, gk, gv))]
+    print(f"suffix groups P={P} s={s} R={R} B={B}: o {e_o:.2e} dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+    assert max(e) < 1e-2, e
+    # (b) the R separate sequences this layout replaces
+    Sr = P + s
+    rows = torch.cat([torch.cat([torch.arange(P), P + r * s + torch.arange(s)]) + b * S for r in range(R) for b in range(B)])   # sequence index r * B + b
+    sep = dq_[rows.to(dev)].contiguous()
+    o2, lse2 = hip.attn_fwd(sep[:, :H * D], sep[:, H * D:2 * H * D], sep[:, 2 * H * D:], R * B, Sr, H, D, 3 * H * D, None, 1 / math.sqrt(D))
+    o2 = o2.view(R, B, Sr, H * D)
+    og = o.view(B, S, H * D)
+    for r in range(R):
+        assert fro_rel(og[:, P + r * s:P + (r + 1) * s], o2[r][:, P:].float().cpu()) < 4e-3
+        assert fro_rel(og[:, :P], o2[r][:, :P].float().cpu()) < 4e-3
+    d2 = torch.full_like(sep, float("nan"))
+    do2 = do.to(dev)[rows.to(dev)].contiguous()
+    do2.view(R, B, Sr, H * D)[1:, :, :P] = 0                                   # the prefix rows' own output gradient counts once, not R times
+    hip.attn_bwd(sep[:, :H * D], sep[:, H * D:2 * H * D], sep[:, 2 * H * D:], o2.reshape(R * B * Sr, H * D), do2, lse2, None, d2[:, :H * D],
+                 d2[:, H * D:2 * H * D], d2[:, 2 * H * D:], R * B, Sr, H, D, 3 * H * D, 1 / math.sqrt(D))
+    d2 = d2.float().view(R, B, Sr, 3 * H * D)
+    mine = outs[True].float().view(B, S, 3 * H * D)
+    assert fro_rel(mine[:, :P], d2[:, :, :P].sum(0)) < 1e-2                    # prefix: summed over the R copies
+    for r in range(R):
+        assert fro_rel(mine[:, P + r * s:P + (r + 1) * s], d2[r][:, P:]) < 1e-2
+
+
 @pytest.mark.parametrize("T,S,nh", [(548 * 2, 548, 4), (300, 100, 2), (2048, 2048, 2)])
 def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, T, S, nh):
     """mla_gemm_qkv_rope == mla_gemm_bf16 + mla_rope_inplace on the packed q|k|v buffer, bit for bit (ragged tile edges: T % 256 != 0,

@@ -180,13 +180,16 @@ def test_trainable_point_tokenizer_gradients_vs_oracle(dev):
     assert report["proj.weight"][0] < 1e-2               # no max-pool below it: tight
 
 
-def run_pretrain_e2e(dev, pc):
-    """Builds the stage-"pretrain" tiny MLA, runs forward + backward on the recipe batch; returns (model, loss_dict, golden)."""
+def run_pretrain_e2e(dev, pc, eq=False, share_prefix=False):
+    """Builds the stage-"pretrain" tiny MLA, runs forward + backward on the recipe batch; returns (model, loss_dict, golden).
+    eq: the unpadded batch with R = 4 diffusion repeats (mla_tiny_e2e_pretrain_eq.npz); share_prefix: the opt-in shared-prefix forward."""
     from mla_amd.backbones import LLaMa2LLMBackbone
     from mla_amd.llama import LlamaConfig
     from mla_amd.mla import MLA
     from mla_amd.prismatic import PrismaticVLM
-    gold = np.load(os.path.join(G, "mla_tiny_e2e_pretrain_pc.npz" if pc else "mla_tiny_e2e_pretrain.npz"), allow_pickle=True)
+    gold = np.load(os.path.join(G, "mla_tiny_e2e_pretrain_eq.npz" if eq else "mla_tiny_e2e_pretrain_pc.npz" if pc else "mla_tiny_e2e_pretrain.npz"),
+                   allow_pickle=True)
+    R = int(gold["R"]) if eq else 2
     bb = LLaMa2LLMBackbone(config=LlamaConfig(**recipe.TINY_LLAMA, activation_save_level=2), pad_to_multiple_of=1)
     vlm = PrismaticVLM("tiny", bb, token_size=recipe.TOKEN_SIZE, use_diff=True, use_pointcloud=pc, use_contrastive=pc, use_generation=False)
     m = MLA(vlm, None, token_size=recipe.TOKEN_SIZE, future_action_window_size=0, use_diff=True, use_pointcloud=pc, use_contrastive=pc)
@@ -197,16 +200,18 @@ def run_pretrain_e2e(dev, pc):
     m.train().to(dev)
     for p in m.parameters():
         p.data = p.data.to(BF)
-    batch, draws = recipe.make_batch(R=2)
+    m.share_prefix = share_prefix
+    batch, draws = recipe.make_batch(R=R, ragged=not eq)
     to = lambda v: v.to(dev)  # noqa: E731
     if pc:
         m.vlm.vision_tower_3d.fps_starts_override = [draws["fps_start0"], draws["fps_start1"]]
     ld, out = m(input_ids=to(batch["input_ids"]), attention_mask=to(batch["attention_mask"]), labels=to(batch["labels"]),
                 images={"front_image": to(batch["images"]["front_image"])}, point_cloud=to(batch["point_cloud"]) if pc else None,
                 actions=to(batch["actions"]), proprio=to(batch["proprio"]),
-                action_masks=to(batch["action_masks"]), camera_name=batch["camera_name"], repeated_diffusion_steps=2, use_diff=True,
+                action_masks=to(batch["action_masks"]), camera_name=batch["camera_name"], repeated_diffusion_steps=R, use_diff=True,
                 noise=to(draws["noise"]), timestep=to(draws["timestep"]))
     ld["total_loss"].backward()
+    run_pretrain_e2e.last_output = out
     return m, ld, gold
 
 
@@ -245,6 +250,42 @@ def test_mla_e2e_pretrain_stage(dev, pc):
     rows = grad_sample_rows(grads, gold)
     assert len(rows) == len(names)
     assert not strict_violations(rows), strict_violations(rows)
+
+
+def test_shared_prefix_forward_matches_the_reference_golden_like_the_tiled_forward(dev):
+    """Round 6, opt-in (`mla.share_prefix = True`): stage "pretrain" without a point cloud (BASELINE configs[4], scripts/pretrain.sh) --
+    the R = 4 diffusion copies of a sample differ only in their last rows [t, x, </s>], so ONE sequence [prefix | 4 suffix groups] per
+    sample replaces the reference's 4 tiled sequences (models/mla/model_mla.py:148-180). Against the reference golden of the same
+    unpadded batch (mla_tiny_e2e_pretrain_eq.npz, captured from the real reference's TILED forward): loss and the strict per-tensor
+    gradient yardstick on every parameter, for the shared-prefix forward AND for the tiled forward; the two agree with each other far
+    inside that bound; the shared layout executes P + R s rows per sample instead of R (P + s)."""
+    from parity_util import grad_sample_rows, strict_violations
+    res = {}
+    for share in (False, True):
+        m, ld, gold = run_pretrain_e2e(dev, False, eq=True, share_prefix=share)
+        A, C = float(gold["A_total_loss"]), float(gold["C_total_loss"])
+        half_ulp = 2.0 ** (np.floor(np.log2(abs(A))) - 7) / 2                      # mode C's loss is a bf16 number
+        assert abs(float(ld["total_loss"]) - A) <= 2 * max(abs(C - A), half_ulp), (share, float(ld["total_loss"]), A, C)
+        grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        assert sorted(grads) == [str(n) for n in gold["grad_names"]]
+        rows = grad_sample_rows(grads, gold)
+        assert not strict_violations(rows), (share, strict_violations(rows))
+        res[share] = (float(ld["total_loss"]), {k: v.float().cpu() for k, v in grads.items()}, np.median([r["ratio"] for r in rows]))
+        if share:
+            lay = run_pretrain_e2e.last_output.shared_prefix_layout
+            assert lay["repeats"] == 4 and lay["executed_rows_per_sample"] == lay["prefix_rows"] + 4 * lay["suffix_rows"]
+            assert lay["tiled_rows_per_sample"] == 4 * (lay["prefix_rows"] + lay["suffix_rows"])
+            # the (lazy) language-model loss of the shared layout: the same R * B next-token terms as the tiled layout
+            res["llm_loss_shared"] = float(run_pretrain_e2e.last_output.loss)
+        else:
+            res["llm_loss_tiled"] = float(run_pretrain_e2e.last_output.loss)
+    assert abs(res[True][0] - res[False][0]) <= 2e-3 * abs(res[False][0]), (res[True][0], res[False][0])
+    assert abs(res["llm_loss_shared"] - res["llm_loss_tiled"]) <= 5e-3 * abs(res["llm_loss_tiled"]), (res["llm_loss_shared"], res["llm_loss_tiled"])
+    num = sum(float(((res[True][1][k] - res[False][1][k]) ** 2).sum()) for k in res[True][1]) ** 0.5
+    den = sum(float((res[False][1][k] ** 2).sum()) for k in res[True][1]) ** 0.5
+    print(f"shared-prefix vs tiled forward: loss {res[True][0]:.6f} vs {res[False][0]:.6f}, all gradients rel {num / den:.2e}; "
+          f"median gradient-sample ratio vs mode C: shared {res[True][2]:.2f}, tiled {res[False][2]:.2f}")
+    assert num / den < 2e-2
 
 
 def test_pretrain_step_with_point_tower_through_fsdp(dev):
