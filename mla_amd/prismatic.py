@@ -346,20 +346,29 @@ class PrismaticVLM(nn.Module):
         T, H = x_e.shape[1], text_emb.shape[2]
         n_fused = sum(p_.shape[1] for p_ in parts)
         P, s_len = k + n_fused + 1, 1 + T + (L - k)
-        S = P + R * s_len
+        # the attention backward writes its transposed (wgrad-operand) copies only for S % 4 == 0: up to three DUMMY suffix groups of zero
+        # rows are appended when that makes the row count a multiple of 4 (no loss reads them, so no gradient flows from them; a group
+        # only ever attends to the prefix and itself, so no real row sees them)
+        n_dummy = next((d for d in range(4) if (P + (R + d) * s_len) % 4 == 0), 0)
+        G = R + n_dummy
+        S = P + G * s_len
         tail = text_emb[:, k:]
         seq = [text_emb[:, :1]] + parts + [text_emb[:, 1:k], proprio_e]
         for r in range(R):
             seq += [t_e[r * B:(r + 1) * B], x_e[r * B:(r + 1) * B], tail]
+        if n_dummy:
+            seq.append(torch.zeros((B, n_dummy * s_len, H), dtype=text_emb.dtype, device=dev))
         fused_embeddings = torch.cat(seq, dim=1)                                 # [B, S, H]
         assert fused_embeddings.shape[1] == S
-        positions = torch.cat([torch.arange(P), torch.arange(P, P + s_len).repeat(R)]).to(dev)
+        positions = torch.cat([torch.arange(P), torch.arange(P, P + s_len).repeat(G)]).to(dev)
         fused_labels = None
         if labels is not None:
             ign = lambda n: torch.full((B, n), -100, dtype=labels.dtype, device=dev)   # noqa: E731
             lab = [labels[:, :1], ign(n_fused), labels[:, 1:k], ign(1)]
             for _ in range(R):
                 lab += [ign(1 + T), labels[:, k:]]
+            if n_dummy:
+                lab.append(ign(n_dummy * s_len))
             fused_labels = torch.cat(lab, dim=1)
         output: CausalLMOutputWithPast = self.llm_backbone(
             input_ids=None, attention_mask=None, position_ids=positions, inputs_embeds=fused_embeddings, labels=fused_labels,
@@ -372,7 +381,8 @@ class PrismaticVLM(nn.Module):
         rows = (ii * S + P + rr * s_len + 1 + jj).reshape(-1)
         picked = ops.gather_rows(last_hidden.reshape(B * S, H), rows)
         noise_pred = self.final_layer(picked).view(R * B, T, -1)
-        output.shared_prefix_layout = dict(prefix_rows=P, suffix_rows=s_len, repeats=R, executed_rows_per_sample=S, tiled_rows_per_sample=R * (P + s_len))
+        output.shared_prefix_layout = dict(prefix_rows=P, suffix_rows=s_len, repeats=R, dummy_groups=n_dummy, executed_rows_per_sample=S,
+                                           tiled_rows_per_sample=R * (P + s_len))
         return output, noise_pred
 
     # ------------------------------------------------------------------------------------------ forward

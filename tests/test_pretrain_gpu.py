@@ -273,7 +273,8 @@ def test_shared_prefix_forward_matches_the_reference_golden_like_the_tiled_forwa
         res[share] = (float(ld["total_loss"]), {k: v.float().cpu() for k, v in grads.items()}, np.median([r["ratio"] for r in rows]))
         if share:
             lay = run_pretrain_e2e.last_output.shared_prefix_layout
-            assert lay["repeats"] == 4 and lay["executed_rows_per_sample"] == lay["prefix_rows"] + 4 * lay["suffix_rows"]
+            assert lay["repeats"] == 4 and lay["executed_rows_per_sample"] == lay["prefix_rows"] + (4 + lay["dummy_groups"]) * lay["suffix_rows"]
+            assert lay["executed_rows_per_sample"] % 4 == 0 or lay["dummy_groups"] == 0
             assert lay["tiled_rows_per_sample"] == 4 * (lay["prefix_rows"] + lay["suffix_rows"])
             # the (lazy) language-model loss of the shared layout: the same R * B next-token terms as the tiled layout
             res["llm_loss_shared"] = float(run_pretrain_e2e.last_output.loss)
