@@ -249,8 +249,8 @@ def test_gradient_accumulation_matches_one_big_batch(dev):
 
 def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_right(dev):
     """Gradient-norm partials vs accumulation (round-2 advisor finding): micro-batch 1 has T = 2 x 544 = 1088 tokens (T % 64 == 0, so the
-    wgrad launches leave sum(dW^2) partials), micro-batch 2 is a shorter sample (24 text tokens: T = 2 x 540 = 1080, not a multiple
-    of 64: plain accumulate launches). The partials of micro-batch 1 describe values that micro-batch 2
+    wgrad launches leave sum(dW^2) partials), micro-batch 2 is a shorter sample (12 text tokens: T = 2 x 528 = 1056, a multiple of 32 --
+    round 6 pads a layer's token rows to that -- but not of 64: plain accumulate launches). The partials of micro-batch 1 describe values that micro-batch 2
     has since added to -- they must be dropped, and the clipping norm must equal the norm of the fp32 gradient buffers."""
     from mla_amd.strategy import FSDPStrategy
     from oracle import recipe
@@ -261,7 +261,7 @@ def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_righ
     assert strat.grad_accumulation_steps == 2
     strat.run_setup(100)
     batch, draws = recipe.make_batch(B=2, L=28, R=R, ragged=False)
-    lens = [28, 24]
+    lens = [28, 12]
     orig = m.forward
 
     def micro(part):
