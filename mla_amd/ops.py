@@ -197,9 +197,10 @@ def _pad8(n: int) -> int:
 
 def _pad_tokens(n: int) -> int:
     """Token rows of a decoder layer: a multiple of 8 (the tile transposes of the all-NT backward move 8 tokens per 16-B access) and, for
-    more than a tile of tokens, of 32 -- the token count is the REDUCTION dimension of every wgrad GEMM, and K % 32 != 0 sends a GEMM to
-    the SIMT fallback kernel (round 6: the shared-prefix layout has 8 x 2 057 = 16 456 rows; unpadded its step ran at 118 TFLOP/s)."""
-    return (n + 31) // 32 * 32 if n > 256 else (n + 7) // 8 * 8
+    more than a tile of tokens, of 64 -- the token count is the REDUCTION dimension of every wgrad GEMM: K % 32 != 0 sends a GEMM to
+    the SIMT fallback kernel (round 6: the shared-prefix layout has 8 x 2 057 = 16 456 rows; unpadded its step ran at 118 TFLOP/s), and the
+    256-tile kernel's K step is 64. The benchmark shapes (17 536 = 274 x 64, 65 536) are multiples of 64 already."""
+    return (n + 63) // 64 * 64 if n > 256 else (n + 7) // 8 * 8
 
 
 def _as2d(x: torch.Tensor) -> torch.Tensor:

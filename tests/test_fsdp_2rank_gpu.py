@@ -249,9 +249,11 @@ def test_gradient_accumulation_matches_one_big_batch(dev):
 
 def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_right(dev):
     """Gradient-norm partials vs accumulation (round-2 advisor finding): micro-batch 1 has T = 2 x 544 = 1088 tokens (T % 64 == 0, so the
-    wgrad launches leave sum(dW^2) partials), micro-batch 2 is a shorter sample (12 text tokens: T = 2 x 528 = 1056, a multiple of 32 --
-    round 6 pads a layer's token rows to that -- but not of 64: plain accumulate launches). The partials of micro-batch 1 describe values that micro-batch 2
+    wgrad launches leave sum(dW^2) partials), micro-batch 2 is a shorter sample whose wgrad launches are plain accumulates WITHOUT
+    partials (until round 5 because its T = 1080 was not a multiple of 64; round 6 pads a layer's token rows to 64, so the test
+    switches the partials off for that micro-batch). The partials of micro-batch 1 describe values that micro-batch 2
     has since added to -- they must be dropped, and the clipping norm must equal the norm of the fp32 gradient buffers."""
+    from mla_amd import ops
     from mla_amd.strategy import FSDPStrategy
     from oracle import recipe
     R = 2
@@ -261,7 +263,7 @@ def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_righ
     assert strat.grad_accumulation_steps == 2
     strat.run_setup(100)
     batch, draws = recipe.make_batch(B=2, L=28, R=R, ragged=False)
-    lens = [28, 12]
+    lens = [28, 24]
     orig = m.forward
 
     def micro(part):
@@ -281,7 +283,11 @@ def test_accumulation_window_with_changing_token_counts_keeps_the_clip_norm_righ
         micro(0)
         layer_units = [u for u in strat.sharded.units if u.name.endswith("layers.3")]
         assert layer_units and len(layer_units[0].sq_entries) >= 4, "micro-batch 1 should have registered wgrad-epilogue partials"
-        micro(1)
+        ops._WGRAD_SQ = False                             # micro-batch 2: plain accumulate launches (no sum(dW^2) partials)
+        try:
+            micro(1)
+        finally:
+            ops._WGRAD_SQ = True
         assert not layer_units[0].sq_entries, "micro-batch 2 wrote the same ranges without partials: the entries must be gone"
         got = float(strat.sharded._norm)
         direct = sum(float((u.grad32.double() ** 2).sum()) for u in strat.sharded.units if u.trainable) ** 0.5
