@@ -427,7 +427,7 @@ def main():
         torch.cuda.synchronize()
         base = torch.cuda.max_memory_allocated()                 # bytes
         total = torch.cuda.mem_get_info()[1]                     # bytes, this device
-        tok = B_PER_GPU * R_DIFF * 2048
+        tok = B_PER_GPU * ((2048 - 3) + (R_DIFF + 1) * 3 if args.share_prefix else R_DIFF * 2048)   # executed rows per rank
         per_layer = ({1: (6 * 4096 + 3 * 11008) * 2, 3: (6 * 4096 + 2 * 11008) * 2, 2: (8 * 4096 + 4 * 11008) * 2}[args.keep_level]
                      - 4096 * 2) * tok                           # bytes; minus the layer input a checkpointed layer keeps anyway
         keep_layers = max(0, min(32, int((args.mem_frac * total - base) // per_layer)))
