@@ -182,13 +182,17 @@ int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * the R copies differ only in their last rows [t, x, </s>]): one sequence [prefix | R suffix groups of grp_len rows]. Rows >= grp_start
  * belong to group (row - grp_start) / grp_len; a query attends to the prefix and, causally, to its OWN group. The RoPE positions of the
  * suffix rows come from the caller's tables (row s of rope_cos / rope_sin is the table row of position pos(s)). grp_len == 0: plain causal.
- * mla_attn_bwd_g = mla_attn_bwd_t (transposed copies and head_sync optional) with the same grouping. */
+ * grp_starts (int32 [B] on the device, or NULL): a first suffix row per sample for ragged prompts (valid rows of sample b: [0, seqlens[b])).
+ * mla_attn_bwd_g = mla_attn_bwd_t (transposed copies and head_sync optional) with the same grouping; rope_per_sample = 1: the tables are
+ * [B * S, 64], one block of S rows per sample (per-sample positions), instead of one [S, 64] table. */
 int mla_attn_fwd_g(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B, int S, int H,
-                   int head_dim, long long ld_qkv, long long ld_o, float scale, int grp_start, int grp_len, mla_stream_t stream);
+                   int head_dim, long long ld_qkv, long long ld_o, float scale, int grp_start, int grp_len, const int* grp_starts,
+                   mla_stream_t stream);
 int mla_attn_bwd_g(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const int* seqlens,
                    void* dq, void* dk, void* dv, float* delta, int B, int S, int H, int head_dim, long long ld_qkv, long long ld_o,
                    float scale, const float* rope_cos, const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT,
-                   long long ldt, int* head_sync, long long head_sync_ints, int grp_start, int grp_len, mla_stream_t stream);
+                   long long ldt, int* head_sync, long long head_sync_ints, int grp_start, int grp_len, const int* grp_starts,
+                   int rope_per_sample, mla_stream_t stream);
 /* rope_cos / rope_sin ([S, 64] fp32, both or neither): when given, dq and dk are written with the backward of apply_rotary_pos_emb
  * (modeling_llama.py:184-208) already applied -- the same values mla_rope_inplace(backward = 1) would produce on them afterwards.
  * Launch form (mla_attn_bwd and mla_attn_bwd_t; results are bit-identical either way): with head_sync == NULL the dQ kernel and the

@@ -227,7 +227,11 @@ struct AttnArgs {
   int grp_start, grp_len;                              // suffix groups (round 6, shared-prefix sequences; 0 / 0 = plain causal): rows
                                                        // >= grp_start form groups of grp_len rows; a query sees the prefix and, causally,
                                                        // its OWN group only (mla_attn_fwd_g / mla_attn_bwd_g)
+  const int* grp_starts;                               // [B] or null: per-sample first suffix row (ragged prompts) instead of grp_start
+  long long rope_bs;                                   // backward: row stride between the samples' RoPE table blocks (0 = one [S, 64]
+                                                       // table for every sample; S = per-sample positions, tables [B * S, 64])
 };
+__device__ __forceinline__ int grp_start_of(const AttnArgs& p, int b) { return p.grp_starts ? p.grp_starts[b] : p.grp_start; }
 // key (>= grp_start, <= query) belongs to another suffix group than the query
 __device__ __forceinline__ bool other_group(int key, int query, int gs, int gl) {
   return key >= gs && (key - gs) / gl != (query - gs) / gl;
@@ -509,11 +513,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_kernel(Attn
     for (int rb = 0; rb < RB; ++rb)
       if (grow0[rb] < row_lim && kt * 64 <= grow0[rb] + 15) mask |= 1 << rb;
     if (RB == 2) {
-      if (mask == 3) fwd_tile<RB, 3>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
-      else if (mask == 2) fwd_tile<RB, 2>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
-      else if (mask == 1) fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
+      if (mask == 3) fwd_tile<RB, 3>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? grp_start_of(p, b) : 0, GRP ? p.grp_len : 0);
+      else if (mask == 2) fwd_tile<RB, 2>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? grp_start_of(p, b) : 0, GRP ? p.grp_len : 0);
+      else if (mask == 1) fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? grp_start_of(p, b) : 0, GRP ? p.grp_len : 0);
     } else if (mask) {
-      fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? p.grp_start : 0, GRP ? p.grp_len : 0);
+      fwd_tile<RB, 1>(kt_, vt_, qf, ot, m, l, myq, grow0, kt, lane, sc2, GRP ? grp_start_of(p, b) : 0, GRP ? p.grp_len : 0);
     }
   }
   // ---- epilogue: O leaves through LDS (the K / V ring is free now) as whole 256-B rows, 16 B per lane, 4 rows per store
@@ -842,7 +846,7 @@ __device__ __forceinline__ void dq_epilogue(const AttnArgs& p, char* smem, f32x4
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const bool valid = myq[rb] >= 0 && myq[rb] < p.S;
-    if (p.rope_cos) rope_tab_load(rt[rb], p.rope_cos, p.rope_sin, valid ? myq[rb] : 0, g);
+    if (p.rope_cos) rope_tab_load(rt[rb], p.rope_cos + b * p.rope_bs * 64, p.rope_sin + b * p.rope_bs * 64, valid ? myq[rb] : 0, g);
   }
   __syncthreads();
 #pragma unroll
@@ -1167,11 +1171,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs p, char* smem, i
     int lane_t = lane;
     asm volatile("" : "+v"(lane_t));
     if (RB == 2) {
-      if (mask == 3) dq_tile<RB, 3>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
-      else if (mask == 2) dq_tile<RB, 2>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
-      else if (mask == 1) dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
+      if (mask == 3) dq_tile<RB, 3>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, grp_start_of(p, b), p.grp_len);
+      else if (mask == 2) dq_tile<RB, 2>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, grp_start_of(p, b), p.grp_len);
+      else if (mask == 1) dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, grp_start_of(p, b), p.grp_len);
     } else if (mask) {
-      dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, p.grp_start, p.grp_len);
+      dq_tile<RB, 1>(kt_, vt_, qf, dof, dqt, lse2, dlt, myq, grow0, kt, lane_t, sc2, grp_start_of(p, b), p.grp_len);
     }
   }
   BT(0, 3);
@@ -1329,7 +1333,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /
     // instead of 32, and the second half's MFMAs overlap the first half's exp / pack VALU. Bit-identical.
     bf16x8_t ph[2], dsh[2];
     // shared-prefix sequences: this block's keys include suffix rows and so do the queries of this tile -> group mask (block-uniform)
-    const bool grp_tile = p.grp_len > 0 && kb * 64 + 63 >= p.grp_start && qt * 64 + 63 >= p.grp_start;
+    const int gs_b = grp_start_of(p, b);
+    const bool grp_tile = p.grp_len > 0 && kb * 64 + 63 >= gs_b && qt * 64 + 63 >= gs_b;
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {
       f32x4_t s[2], dp[2];
@@ -1354,7 +1359,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /
         for (int r = 0; r < 4; ++r) {
           float sv = s[ff][r];
           if (qt == kb && mykey > qt * 64 + f * 16 + g * 4 + r) sv = -INFINITY;   // only the first query tile touches the diagonal
-          if (grp_tile && other_group(mykey, qt * 64 + f * 16 + g * 4 + r, p.grp_start, p.grp_len)) sv = -INFINITY;
+          if (grp_tile && other_group(mykey, qt * 64 + f * 16 + g * 4 + r, gs_b, p.grp_len)) sv = -INFINITY;
           const float pv = __builtin_amdgcn_exp2f(sv * sc2 - l4[r]);
           pr[ff][r] = pv;
           s[ff][r] = pv * (dp[ff][r] - d4[r]);
@@ -1439,7 +1444,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs p, char* smem /
   // Round 5: the RoPE table row of this lane's key is requested first; dv (which needs no tables) is packed and staged while the
   // loads are in flight, dk follows (the loads used to sit in front of everything with their round trip exposed).
   RopeTab rt;
-  if (p.rope_cos) rope_tab_load(rt, p.rope_cos, p.rope_sin, kvalid ? mykey : 0, g);
+  if (p.rope_cos) rope_tab_load(rt, p.rope_cos + b * p.rope_bs * 64, p.rope_sin + b * p.rope_bs * 64, kvalid ? mykey : 0, g);
 #pragma unroll
   for (int fd = 0; fd < 8; ++fd) {
     wv[fd][0] = kvalid ? pack2bf(dvt[fd][0], dvt[fd][1]) : 0u;
@@ -1591,16 +1596,17 @@ extern "C" int mla_attn_btrace(void* host, int bytes) { return (int)hipMemcpyFro
 #endif
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
-                         int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, int grp_start, int grp_len, hipStream_t stream) {
+                         int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, int grp_start, int grp_len,
+                         const int* grp_starts, hipStream_t stream) {
   MLA_CHECK_ARG(q && k && v && o && lse, "mla_attn_fwd: null pointer");
-  MLA_CHECK_ARG(grp_len >= 0 && (grp_len == 0 || (grp_start >= 0 && grp_start <= S && (S - grp_start) % grp_len == 0)),
-                "mla_attn_fwd_g: suffix groups need 0 <= grp_start <= S and (S - grp_start) %% grp_len == 0 (S %d, start %d, len %d)", S, grp_start, grp_len);
+  MLA_CHECK_ARG(grp_len >= 0 && (grp_len == 0 || grp_starts || (grp_start >= 0 && grp_start <= S)),
+                "mla_attn_fwd_g: suffix groups need 0 <= grp_start <= S (S %d, start %d, len %d)", S, grp_start, grp_len);
   MLA_CHECK_ARG(head_dim == D, "mla_attn_fwd: head_dim must be 128 (got %d)", head_dim);
   MLA_CHECK_ARG(AL16(q) && AL16(k) && AL16(v) && AL16(o), "mla_attn_fwd: 16-B alignment required");
   AttnArgs p{};
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
   p.seqlens = seqlens; p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
-  p.grp_start = grp_len > 0 ? grp_start : 0; p.grp_len = grp_len;
+  p.grp_start = grp_len > 0 ? grp_start : 0; p.grp_len = grp_len; p.grp_starts = grp_len > 0 ? grp_starts : nullptr;
   if (check_common(p, "mla_attn_fwd")) return -1;
   static bool attr = false;
   constexpr int BQ = 16 * FWD_NW * FWD_RB;
@@ -1629,14 +1635,15 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
 }
 extern "C" int mla_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
                             int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, hipStream_t stream) {
-  return attn_fwd_impl(q, k, v, o, lse, seqlens, B, S, H, head_dim, ld_qkv, ld_o, scale, 0, 0, stream);
+  return attn_fwd_impl(q, k, v, o, lse, seqlens, B, S, H, head_dim, ld_qkv, ld_o, scale, 0, 0, nullptr, stream);
 }
 // Shared-prefix sequences (round 6): rows >= grp_start are (S - grp_start) / grp_len suffix groups of grp_len rows; a query attends to
-// the prefix [0, grp_start) and, causally, to its own group only. grp_len == 0: plain causal attention.
+// the prefix [0, grp_start) and, causally, to its own group only. grp_len == 0: plain causal attention. grp_starts (int32 [B], device) or
+// NULL: a first suffix row per sample (ragged prompts: the valid rows of sample b are [0, seqlens[b]), its groups start at grp_starts[b]).
 extern "C" int mla_attn_fwd_g(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B,
                               int S, int H, int head_dim, long long ld_qkv, long long ld_o, float scale, int grp_start, int grp_len,
-                              hipStream_t stream) {
-  return attn_fwd_impl(q, k, v, o, lse, seqlens, B, S, H, head_dim, ld_qkv, ld_o, scale, grp_start, grp_len, stream);
+                              const int* grp_starts, hipStream_t stream) {
+  return attn_fwd_impl(q, k, v, o, lse, seqlens, B, S, H, head_dim, ld_qkv, ld_o, scale, grp_start, grp_len, grp_starts, stream);
 }
 
 // delta: workspace [B,H,S] fp32 (caller-allocated)
@@ -1652,9 +1659,9 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                          int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
                          const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, int* head_sync,
                          long long head_sync_ints, hipStream_t stream, void* ws = nullptr, long long ws_bytes = 0, int grp_start = 0,
-                         int grp_len = 0) {
-  MLA_CHECK_ARG(grp_len >= 0 && (grp_len == 0 || (!ws && grp_start >= 0 && grp_start <= S && (S - grp_start) % grp_len == 0)),
-                "mla_attn_bwd_g: suffix groups need 0 <= grp_start <= S and (S - grp_start) %% grp_len == 0 (S %d, start %d, len %d)", S, grp_start, grp_len);
+                         int grp_len = 0, const int* grp_starts = nullptr, int rope_per_sample = 0) {
+  MLA_CHECK_ARG(grp_len >= 0 && (grp_len == 0 || (!ws && (grp_starts || (grp_start >= 0 && grp_start <= S)))),
+                "mla_attn_bwd_g: suffix groups need 0 <= grp_start <= S (S %d, start %d, len %d)", S, grp_start, grp_len);
   const int nT = (dqT != nullptr) + (dkT != nullptr) + (dvT != nullptr) + (oT != nullptr);
   MLA_CHECK_ARG(nT == 0 || nT == 4, "mla_attn_bwd_t: dqT / dkT / dvT / oT must all be given or all be null");
   MLA_CHECK_ARG(nT == 0 || (S % 4 == 0 && ldt % 4 == 0 && ldt >= (long long)B * S && ((uintptr_t)dqT & 7) == 0 &&
@@ -1672,7 +1679,8 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
   p.B = B; p.S = S; p.H = H; p.ld = ld_qkv; p.ld_o = ld_o; p.scale = scale;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   p.dqT = (bf16_t*)dqT; p.dkT = (bf16_t*)dkT; p.dvT = (bf16_t*)dvT; p.oT = (bf16_t*)oT; p.ldT = ldt;
-  p.grp_start = grp_len > 0 ? grp_start : 0; p.grp_len = grp_len;
+  p.grp_start = grp_len > 0 ? grp_start : 0; p.grp_len = grp_len; p.grp_starts = grp_len > 0 ? grp_starts : nullptr;
+  p.rope_bs = rope_per_sample ? S : 0;
   if (check_common(p, "mla_attn_bwd")) return -1;
   static bool attr = false;
   if (!attr) {
@@ -1775,13 +1783,15 @@ extern "C" int mla_attn_bwd_t(const void* q, const void* k, const void* v, const
 }
 
 // mla_attn_bwd_t for shared-prefix sequences (see mla_attn_fwd_g); dqT / dkT / dvT / oT and head_sync optional as in mla_attn_bwd_t.
+// rope_per_sample: the RoPE tables are [B * S, 64] (row b * S + s = the table row of the position of row s of sample b) instead of [S, 64].
 extern "C" int mla_attn_bwd_g(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                               const int* seqlens, void* dq, void* dk, void* dv, float* delta, int B, int S, int H,
                               int head_dim, long long ld_qkv, long long ld_o, float scale, const float* rope_cos,
                               const float* rope_sin, void* dqT, void* dkT, void* dvT, void* oT, long long ldt, int* head_sync,
-                              long long head_sync_ints, int grp_start, int grp_len, hipStream_t stream) {
+                              long long head_sync_ints, int grp_start, int grp_len, const int* grp_starts, int rope_per_sample,
+                              hipStream_t stream) {
   return attn_bwd_impl(q, k, v, o, dout, lse, seqlens, dq, dk, dv, delta, B, S, H, head_dim, ld_qkv, ld_o, scale, rope_cos, rope_sin,
-                       dqT, dkT, dvT, oT, ldt, head_sync, head_sync_ints, stream, nullptr, 0, grp_start, grp_len);
+                       dqT, dkT, dvT, oT, ldt, head_sync, head_sync_ints, stream, nullptr, 0, grp_start, grp_len, grp_starts, rope_per_sample);
 }
 
 // 5-product backward (experiment build only -- the product library rejects the call): same outputs as

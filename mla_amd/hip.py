@@ -89,10 +89,10 @@ _SIGNATURES = {
                        c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p],
     "mla_attn_bwd_sync_ints": [c_int, c_int],                # returns long long (restype fixed up in lib())
     "mla_attn_fwd_g": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_longlong,
-                       c_longlong, c_float, c_int, c_int, c_void_p],
+                       c_longlong, c_float, c_int, c_int, c_void_p, c_void_p],
     "mla_attn_bwd_g": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                        c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
-                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_void_p],
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_void_p, c_int, c_void_p],
     "mla_attn_bwd_ws_bytes": [c_int, c_int, c_int],          # returns long long (restype fixed up in lib())
     "mla_attn_bwd_ws": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                         c_void_p, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_float, c_void_p, c_void_p,
@@ -545,6 +545,16 @@ def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
 
 
 # --------------------------------------------------------------------------------------------- attention
+def _group_args(groups, B):
+    """groups = (start, len): start an int (every sample) or an int32 device tensor [B] (per sample) -> (scalar start, tensor or None)"""
+    start = groups[0]
+    if torch.is_tensor(start):
+        _req(start, torch.int32, "attention group starts")
+        assert start.numel() == B and start.is_contiguous()
+        return 0, start
+    return int(start), None
+
+
 def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None, groups=None):
     """q/k/v: views into the packed [B*S, 3*H*D] buffer (first element of each slice). rows > B*S: the output gets that many rows,
     the extra ones zero (row padding of the caller, ops.DecoderLayerFn). groups = (start, len): shared-prefix sequences -- rows >= start
@@ -555,7 +565,8 @@ def attn_fwd(q, k, v, B, S, H, D, ld_qkv, seqlens, scale, rows=None, groups=None
         o[B * S:].zero_()
     lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
     if groups is not None:
-        call("mla_attn_fwd_g", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale), int(groups[0]), int(groups[1]))
+        gs, gst = _group_args(groups, B)
+        call("mla_attn_fwd_g", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale), gs, int(groups[1]), _p(gst))
     else:
         call("mla_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, S, H, D, ld_qkv, H * D, float(scale))
     return o, lse
@@ -637,7 +648,8 @@ def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, sca
     if rope_cos is not None:
         _req(rope_cos, torch.float32, "rope cos")
         _req(rope_sin, torch.float32, "rope sin")
-        assert rope_cos.shape == (S, D // 2) and rope_sin.shape == (S, D // 2) and rope_cos.is_contiguous() and rope_sin.is_contiguous()
+        assert rope_cos.shape in ((S, D // 2), (B * S, D // 2)) and rope_sin.shape == rope_cos.shape and rope_cos.is_contiguous() and rope_sin.is_contiguous()
+        assert rope_cos.shape[0] == S or groups is not None, "per-sample RoPE tables [B * S, 64] go with mla_attn_bwd_g (groups=...)"
     if transposed is not None:
         dqkvT, oT = transposed
         _req(dqkvT, torch.bfloat16, "dqkvT")
@@ -664,9 +676,10 @@ def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, sca
         tq = tk = tv = to_ = None
         if transposed is not None:
             tq, tk, tv, to_ = dqkvT[:H * D], dqkvT[H * D:2 * H * D], dqkvT[2 * H * D:], oT
+        gs, gst = _group_args(groups, B)
         call("mla_attn_bwd_g", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,
              H, D, ld_qkv, H * D, float(scale), _p(rope_cos), _p(rope_sin), _p(tq), _p(tk), _p(tv), _p(to_), ldt if transposed is not None else 0,
-             _p(sync), n_sync, int(groups[0]), int(groups[1]))
+             _p(sync), n_sync, gs, int(groups[1]), _p(gst), 1 if (rope_cos is not None and rope_cos.shape[0] == B * S and B > 1) else 0)
         return
     if transposed is not None:
         call("mla_attn_bwd_t", _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(seqlens), _p(dq), _p(dk), _p(dv), _p(delta), B, S,

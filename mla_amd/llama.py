@@ -209,9 +209,11 @@ class LlamaModel(nn.Module):
         all_hidden = () if output_hidden_states else None
         rope_tables = None
         if attn_groups is not None:
-            if position_ids is None or seqlens is not None:
-                raise ValueError("attn_groups needs explicit position_ids [S] and an unpadded batch")
-            rope_tables = self.layers[0].self_attn.rotary_emb.tables_for_positions(position_ids.reshape(-1)[:S])
+            if position_ids is None:
+                raise ValueError("attn_groups needs explicit position_ids ([S], or [B, S] with per-sample group starts)")
+            # position_ids [S]: one table for every sample; [B, S]: per-sample positions (ragged prompts) -> tables [B * S, 64]
+            rope_tables = self.layers[0].self_attn.rotary_emb.tables_for_positions(position_ids.reshape(-1))
+            assert rope_tables[0].shape[0] in (S, B * S)
         with ops.attn_groups(attn_groups):
             for layer in self.layers:
                 if output_hidden_states:

@@ -583,14 +583,17 @@ class DecoderLayerFn(torch.autograd.Function):
         wqkv = cat_view((wq, wk, wv))
         # fused RMSNorm-output x [Wq|Wk|Wv]^T + RoPE: the rotary embedding of q and k happens in the GEMM epilogue (north_star's
         # "fused RoPE + QKV"); shapes outside the fused kernel's contract take the two separate launches
-        if not (wqkv is not None and D == 128 and _ROPE_EPILOGUE and cos.shape[0] == S and
-                hip.gemm_qkv_rope(xn1, wqkv, qkv, cos, sin, S, 2 * H)):
+        # (tables with B * S rows = per-sample positions, shared-prefix sequences of ragged prompts: position = row % (B * S) = the row)
+        Sr = cos.shape[0]
+        assert Sr == S or (Sr == B * S and groups is not None), (Sr, S, B)
+        if not (wqkv is not None and D == 128 and _ROPE_EPILOGUE and
+                hip.gemm_qkv_rope(xn1, wqkv, qkv, cos, sin, Sr, 2 * H)):
             if wqkv is not None:
                 hip.gemm(xn1, wqkv, out=qkv)
             else:
                 for i, wi in enumerate((wq, wk, wv)):
                     hip.gemm(xn1, wi, out=qkv[:, i * H:(i + 1) * H])
-            hip.rope_inplace(qkv, cos, sin, S, nheads, D, 0, H)
+            hip.rope_inplace(qkv, cos, sin, Sr, nheads, D, 0, H)
         o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
                               rows=h2.shape[0], groups=groups)
         h1 = hip.gemm(o, wo, residual=h2)
@@ -734,7 +737,7 @@ class DecoderLayerFn(torch.autograd.Function):
         if T != Tr:
             dqkv[Tr:].zero_()
         # the RoPE backward of dq / dk is applied in the attention-backward epilogues (no separate in-place pass over dqkv)
-        fuse_rope = cos.shape[0] == S and cos.is_contiguous() and sin.is_contiguous() and cos.dtype == torch.float32
+        fuse_rope = cos.shape[0] in (S, B * S) and cos.is_contiguous() and sin.is_contiguous() and cos.dtype == torch.float32
         want_qkv_w = need[1] or need[2] or need[3]
         # dqkv^T and o^T (wgrad operands) leave the attention-backward kernels with the rows: no transpose passes over them
         tr = None
@@ -748,7 +751,7 @@ class DecoderLayerFn(torch.autograd.Function):
                      rope_sin=sin if fuse_rope else None, transposed=tr, groups=ctx.groups)
         del do
         if not fuse_rope:
-            hip.rope_inplace(dqkv, cos, sin, S, nheads, D, 0, H, backward=True)
+            hip.rope_inplace(dqkv, cos, sin, cos.shape[0], nheads, D, 0, H, backward=True)
         if need[4]:
             grads[4] = deliver_wgrad_nt((wo,), hip.transpose(dh1), tr[1] if tr is not None else hip.transpose(o), need[4:5])[0]
         # ---- q | k | v projection

@@ -321,7 +321,7 @@ class PrismaticVLM(nn.Module):
             [BOS | pc 256 (zeros) | img 256 | tac 1 (zero) | text[1:k] | proprio]   +   R x [t_r | x_r (T rows) | text[k:]]
         with the suffix rows of copy r attending to the prefix and (causally) to their own copy only, at the positions they have in the
         reference's layout. x [R * B, T, A], t [R * B] in the reference's tiled order (index r * B + i). Executes P + R s rows per sample
-        instead of R (P + s). Same mathematics (the prefix rows of the R copies are identical by construction); gradients reach the
+        instead of R (P + s). Right-padded prompts of different lengths take `_forward_shared_prefix_ragged` (per-sample prefix lengths). Same mathematics (the prefix rows of the R copies are identical by construction); gradients reach the
         prefix summed over the R copies inside the attention backward instead of through R separate sequences.
         Returns (output, noise_pred [R * B, T, A]) -- output.hidden_states / logits are in the SHARED layout [B, P + R s, .]."""
         assert self.training and self.shared_prefix_ok()
@@ -339,9 +339,10 @@ class PrismaticVLM(nn.Module):
         x_e = self.x_embedder(x.to(bf16))                                        # [R * B, T, H]
         t_e = self.t_embedder(t.to(bf16)).unsqueeze(1)                           # [R * B, 1, H]
         self.vision_tower_2d.assert_masks_ok()
+        if not bool(is_tag.any(dim=1).all()):
+            raise IndexError(f"input_ids row without the splice tag {tag_0} (models/vlm/prismatic.py:983)")
         if not bool(ok):                                                         # (one host sync, like the tag check of forward())
-            raise ValueError("shared-prefix forward needs an unpadded batch with the same splice position in every row "
-                             "(models/vlm/prismatic.py:983); use the tiled forward for ragged batches")
+            return self._forward_shared_prefix_ragged(x_e, t_e, R, proprio_e, text_emb, parts, input_ids, attention_mask, labels, k_all)
         k = int(k_all[0])
         T, H = x_e.shape[1], text_emb.shape[2]
         n_fused = sum(p_.shape[1] for p_ in parts)
@@ -383,6 +384,71 @@ class PrismaticVLM(nn.Module):
         noise_pred = self.final_layer(picked).view(R * B, T, -1)
         output.shared_prefix_layout = dict(prefix_rows=P, suffix_rows=s_len, repeats=R, dummy_groups=n_dummy, executed_rows_per_sample=S,
                                            tiled_rows_per_sample=R * (P + s_len))
+        return output, noise_pred
+
+    def _forward_shared_prefix_ragged(self, x_e, t_e, R, proprio_e, text_emb, parts, input_ids, attention_mask, labels, k_all):
+        """forward_shared_prefix for right-padded prompts of different lengths: sample i has its own splice position k_i, prefix length
+        P_i = k_i + n_fused + 1 and valid rows V_i = P_i + R s (s = 1 + T + 1: t, x rows, </s>); its pad tokens -- which the reference
+        appends behind </s> in every copy (right padding, attention mask 0: flash / varlen semantics give them zero attention output) --
+        are simply not executed. Rows >= V_i of the [B, S] buffer are padding (`seqlens`); the attention kernels get a first suffix row
+        per sample and per-sample RoPE positions. Assembled with one row gather (indices computed on the device, no host loop)."""
+        B, L = input_ids.shape
+        dev = input_ids.device
+        T, H = x_e.shape[1], text_emb.shape[2]
+        n_fused = sum(p_.shape[1] for p_ in parts)
+        valid_len = attention_mask.long().sum(1) if attention_mask is not None else torch.full((B,), L, device=dev)
+        if not bool((valid_len == k_all + 1).all()):
+            raise ValueError("shared-prefix forward: expected the splice tag to be the last valid token of every row (labels keep only the final "
+                             "</s>, vla/datasets/datasets.py:158-164)")
+        s_len = T + 2
+        P_i = (k_all + n_fused + 1).long()                                        # [B]
+        V_i = P_i + R * s_len
+        S = int((int(V_i.max()) + 3) // 4 * 4)
+        j = torch.arange(S, device=dev)[None, :].expand(B, S)
+        Pc, kc = P_i[:, None], k_all.long()[:, None]
+        ib = torch.arange(B, device=dev)[:, None].expand(B, S)
+        # pool rows: [text B*L | fused B*n_fused | proprio B | t R*B | x R*B*T | one zero row]
+        o_txt, o_fus = 0, B * L
+        o_pro = o_fus + B * n_fused
+        o_t = o_pro + B
+        o_x = o_t + R * B
+        o_zero = o_x + R * B * T
+        rel = (j - Pc).clamp(min=0)
+        g, w = rel // s_len, rel % s_len
+        in_suffix = (j >= Pc) & (g < R)
+        idx = torch.full((B, S), o_zero, dtype=torch.long, device=dev)
+        idx = torch.where(j == 0, o_txt + ib * L, idx)
+        idx = torch.where((j >= 1) & (j <= n_fused), o_fus + ib * n_fused + (j - 1), idx)
+        idx = torch.where((j > n_fused) & (j < Pc - 1), o_txt + ib * L + (j - n_fused), idx)
+        idx = torch.where(j == Pc - 1, o_pro + ib, idx)
+        idx = torch.where(in_suffix & (w == 0), o_t + g * B + ib, idx)
+        idx = torch.where(in_suffix & (w >= 1) & (w <= T), o_x + (g * B + ib) * T + (w - 1), idx)
+        idx = torch.where(in_suffix & (w == T + 1), o_txt + ib * L + kc, idx)
+        pool = torch.cat([text_emb.reshape(B * L, H)] + [p_.reshape(-1, H) for p_ in [torch.cat(parts, dim=1)]] +
+                         [proprio_e.reshape(B, H), t_e.reshape(R * B, H), x_e.reshape(R * B * T, H), torch.zeros((1, H), dtype=text_emb.dtype, device=dev)], dim=0)
+        fused_embeddings = ops.gather_rows(pool, idx.reshape(-1)).view(B, S, H)
+        positions = torch.where(j < Pc, j, Pc + w)                                # [B, S]; rows >= V_i are padding (any position)
+        fused_labels = None
+        if labels is not None:
+            lab = torch.full((B, S), -100, dtype=labels.dtype, device=dev)
+            lab = torch.where(j == 0, labels[:, :1].expand(B, S), lab)
+            txt = torch.gather(labels, 1, (j - n_fused).clamp(0, L - 1))
+            lab = torch.where((j > n_fused) & (j < Pc - 1), txt, lab)
+            lab = torch.where(in_suffix & (w == T + 1), torch.gather(labels, 1, kc).expand(B, S), lab)
+            fused_labels = lab
+        mask = j < V_i[:, None]
+        output: CausalLMOutputWithPast = self.llm_backbone(
+            input_ids=None, attention_mask=mask, position_ids=positions, inputs_embeds=fused_embeddings, labels=fused_labels,
+            output_hidden_states=True, return_dict=True, attn_groups=(P_i.to(torch.int32).contiguous(), s_len))
+        last_hidden = output.hidden_states[-1]
+        rr = torch.arange(R, device=dev)[:, None, None]
+        ii = torch.arange(B, device=dev)[None, :, None]
+        jj = torch.arange(T, device=dev)[None, None, :]
+        rows = (ii * S + P_i[None, :, None] + rr * s_len + 1 + jj).reshape(-1)
+        picked = ops.gather_rows(last_hidden.reshape(B * S, H), rows)
+        noise_pred = self.final_layer(picked).view(R * B, T, -1)
+        output.shared_prefix_layout = dict(prefix_rows=[int(v) for v in P_i], suffix_rows=s_len, repeats=R, dummy_groups=0,
+                                           executed_rows_per_sample=S, tiled_rows_per_sample=R * (L + n_fused + 2 + T))
         return output, noise_pred
 
     # ------------------------------------------------------------------------------------------ forward

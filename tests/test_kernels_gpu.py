@@ -323,6 +323,61 @@ def test_attention_suffix_groups_match_masked_reference_and_separate_sequences(d
         assert fro_rel(mine[:, P + r * s:P + (r + 1) * s], d2[r][:, P:]) < 1e-2
 
 
+@pytest.mark.parametrize("starts,s,R", [([61, 58, 64], 3, 4), ([130, 120], 3, 2), ([20, 33, 7, 40], 4, 3)])
+def test_attention_suffix_groups_with_per_sample_starts(dev, starts, s, R):
+    """mla_attn_fwd_g / mla_attn_bwd_g with a first suffix row PER SAMPLE and per-sample RoPE tables (shared-prefix sequences of ragged
+    prompts): sample b has P_b prefix rows, R groups of s rows, then padding up to S (varlen: zero output / zero gradients). Forward and
+    the three gradients (RoPE backward fused, tables [B * S, 64] indexed by sample) against the fp32 reference with each sample's mask."""
+    from mla_amd import hip
+    H, D, B = 2, 128, len(starts)
+    V = [p + R * s for p in starts]
+    S = (max(V) + 3) // 4 * 4
+    g = torch.Generator().manual_seed(sum(starts))
+    qkv = (torch.randn(B * S, 3 * H * D, generator=g) * 0.7).to(BF)
+    do = (torch.randn(B * S, H * D, generator=g) * 0.5).to(BF)
+    idx = torch.arange(S)
+    pos = torch.stack([torch.where(idx < p, idx, p + (idx - p).clamp(min=0) % s) for p in starts])          # [B, S]
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = pos.reshape(-1, 1).float() * inv[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()                                                # [B * S, 64]
+    dq_ = qkv.to(dev)
+    q, k, v = dq_[:, :H * D], dq_[:, H * D:2 * H * D], dq_[:, 2 * H * D:]
+    sl = torch.tensor(V, dtype=torch.int32, device=dev)
+    gst = torch.tensor(starts, dtype=torch.int32, device=dev)
+    o, lse = hip.attn_fwd(q, k, v, B, S, H, D, 3 * H * D, sl, 1 / math.sqrt(D), groups=(gst, s))
+    qf, kf, vf = (qkv[:, i * H * D:(i + 1) * H * D].float().view(B, S, H, D).transpose(1, 2).requires_grad_(True) for i in range(3))
+    allowed = torch.zeros(B, S, S, dtype=torch.bool)
+    for b, p in enumerate(starts):
+        grp = torch.where(idx >= p, (idx - p) // s, torch.full_like(idx, -1))
+        a = (idx[None, :] <= idx[:, None]) & ((idx[None, :] < p) | (grp[None, :] == grp[:, None]))
+        a &= (idx[None, :] < V[b]) & (idx[:, None] < V[b])
+        allowed[b] = a
+    sc = (qf @ kf.transpose(-1, -2)) / math.sqrt(D)
+    pr = torch.softmax(sc.masked_fill(~allowed[:, None], float("-inf")), -1)
+    pr = torch.nan_to_num(pr, nan=0.0)                                          # pad query rows: no keys -> zero output
+    ref = (pr @ vf).transpose(1, 2).reshape(B * S, H * D)
+    assert fro_rel(o, ref) < 5e-3
+    ref.backward(do.float())
+    # q, k as given are POST-RoPE values; the fused RoPE backward rotates dq, dk back: the reference does the same rotation on its gradients
+    def rope_bwd(gr):
+        gr = gr.view(B * S, H, D)
+        a, b_ = gr[..., :64], gr[..., 64:]
+        c, s_ = cos[:, None, :], sin[:, None, :]
+        return torch.cat([a * c + b_ * s_, b_ * c - a * s_], -1).reshape(B * S, H * D)
+    gq, gk, gv = (t.grad.transpose(1, 2).reshape(B * S, H * D) for t in (qf, kf, vf))
+    gq, gk = rope_bwd(gq), rope_bwd(gk)
+    dqkv = torch.full_like(dq_, float("nan"))
+    hip.attn_bwd(q, k, v, o, do.to(dev), lse, sl, dqkv[:, :H * D], dqkv[:, H * D:2 * H * D], dqkv[:, 2 * H * D:], B, S, H, D, 3 * H * D,
+                 1 / math.sqrt(D), rope_cos=cos.to(dev), rope_sin=sin.to(dev), groups=(gst, s))
+    assert torch.isfinite(dqkv.float()).all()
+    e = [fro_rel(dqkv[:, i * H * D:(i + 1) * H * D], gr) for i, gr in enumerate((gq, gk, gv))]
+    print(f"per-sample suffix groups starts={starts} s={s} R={R}: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+    assert max(e) < 1e-2, e
+    for b in range(B):                                                          # rows beyond the sample's valid length: zero output, zero gradients
+        assert float(o[b * S + V[b]:(b + 1) * S].float().abs().max() if V[b] < S else 0.0) == 0.0
+        assert float(dqkv[b * S + V[b]:(b + 1) * S].float().abs().max() if V[b] < S else 0.0) == 0.0
+
+
 @pytest.mark.parametrize("T,S,nh", [(548 * 2, 548, 4), (300, 100, 2), (2048, 2048, 2)])
 def test_qkv_gemm_with_rope_epilogue_is_bit_identical(dev, T, S, nh):
     """mla_gemm_qkv_rope == mla_gemm_bf16 + mla_rope_inplace on the packed q|k|v buffer, bit for bit (ragged tile edges: T % 256 != 0,

@@ -289,6 +289,24 @@ def test_shared_prefix_forward_matches_the_reference_golden_like_the_tiled_forwa
     assert num / den < 2e-2
 
 
+def test_shared_prefix_forward_on_a_ragged_batch_matches_the_reference_golden(dev):
+    """The shared-prefix forward on a right-padded batch of different prompt lengths (per-sample prefix lengths, first suffix rows and
+    RoPE positions; the reference's pad rows behind </s> are not executed) against the golden the reference's TILED forward produced
+    on the same ragged batch (mla_tiny_e2e_pretrain.npz, R = 2): loss and the strict per-tensor gradient yardstick on all 113 parameters."""
+    from parity_util import grad_sample_rows, strict_violations
+    m, ld, gold = run_pretrain_e2e(dev, False, eq=False, share_prefix=True)
+    lay = run_pretrain_e2e.last_output.shared_prefix_layout
+    assert isinstance(lay["prefix_rows"], list) and len(set(lay["prefix_rows"])) > 1, lay       # the ragged path really ran
+    A, C = float(gold["A_total_loss"]), float(gold["C_total_loss"])
+    half_ulp = 2.0 ** (np.floor(np.log2(abs(A))) - 7) / 2
+    assert abs(float(ld["total_loss"]) - A) <= 2 * max(abs(C - A), half_ulp), (float(ld["total_loss"]), A, C)
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(grads) == [str(n) for n in gold["grad_names"]]
+    rows = grad_sample_rows(grads, gold)
+    assert len(rows) == 113 and not strict_violations(rows), strict_violations(rows)
+    print(f"ragged shared prefix: loss {float(ld['total_loss']):.6f} vs A {A:.6f}; median gradient-sample ratio vs mode C {np.median([r['ratio'] for r in rows]):.2f}; layout {lay}")
+
+
 def test_shared_prefix_steps_through_fsdp_match_tiled_steps(dev):
     """The opt-in shared-prefix forward through FSDPStrategy (fp32 main_grad delivery, fused AdamW, clip; token rows padded to 64 inside
     the decoder layers): two optimizer steps from the same weights, noise and timesteps -- losses, the clipping norm and the updated
