@@ -79,24 +79,25 @@ class PrefixCachedEps:
         ~40 % launch + ramp). Under FSDPStrategy the parameters already live like that in the unit's flat buffer (views are used as they
         are); otherwise the engine keeps packed COPIES (9.4 GB at 7B), rebuilt when a parameter's storage or version changes."""
         key = tuple((p.data_ptr(), p._version) for layer in self.model.layers for p in layer._weights())
-        if self._packed is not None and key == self._packed_key:
-            return self._packed
-        packed = []
-        with torch.no_grad(), torch.inference_mode(False):
-            for layer in self.model.layers:
-                ln1, wq, wk, wv, wo, ln2, wg, wu, wd = layer._weights()
-                if ops.cat_view((wq, wk, wv)) is None:
-                    buf = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
-                    H = wq.shape[0]
-                    wq, wk, wv = buf[:H], buf[H:H + wk.shape[0]], buf[H + wk.shape[0]:]
-                if ops.cat_view((wg, wu)) is None:
-                    buf = torch.cat([wg.detach(), wu.detach()], 0)
-                    wg, wu = buf[:wg.shape[0]], buf[wg.shape[0]:]
-                packed.append((ln1, wq, wk, wv, wo, ln2, wg, wu, wd))
-        if self._packed is not None:
-            self.graph = None            # the captured pass holds the old buffers' addresses
-        self._packed, self._packed_key = packed, key
-        return packed
+        shared = self.vlm.__dict__.setdefault("_prefix_packed", {})          # one packed copy per model, shared by its engines
+        if shared.get("key") != key:
+            packed = []
+            with torch.no_grad(), torch.inference_mode(False):
+                for layer in self.model.layers:
+                    ln1, wq, wk, wv, wo, ln2, wg, wu, wd = layer._weights()
+                    if ops.cat_view((wq, wk, wv)) is None:
+                        buf = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+                        H = wq.shape[0]
+                        wq, wk, wv = buf[:H], buf[H:H + wk.shape[0]], buf[H + wk.shape[0]:]
+                    if ops.cat_view((wg, wu)) is None:
+                        buf = torch.cat([wg.detach(), wu.detach()], 0)
+                        wg, wu = buf[:wg.shape[0]], buf[wg.shape[0]:]
+                    packed.append((ln1, wq, wk, wv, wo, ln2, wg, wu, wd))
+            shared["key"], shared["packed"] = key, packed
+        if self._packed is not shared["packed"]:
+            self.graph = None            # a captured pass holds the previous buffers' addresses
+            self._packed, self._packed_key = shared["packed"], key
+        return self._packed
 
     def prefill(self, input_ids, k, images=None, point_cloud=None, camera_name=None, proprio=None, tactile=None, gripper_xyz=None, **unused):
         vlm, bf16, dev = self.vlm, torch.bfloat16, input_ids.device

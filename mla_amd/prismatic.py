@@ -29,6 +29,41 @@ from .vision_tokenizer import MLP_GELU, VisionTokenizer
 IGNORE_INDEX = -100
 
 
+def shared_prefix_plan(k_all: torch.Tensor, B: int, L: int, n_fused: int, T: int, R: int):
+    """Row plan of the shared-prefix layout for prompts of different lengths (PrismaticVLM._forward_shared_prefix_ragged): sample i has
+    the splice position k_i, P_i = k_i + n_fused + 1 prefix rows `[BOS | fused | text[1:k_i] | proprio]` and R suffix groups
+    `[t | x (T rows) | text[k_i] = </s>]` of s = T + 2 rows; S = max_i (P_i + R s) rounded up to a multiple of 4. Returns
+    (idx [B, S] into the row pool [text B*L | fused B*n_fused | proprio B | t R*B | x R*B*T | one zero row] with copy r of sample i at
+    r * B + i, positions [B, S] = the row's position in the reference's tiled sequence, P_i, V_i, S, in_suffix, w). Pure index
+    arithmetic on k_all's device -- no host loop, one host read for S."""
+    dev = k_all.device
+    s_len = T + 2
+    P_i = (k_all + n_fused + 1).long()
+    V_i = P_i + R * s_len
+    S = int((int(V_i.max()) + 3) // 4 * 4)
+    j = torch.arange(S, device=dev)[None, :].expand(B, S)
+    Pc, kc = P_i[:, None], k_all.long()[:, None]
+    ib = torch.arange(B, device=dev)[:, None].expand(B, S)
+    o_txt, o_fus = 0, B * L
+    o_pro = o_fus + B * n_fused
+    o_t = o_pro + B
+    o_x = o_t + R * B
+    o_zero = o_x + R * B * T
+    rel = (j - Pc).clamp(min=0)
+    g, w = rel // s_len, rel % s_len
+    in_suffix = (j >= Pc) & (g < R)
+    idx = torch.full((B, S), o_zero, dtype=torch.long, device=dev)
+    idx = torch.where(j == 0, o_txt + ib * L, idx)
+    idx = torch.where((j >= 1) & (j <= n_fused), o_fus + ib * n_fused + (j - 1), idx)
+    idx = torch.where((j > n_fused) & (j < Pc - 1), o_txt + ib * L + (j - n_fused), idx)
+    idx = torch.where(j == Pc - 1, o_pro + ib, idx)
+    idx = torch.where(in_suffix & (w == 0), o_t + g * B + ib, idx)
+    idx = torch.where(in_suffix & (w >= 1) & (w <= T), o_x + (g * B + ib) * T + (w - 1), idx)
+    idx = torch.where(in_suffix & (w == T + 1), o_txt + ib * L + kc, idx)
+    positions = torch.where(j < Pc, j, Pc + w)            # rows >= V_i are padding (any position)
+    return idx, positions, P_i, V_i, S, in_suffix, w
+
+
 def build_splice_plan(input_ids, attention_mask, labels, n_fused: int, ins: int, tag_0: int = 2):
     """Index arithmetic of the splice loop prismatic.py:981-1038, vectorised (no host sync).
 
@@ -401,33 +436,12 @@ class PrismaticVLM(nn.Module):
             raise ValueError("shared-prefix forward: expected the splice tag to be the last valid token of every row (labels keep only the final "
                              "</s>, vla/datasets/datasets.py:158-164)")
         s_len = T + 2
-        P_i = (k_all + n_fused + 1).long()                                        # [B]
-        V_i = P_i + R * s_len
-        S = int((int(V_i.max()) + 3) // 4 * 4)
+        idx, positions, P_i, V_i, S, in_suffix, w = shared_prefix_plan(k_all, B, L, n_fused, T, R)
         j = torch.arange(S, device=dev)[None, :].expand(B, S)
         Pc, kc = P_i[:, None], k_all.long()[:, None]
-        ib = torch.arange(B, device=dev)[:, None].expand(B, S)
-        # pool rows: [text B*L | fused B*n_fused | proprio B | t R*B | x R*B*T | one zero row]
-        o_txt, o_fus = 0, B * L
-        o_pro = o_fus + B * n_fused
-        o_t = o_pro + B
-        o_x = o_t + R * B
-        o_zero = o_x + R * B * T
-        rel = (j - Pc).clamp(min=0)
-        g, w = rel // s_len, rel % s_len
-        in_suffix = (j >= Pc) & (g < R)
-        idx = torch.full((B, S), o_zero, dtype=torch.long, device=dev)
-        idx = torch.where(j == 0, o_txt + ib * L, idx)
-        idx = torch.where((j >= 1) & (j <= n_fused), o_fus + ib * n_fused + (j - 1), idx)
-        idx = torch.where((j > n_fused) & (j < Pc - 1), o_txt + ib * L + (j - n_fused), idx)
-        idx = torch.where(j == Pc - 1, o_pro + ib, idx)
-        idx = torch.where(in_suffix & (w == 0), o_t + g * B + ib, idx)
-        idx = torch.where(in_suffix & (w >= 1) & (w <= T), o_x + (g * B + ib) * T + (w - 1), idx)
-        idx = torch.where(in_suffix & (w == T + 1), o_txt + ib * L + kc, idx)
         pool = torch.cat([text_emb.reshape(B * L, H)] + [p_.reshape(-1, H) for p_ in [torch.cat(parts, dim=1)]] +
                          [proprio_e.reshape(B, H), t_e.reshape(R * B, H), x_e.reshape(R * B * T, H), torch.zeros((1, H), dtype=text_emb.dtype, device=dev)], dim=0)
         fused_embeddings = ops.gather_rows(pool, idx.reshape(-1)).view(B, S, H)
-        positions = torch.where(j < Pc, j, Pc + w)                                # [B, S]; rows >= V_i are padding (any position)
         fused_labels = None
         if labels is not None:
             lab = torch.full((B, S), -100, dtype=labels.dtype, device=dev)

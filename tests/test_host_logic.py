@@ -501,3 +501,57 @@ def test_collective_knobs_and_buffer_arenas():
     with pytest.raises(AssertionError):
         for _ in range(8):
             ar.take("master", 600)                                          # beyond the planned capacity: loud, never silent overlap
+
+
+def test_shared_prefix_row_plan_matches_a_per_sample_loop():
+    """mla_amd.prismatic.shared_prefix_plan (round 6: the shared-prefix layout for prompts of different lengths) against the layout
+    written out sample by sample: [BOS | fused | text[1:k] | proprio] + R x [t | x (T rows) | text[k]] with copy r of sample i at
+    r * B + i in the t / x pools, zero rows behind the sample's valid rows, positions = the row's position in the reference's TILED
+    sequence (models/vlm/prismatic.py:981-1038 builds that sequence once per copy)."""
+    from mla_amd.prismatic import shared_prefix_plan
+    B, L, n_fused, T, R = 3, 12, 5, 2, 4
+    k_all = torch.tensor([11, 7, 9])
+    idx, pos, P_i, V_i, S, in_suffix, w = shared_prefix_plan(k_all, B, L, n_fused, T, R)
+    s = T + 2
+    assert P_i.tolist() == [k + n_fused + 1 for k in k_all.tolist()] and V_i.tolist() == [p + R * s for p in P_i.tolist()]
+    assert S % 4 == 0 and S >= max(V_i.tolist()) and S - max(V_i.tolist()) < 4
+    o_fus, o_pro = B * L, B * L + B * n_fused
+    o_t = o_pro + B
+    o_x = o_t + R * B
+    o_zero = o_x + R * B * T
+    for i in range(B):
+        k = int(k_all[i])
+        want = [i * L] + [o_fus + i * n_fused + f for f in range(n_fused)] + [i * L + c for c in range(1, k)] + [o_pro + i]
+        wpos = list(range(len(want)))
+        P = len(want)
+        for r in range(R):
+            want += [o_t + r * B + i] + [o_x + (r * B + i) * T + c for c in range(T)] + [i * L + k]
+            wpos += [P + c for c in range(s)]
+        assert idx[i, :len(want)].tolist() == want, i
+        assert pos[i, :len(want)].tolist() == wpos, i
+        assert (idx[i, len(want):] == o_zero).all()
+        assert in_suffix[i].sum() == R * s and not in_suffix[i, :P].any()
+    # equal prompts degenerate to the same prefix length for every sample
+    idx2, pos2, P2, V2, S2, _, _ = shared_prefix_plan(torch.tensor([9, 9]), 2, 10, 5, 1, 4)
+    assert P2.tolist() == [15, 15] and S2 == 28 and pos2[0, 15:27].tolist() == [15, 16, 17] * 4
+
+
+def test_lazy_lm_output_materialises_once_and_adds_the_contrastive_terms_in_order():
+    """mla_amd.modeling_outputs.CausalLMOutputWithPast (round 6): with `lazy_lm` the logits / loss are produced on first access, exactly
+    once, and loss = CE + img_pc + tactile in the reference's order (modeling_llama.py:1272-1303); without it the fields behave like
+    the plain dataclass of the reference (modeling_outputs.py:706-713)."""
+    from mla_amd.modeling_outputs import CausalLMOutputWithPast
+    calls = []
+
+    def lm():
+        calls.append(1)
+        return torch.ones(2, 3), torch.tensor(2.0)
+    out = CausalLMOutputWithPast(img_pc_contrastive_loss=torch.tensor(0.5), tactile_contrastive_loss=torch.tensor(0.25), lazy_lm=lm,
+                                 hidden_states=(torch.zeros(1),))
+    assert out.lm_head_pending and not calls and "<lazy>" in repr(out)
+    assert float(out.loss) == 2.75 and len(calls) == 1 and not out.lm_head_pending
+    assert out.logits.shape == (2, 3) and len(calls) == 1 and out["loss"] is out.loss and out[0] is out.loss
+    plain = CausalLMOutputWithPast(loss=torch.tensor(1.0), logits=None, hidden_states=None)
+    assert float(plain.loss) == 1.0 and plain.logits is None and not plain.lm_head_pending
+    none = CausalLMOutputWithPast(lazy_lm=lambda: (torch.zeros(1), None), img_pc_contrastive_loss=torch.tensor(1.0))
+    assert none.loss is None and none.logits is not None          # no labels -> no CE -> loss stays None (the reference would raise on None + tensor)
