@@ -238,10 +238,14 @@ int mla_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, 
  *   the per-sample cache slots. Replaces the nn.Linear calls of modeling_llama.py:240, 351-353, 390 for the suffix rows.
  *   pre: what is applied to the input rows on their way into LDS -- 0 nothing; 1 LlamaRMSNorm with weight pre_w and eps
  *   (modeling_llama.py:76-90, the arithmetic of mla_rmsnorm_fwd); 2 SwiGLU: x rows are packed gate|up [2 K], the input is
- *   silu(gate) * up (modeling_llama.py:240, the arithmetic of mla_swiglu_fwd). */
+ *   silu(gate) * up (modeling_llama.py:240, the arithmetic of mla_swiglu_fwd).
+ *   rope_cos / rope_sin ([rows_per_batch, 64] fp32, both or neither; no residual then): columns [0, rope_cols) are rotated per head of
+ *   128 in the epilogue (apply_rotary_pos_emb modeling_llama.py:184-208, the arithmetic of mla_rope_inplace on the bf16-rounded
+ *   projection; row m uses table row m % rows_per_batch) -- with pre = 1 this is north_star's "fused RMSNorm + RoPE + QKV" as ONE kernel,
+ *   on the inference path. */
 int mla_gemv_bf16(const void* x, long long ldx, const void* W, long long ldw, void* out, long long ldo, long long out_batch_stride,
                   int rows_per_batch, const void* residual, long long ld_res, int M, int N, int K, int pre, const void* pre_w, float eps,
-                  mla_stream_t stream);
+                  const float* rope_cos, const float* rope_sin, int rope_cols, mla_stream_t stream);
 /* mla_attn_decode: R <= 8 new query rows per (sample, head) -- rows [S_kv - R, S_kv) of the packed q|k|v cache (row stride ld, sample stride
  *   batch_stride, q / k / v = the three slices' first elements) -- against keys / values [0, S_kv - R + r] (causal, scale applied to the
  *   scores, fp32 softmax, P rounded to bf16 before P V like the flash kernel). o: [B * R, H * 128] bf16. head_dim 128.

@@ -45,7 +45,8 @@ template <int M, int PRE>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, long long ldx, const bf16_t* __restrict__ W, long long ldw,
                                                    bf16_t* __restrict__ out, long long ldo, long long out_bs, int rpb,
                                                    const bf16_t* __restrict__ res, long long ld_res, int N, int K,
-                                                   const bf16_t* __restrict__ pre_w, float eps) {
+                                                   const bf16_t* __restrict__ pre_w, float eps, const float* __restrict__ rope_cos,
+                                                   const float* __restrict__ rope_sin, int rope_cols) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int kc = K >> 3;
   u32x4_t* xs = (u32x4_t*)smem;                       // [M][K / 8] chunks of 8 bf16
@@ -112,12 +113,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
     __syncthreads();
   }
   for (int set = blockIdx.x * 4 + wave; set < sets; set += gridDim.x * 4) {
-    const int n0 = set * GEMV_ROWS;
+    // rows of this wave: a consecutive pair -- or, in the rotary columns [0, rope_cols) of a fused q|k|v projection, channel d of a head
+    // and its rotation partner d + 64 (apply_rotary_pos_emb, modeling_llama.py:184-208), so that the epilogue can rotate them
+    const bool rot = rope_cos != nullptr && set * GEMV_ROWS < rope_cols;
+    const int n0 = rot ? (set >> 6) * 128 + (set & 63) : set * GEMV_ROWS;
+    const int nstep = rot ? 64 : 1;
     float acc[GEMV_ROWS][M];
     const bf16_t* wr[GEMV_ROWS];
 #pragma unroll
     for (int r = 0; r < GEMV_ROWS; ++r) {
-      wr[r] = W + (long long)(n0 + r < N ? n0 + r : N - 1) * ldw;
+      wr[r] = W + (long long)(n0 + r * nstep < N ? n0 + r * nstep : N - 1) * ldw;
 #pragma unroll
       for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
     }
@@ -154,14 +159,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
       for (int m = 0; m < M; ++m) acc[r][m] = wave_sum(acc[r][m]);
     if (lane < GEMV_ROWS * M) {
       const int r = lane / M, m = lane - r * M;
-      if (n0 + r < N) {
-        float v = 0.f;
+      if (n0 + r * nstep < N) {
+        float v = 0.f, partner = 0.f;
 #pragma unroll
         for (int rr = 0; rr < GEMV_ROWS; ++rr)
 #pragma unroll
-          for (int mm = 0; mm < M; ++mm) v = (rr == r && mm == m) ? acc[rr][mm] : v;
-        if (res) v += bf2f(res[(long long)m * ld_res + n0 + r]);
-        out[(long long)(m / rpb) * out_bs + (long long)(m % rpb) * ldo + n0 + r] = f2bf(v);
+          for (int mm = 0; mm < M; ++mm) {
+            v = (rr == r && mm == m) ? acc[rr][mm] : v;
+            partner = (rr != r && mm == m) ? acc[rr][mm] : partner;
+          }
+        if (res) v += bf2f(res[(long long)m * ld_res + n0 + r * nstep]);
+        if (rot) {
+          // the arithmetic of rope_kernel (elementwise.hip) on the bf16-rounded projection: a' = a cos - b sin, b' = b cos + a sin
+          const int d = n0 & 63, pos = m % rpb;                    // table row = the row's index inside its sample's block of new rows
+          const float c = rope_cos[pos * 64 + d], sn = rope_sin[pos * 64 + d];
+          const float me = bf2f(f2bf(v)), other = bf2f(f2bf(partner));
+          v = r == 0 ? fmaf(me, c, -(other * sn)) : fmaf(me, c, other * sn);
+        }
+        out[(long long)(m / rpb) * out_bs + (long long)(m % rpb) * ldo + n0 + r * nstep] = f2bf(v);
       }
     }
   }
@@ -308,8 +323,10 @@ __global__ __launch_bounds__(64 * DEC_NW) void attn_decode_kernel(const bf16_t* 
 
 extern "C" int mla_gemv_bf16(const void* x, long long ldx, const void* W, long long ldw, void* out, long long ldo, long long out_batch_stride,
                              int rows_per_batch, const void* residual, long long ld_res, int M, int N, int K, int pre, const void* pre_w, float eps,
-                             hipStream_t stream) {
+                             const float* rope_cos, const float* rope_sin, int rope_cols, hipStream_t stream) {
   MLA_CHECK_ARG(x && W && out, "mla_gemv_bf16: null pointer");
+  MLA_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr) && (!rope_cos || (rope_cols > 0 && rope_cols % 128 == 0 && rope_cols <= N && !residual)),
+                "mla_gemv_bf16: the RoPE epilogue needs both tables, rope_cols a multiple of 128 and <= N, and no residual");
   MLA_CHECK_ARG(pre >= 0 && pre <= 2 && (pre != 1 || (pre_w && AL16(pre_w))), "mla_gemv_bf16: pre must be 0, 1 (RMSNorm: 16-B aligned weight needed) or 2 (SwiGLU)");
   MLA_CHECK_ARG(M >= 1 && M <= GEMV_MMAX && N >= 1 && K >= 8 && K % 8 == 0 && rows_per_batch >= 1, "mla_gemv_bf16: 1 <= M <= 8, K %% 8 == 0 required (M %d, N %d, K %d)", M, N, K);
   MLA_CHECK_ARG(AL16(x) && AL16(W) && ldx % 8 == 0 && ldw % 8 == 0, "mla_gemv_bf16: x / W rows must be 16-B aligned");
@@ -328,7 +345,8 @@ extern "C" int mla_gemv_bf16(const void* x, long long ldx, const void* W, long l
     static bool attr = false;                                                                                                          \
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemv_kernel<MM, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
     hipLaunchKernelGGL((gemv_kernel<MM, PP>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)x, ldx, (const bf16_t*)W, ldw, (bf16_t*)out, ldo, \
-                       out_batch_stride, rows_per_batch, (const bf16_t*)residual, ld_res, N, K, (const bf16_t*)pre_w, eps);            \
+                       out_batch_stride, rows_per_batch, (const bf16_t*)residual, ld_res, N, K, (const bf16_t*)pre_w, eps, rope_cos, rope_sin, \
+                       rope_cos ? rope_cols : 0);                                                                                      \
   }
 #define MLA_GEMV_CASE(MM)                                                                                                              \
   case MM:                                                                                                                             \

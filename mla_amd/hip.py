@@ -32,7 +32,7 @@ _SIGNATURES = {
     "mla_dispatch_probe": [c_void_p, c_int, c_int, c_void_p],
     "mla_calib_mfma": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mla_gemv_bf16": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_longlong, c_int, c_int,
-                      c_int, c_int, c_void_p, c_float, c_void_p],
+                      c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p],
     "mla_attn_decode": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float,
                         c_void_p],
     "mla_gemm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -691,10 +691,11 @@ def attn_bwd(q, k, v, o, dout, lse, seqlens, dq, dk, dv, B, S, H, D, ld_qkv, sca
 
 
 # --------------------------------------------------------------------------------------------- inference (mla_amd/infer.py)
-def gemv(x, W, out, ldo, out_batch_stride, rows_per_batch, residual=None, out_col=0, norm_weight=None, eps=0.0, swiglu=False):
+def gemv(x, W, out, ldo, out_batch_stride, rows_per_batch, residual=None, out_col=0, norm_weight=None, eps=0.0, swiglu=False, rope=None):
     """out row m (at out + (m // rows_per_batch) * out_batch_stride + (m % rows_per_batch) * ldo + out_col) = f(x[m]) @ W^T (+ residual[m]);
     M <= 8 rows, every weight row read once (mla_gemv_bf16). `out` is a base tensor: only its data pointer is used.
-    f = identity; or LlamaRMSNorm(x; norm_weight, eps); or (swiglu=True, x = packed gate|up rows [M, 2 K]) silu(gate) * up."""
+    f = identity; or LlamaRMSNorm(x; norm_weight, eps); or (swiglu=True, x = packed gate|up rows [M, 2 K]) silu(gate) * up.
+    rope = (cos [rows_per_batch, 64], sin, rope_cols): output columns [0, rope_cols) are rotated per head of 128 in the epilogue."""
     _req(x, torch.bfloat16, "gemv x")
     _req(W, torch.bfloat16, "gemv W")
     _req(out, torch.bfloat16, "gemv out")
@@ -706,11 +707,17 @@ def gemv(x, W, out, ldo, out_batch_stride, rows_per_batch, residual=None, out_co
     if norm_weight is not None:
         _req(norm_weight, torch.bfloat16, "gemv norm weight")
         assert norm_weight.numel() == K and norm_weight.is_contiguous()
+    if rope is not None:
+        _req(rope[0], torch.float32, "gemv rope cos")
+        _req(rope[1], torch.float32, "gemv rope sin")
+        assert rope[0].shape == (rows_per_batch, 64) and rope[1].shape == rope[0].shape and rope[0].is_contiguous() and rope[1].is_contiguous()
+        assert out_col == 0 and residual is None
     if residual is not None:
         _req(residual, torch.bfloat16, "gemv residual")
         assert residual.shape[0] == M and residual.stride(1) == 1
     call("mla_gemv_bf16", _p(x), x.stride(0), _p(W), W.stride(0), c_void_p(out.data_ptr() + 2 * out_col), ldo, out_batch_stride, rows_per_batch,
-         _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, pre, _p(norm_weight), float(eps))
+         _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, pre, _p(norm_weight), float(eps),
+         _p(rope[0]) if rope is not None else None, _p(rope[1]) if rope is not None else None, int(rope[2]) if rope is not None else 0)
 
 
 def attn_decode(cache, B, nheads, D, S_kv, R, scale):

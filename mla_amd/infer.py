@@ -11,7 +11,7 @@ them (`text[k:]`) cannot influence the rows that are read out (`noise_pred = fin
 q|k|v rows, and then serves each `model(x, t)` call with a pass over the `1 + T` suffix rows per sample: skinny weight-streaming GEMMs
 (`mla_gemv_bf16`, every weight read once per pass), `mla_attn_decode` against the cached keys / values, the same RMSNorm / RoPE / SwiGLU
 kernels' arithmetic as training (RMSNorm and SwiGLU are applied inside the projections' input staging). The 6 x 32 launches of a pass
-are captured once into a HIP graph and replayed per DDIM step.
+(5 with the rotary embedding in the QKV kernel's epilogue) are captured once into a HIP graph and replayed per DDIM step.
 
 Semantics vs the reference: identical arithmetic up to summation order (fp32 accumulation everywhere), with ONE stated difference -- the
 reference's point tokenizer draws fresh random FPS start indices inside every one of the 8 forwards (Point_PN.py:10); here they are
@@ -153,10 +153,14 @@ class PrefixCachedEps:
         h = self.h_in
         scale = 1.0 / math.sqrt(self.D)
         for (ln1, wq, wk, wv, wo, ln2, wg, wu, wd), c in zip(self._packed, self.cache):
-            # RMSNorm inside the projection's input staging; q|k|v of the suffix rows go straight into the cache slots [S_p, S_p + R)
-            self._gemv(h, (wq, wk, wv), out=c[:, S_p:], rpb=R, out_bs=c.stride(0), norm_weight=ln1, eps=self.eps)
-            for b in range(B):
-                hip.rope_inplace(c[b, S_p:], self.cos_s, self.sin_s, R, self.nheads, self.D, 0, H)
+            # north_star's "fused RMSNorm + RoPE + QKV" as ONE kernel: RMSNorm inside the projection's input staging, the rotary embedding of
+            # the q and k columns in its epilogue; the rows go straight into the cache slots [S_p, S_p + R) of every sample
+            fused = ops.cat_view((wq, wk, wv)) is not None and self.D == 128
+            self._gemv(h, (wq, wk, wv), out=c[:, S_p:], rpb=R, out_bs=c.stride(0), norm_weight=ln1, eps=self.eps,
+                       **({"rope": (self.cos_s, self.sin_s, 2 * H)} if fused else {}))
+            if not fused:
+                for b in range(B):
+                    hip.rope_inplace(c[b, S_p:], self.cos_s, self.sin_s, R, self.nheads, self.D, 0, H)
             o = hip.attn_decode(c, B, self.nheads, self.D, S_cap, R, scale)
             h1 = self._gemv(o, (wo,), residual=h)
             gu = self._gemv(h1, (wg, wu), norm_weight=ln2, eps=self.eps)

@@ -39,6 +39,9 @@ class MLA(nn.Module):
         self.last_diff_mse = None
         if self.use_diff:
             self.ddim_diffusion = None
+            # round 6, opt-in: run the R diffusion copies of a sample as ONE [prefix | R suffix groups] sequence where the prefix does not depend
+            # on the copy (PrismaticVLM.shared_prefix_ok(): the scripts/pretrain.sh configuration); see _forward_shared_prefix
+            self.share_prefix = False
             self.diffusion_steps = 100
             self.diffusion = create_diffusion(timestep_respacing="", noise_schedule="squaredcos_cap_v2", diffusion_steps=100,
                                               sigma_small=True, learn_sigma=False)

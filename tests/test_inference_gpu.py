@@ -188,6 +188,41 @@ def test_gemv_fused_rmsnorm_and_swiglu_inputs_match_the_separate_kernels(dev, M,
     assert torch.isfinite(a.float()).all() and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,R,nh", [(1, 2, 32), (2, 4, 2), (1, 8, 3)])
+def test_gemv_fused_rmsnorm_rope_qkv_is_the_three_kernels(dev, B, R, nh):
+    """north_star's "fused RMSNorm + RoPE + QKV" as ONE kernel on the inference path: mla_gemv_bf16 with the RMSNorm in its input
+    staging and the rotary embedding of the q | k columns in its epilogue, writing into per-sample cache slots -- bit-identical to
+    rmsnorm_fwd + plain GEMV + rope_inplace on the same rows (positions S_p .. S_p + R - 1)."""
+    from mla_amd import hip
+    D, K = 128, 512
+    H = nh * D
+    M, S_p, S_cap = B * R, 11, 11 + R
+    g = torch.Generator().manual_seed(nh * 10 + R)
+    x = (torch.randn(M, K, generator=g) * 1.1).to(BF).to(dev)
+    w = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(dev)
+    W = (torch.randn(3 * H, K, generator=g) * 0.06).to(BF).to(dev)
+    pos = torch.arange(S_p, S_cap).float()
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.outer(pos, inv)
+    cos, sin = fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev)
+    ref = torch.zeros((B, S_cap, 3 * H), dtype=BF, device=dev)
+    hip.gemv(hip.rmsnorm_fwd(x, w, 1e-5)[0], W, ref[:, S_p:], 3 * H, ref.stride(0), R)
+    for b in range(B):
+        hip.rope_inplace(ref[b, S_p:], cos, sin, R, nh, D, 0, H)
+    got = torch.zeros_like(ref)
+    hip.gemv(x, W, got[:, S_p:], 3 * H, got.stride(0), R, norm_weight=w, eps=1e-5, rope=(cos, sin, 2 * H))
+    assert torch.isfinite(got.float()).all() and float(got[:, :S_p].float().abs().max()) == 0
+    assert torch.equal(got, ref)
+    assert not torch.equal(got[:, S_p:, :2 * H], hip_plain(x, w, W, B, R, S_p, S_cap, H, dev)[:, S_p:, :2 * H])    # the rotation really happened
+
+
+def hip_plain(x, w, W, B, R, S_p, S_cap, H, dev):
+    from mla_amd import hip
+    out = torch.zeros((B, S_cap, 3 * H), dtype=BF, device=dev)
+    hip.gemv(x, W, out[:, S_p:], 3 * H, out.stride(0), R, norm_weight=w, eps=1e-5)
+    return out
+
+
 @pytest.mark.parametrize("B,H,S_kv,R", [(1, 32, 550, 2), (2, 4, 77, 5), (1, 2, 8, 8), (3, 3, 1030, 1)])
 def test_attn_decode_matches_fp32_reference(dev, B, H, S_kv, R):
     """mla_attn_decode: the last R rows of the packed q|k|v cache are the queries; query r attends to keys [0, S_kv - R + r]."""
