@@ -94,6 +94,25 @@ int mla_gemm_gateup_swiglu(const void* x, const void* wgu, void* gu, void* act, 
 int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const void* gu, void* dgu, void* dguT, int M, int I, int K, int lda,
                              int ldb, long long ldt, mla_stream_t stream);
 
+/* ---- RMSNorm folded into the projections (round 6): fused RMSNorm + QKV + RoPE and fused RMSNorm + gate|up + SwiGLU, one launch each.
+ * LlamaRMSNorm (modeling_llama.py:76-90) feeds only projections (:351-353 q/k/v, :240 gate/up), and y W^T with y = g * (x * rstd)
+ * equals rstd (.) ((x * g) W^T): the row scale commutes with the product. The GEMM that PRODUCES the residual-stream rows x
+ * (LlamaDecoderLayer :744 / :750: o_proj / down_proj + residual) leaves, besides C = x, xg = bf16(x * g) with g = the NEXT norm's weight
+ * and ss [M, N / 256] = one fp32 partial of sum(x^2) per row and 256-column tile (mla_gemm_res_norm; N % 256 == 0; deterministic; split-K
+ * tail through `workspace` like mla_gemm_bf16_ws). The projection that CONSUMES them (the _rs forms; A = xg) multiplies its fp32
+ * accumulator rows by rstd[m] = 1 / sqrt(sum_j ss[m, j] / K + eps) before the single rounding to bf16 the fused RoPE / SwiGLU epilogues
+ * start from, and stores rstd [M] for the backward; with ss == NULL it reads rstd [M] instead. mla_rmsnorm_prep makes xg and rstd for rows
+ * that do not come out of a GEMM (first layer, recomputation). The stand-alone norm pass disappears from the forward; the backward is
+ * unchanged (it needs x and rstd only). Rounding points: x * g is rounded once where the reference rounds x * rstd and then g * that. */
+int mla_gemm_res_norm(const void* A, const void* B, void* C, const void* R, const void* g, void* xg, float* ss, int M, int N, int K,
+                      int lda, int ldb, int ldc, int ldr, float* workspace, size_t workspace_bytes, mla_stream_t stream);
+int mla_gemm_qkv_rope_rs(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, const float* rope_cos,
+                         const float* rope_sin, int S, int rope_cols, const float* ss, int parts, float eps, float* rstd,
+                         mla_stream_t stream);
+int mla_gemm_gateup_swiglu_rs(const void* x, const void* wgu, void* gu, void* act, void* actT, int M, int I, int K, int lda, int ldb,
+                              long long ldt, const float* ss, int parts, float eps, float* rstd, mla_stream_t stream);
+int mla_rmsnorm_prep(const void* x, const void* w, void* xg, float* rstd, int rows, int H, float eps, mla_stream_t stream);
+
 /* ---- RMSNorm: LlamaRMSNorm.forward modeling_llama.py:76-90; timm RmsNorm in FinalLayer (models/diffusion/models.py:177) */
 int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int H, float eps, mla_stream_t stream);
 int mla_rmsnorm_bwd_blocks(int rows);

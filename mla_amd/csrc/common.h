@@ -37,6 +37,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum over the 32 lanes of this lane's half of the wave (lanes 0..31 / 32..63), fixed butterfly order
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -48,6 +48,33 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   }
 }
 
+// The two halves of a FOLDED RMSNorm (gemm_args.h nrm_* / rs_*, gemm256.hip mla_gemm_res_norm) for rows that do not come out of a GEMM
+// epilogue (the first decoder layer's input; recomputation of a checkpointed layer): xg = bf16(x * w) -- the column scale, which does not
+// commute with the projection -- and rstd per row, which the projection applies to its fp32 accumulator rows. One 256-thread block per row.
+__global__ __launch_bounds__(256) void rmsnorm_prep_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ xg, float* __restrict__ rstd_out, int rows, int H,
+                                                           float eps) {
+  __shared__ float scratch[16];
+  const int row = blockIdx.x;
+  const int nchunk = H >> 3;
+  const bf16_t* xr = x + (size_t)row * H;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NORM_MAXC; ++c) {
+    const int ch = threadIdx.x + c * 256;
+    if (ch < nchunk) {
+      float xv[8], wv[8], o[8];
+      unpack8(*(const u32x4_t*)(xr + ch * 8), xv);
+      unpack8(*(const u32x4_t*)(w + ch * 8), wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ss += xv[j] * xv[j]; o[j] = xv[j] * wv[j]; }
+      *(u32x4_t*)(xg + (size_t)row * H + ch * 8) = pack8(o);
+    }
+  }
+  ss = block_sum(ss, scratch);
+  if (threadIdx.x == 0 && rstd_out) rstd_out[row] = 1.0f / sqrtf(ss / (float)H + eps);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // timm==0.9.10 RmsNorm, the norm_final of the diffusion FinalLayer (models/diffusion/models.py:18,177; pin pyproject.toml:44).
 // timm tag v0.9.10, timm/layers/norm.py::RmsNorm.forward -> timm/layers/fast_norm.py::fast_rms_norm -> (no apex) rms_norm:
@@ -837,6 +864,16 @@ extern "C" int mla_rmsnorm_fwd(const void* x, const void* w, void* y, float* rst
   MLA_CHECK_ARG(AL16(x) && AL16(w) && AL16(y), "mla_rmsnorm_fwd: pointers must be 16-B aligned");
   hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y,
                      rstd, rows, H, eps);
+  MLA_LAUNCH_CHECK();
+}
+
+// xg = bf16(x * w) and (optional) rstd [rows] of LlamaRMSNorm: the two halves of a folded RMSNorm (see rmsnorm_prep_kernel)
+extern "C" int mla_rmsnorm_prep(const void* x, const void* w, void* xg, float* rstd, int rows, int H, float eps, hipStream_t stream) {
+  MLA_CHECK_ARG(x && w && xg, "mla_rmsnorm_prep: null pointer");
+  MLA_CHECK_ARG(rows > 0 && H > 0 && H % 8 == 0 && H <= 8192, "mla_rmsnorm_prep: need H%%8==0, H<=8192 (H=%d)", H);
+  MLA_CHECK_ARG(AL16(x) && AL16(w) && AL16(xg), "mla_rmsnorm_prep: pointers must be 16-B aligned");
+  hipLaunchKernelGGL(rmsnorm_prep_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)xg, rstd, rows,
+                     H, eps);
   MLA_LAUNCH_CHECK();
 }
 

@@ -171,7 +171,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const bf16_t* pA = p.A + (size_t)m0 * p.lda + (size_t)kt0 * 64;
     const int kmax = nt * 128 - 128, nit = nt >> 1, ldsw = wave * 4096;   // kmax, nit: VGPR operands (selects of uniform values)
     const bool img_bf16 = !part && !p.out_fp32 && p.R == nullptr && p.bias == nullptr;     // uniform; mirrors the epilogue's choice below
-    const int emode = img_bf16 ? 0 : 1;       // (a VGPR operand: hipcc hands a select of uniform values to an "s" constraint in a VGPR)
+    // RMSNorm folded into this projection (gemm_args.h rs_*): rstd of the tile's 256 rows goes to the 1 KiB behind the operand ring
+    // (the loop does not touch it; the tail starts with a barrier) and the tail multiplies accumulator rows by it: emode 2
+    const bool rowscale = img_bf16 && p.rs_rstd != nullptr;
+    if (rowscale && tid < 256) {
+      const int mr = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+      float r;
+      if (p.rs_ss) {
+        const float* sp = p.rs_ss + (size_t)mr * p.rs_parts;
+        float t = 0.f;
+        for (int j = 0; j < p.rs_parts; ++j) t += sp[j];
+        r = 1.0f / sqrtf(t / (float)p.K + p.rs_eps);            // same form as rmsnorm_fwd_kernel (elementwise.hip)
+        if (pid_n == 0 && m0 + tid < p.M) p.rs_rstd[mr] = r;
+      } else {
+        r = p.rs_rstd[mr];
+      }
+      *(float*)(smem + 2 * BUF + tid * 4) = r;
+    }
+    const int emode = img_bf16 ? (rowscale ? 2 : 0) : 1;       // (a VGPR operand: hipcc hands a select of uniform values to an "s" constraint in a VGPR)
     const float alpha = part ? 1.f : p.alpha;
     const unsigned vImg = img_bf16 ? (unsigned)((wr * 64 + li) * 512) + ((((unsigned)(wc * 4 + (lg >> 1))) ^ (unsigned)li) << 4) + (unsigned)(lg & 1) * 8u
                                    : (unsigned)((wr * 64 + li) * 1024) + ((((unsigned)(wc * 8 + lg)) ^ (unsigned)li) << 4);
@@ -414,15 +431,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     __syncthreads();     // every wave is done with the operand image (and has drained its own LDS-DMA loads above)
     if (!p.out_fp32 && p.R == nullptr && p.bias == nullptr) {
       if constexpr (!ASM) {     // (the assembly loop's tail has written this image already)
+      if (p.rs_rstd) {          // RMSNorm folded into this projection: rstd of the tile's rows, staged behind the ring (see the assembly path)
+        if (tid < 256) {
+          const int mr = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+          float r;
+          if (p.rs_ss) {
+            const float* sp = p.rs_ss + (size_t)mr * p.rs_parts;
+            float t = 0.f;
+            for (int j = 0; j < p.rs_parts; ++j) t += sp[j];
+            r = 1.0f / sqrtf(t / (float)p.K + p.rs_eps);
+            if (pid_n == 0 && m0 + tid < p.M) p.rs_rstd[mr] = r;
+          } else {
+            r = p.rs_rstd[mr];
+          }
+          *(float*)(smem + 2 * BUF + tid * 4) = r;
+        }
+        __syncthreads();
+      }
 #pragma unroll
       for (int ri = 0; ri < 8; ++ri) {
         const int ml = (ri >> 2) * 128 + wr * 64 + (ri & 3) * 16 + li;
+        const float rsc = p.rs_rstd ? *(const float*)(smem + 2 * BUF + ml * 4) : p.alpha;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
           const int nl = (ci >> 1) * 128 + wc * 32 + (ci & 1) * 16 + lg * 4;
           u32x2_t o;
-          o[0] = pack2bf(acc[ri][ci][0] * p.alpha, acc[ri][ci][1] * p.alpha);
-          o[1] = pack2bf(acc[ri][ci][2] * p.alpha, acc[ri][ci][3] * p.alpha);
+          o[0] = pack2bf(acc[ri][ci][0] * rsc, acc[ri][ci][1] * rsc);
+          o[1] = pack2bf(acc[ri][ci][2] * rsc, acc[ri][ci][3] * rsc);
           *(u32x2_t*)(smem + ml * 512 + ((((nl >> 3) ^ (ml & 31))) << 4) + ((nl >> 2) & 1) * 8) = o;
         }
       }
@@ -719,6 +754,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) bv[j] = 0.f;
           if (p.bias) unpack8(*(const u32x4_t*)(p.bias + n), bv);
+          float ngv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ngv[j] = 0.f;
+          if (p.nrm_xg) unpack8(*(const u32x4_t*)(p.nrm_g + n), ngv);
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
             const int row = wave * 16 + it * 2 + (lane >> 5);
@@ -733,7 +772,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += rv[j];
               }
-              MLA_ST16((bf16_t*)p.C + (size_t)m * p.ldc + n, pack8(v));
+              const u32x4_t hq = pack8(v);
+              MLA_ST16((bf16_t*)p.C + (size_t)m * p.ldc + n, hq);
+              if (p.nrm_xg) {      // uniform: the NEXT RMSNorm's column scale and sum of squares leave with the rows (gemm_args.h nrm_*)
+                float hv[8], xg[8];
+                unpack8(hq, hv);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { q += hv[j] * hv[j]; xg[j] = hv[j] * ngv[j]; }
+                MLA_ST16(p.nrm_xg + (size_t)m * p.ldc + n, pack8(xg));
+                q = half_wave_sum(q);            // the 32 lanes of this row (N % 256 == 0: all of them are inside the matrix)
+                if (ch == 0) p.nrm_ss[(size_t)m * num_n + pid_n] = q;
+              }
             }
           }
         }
@@ -1152,6 +1202,16 @@ __global__ __launch_bounds__(256) void gemm256_fixup_kernel(GemmArgs p) {
       o[0] = pack2bf(v[0], v[1]);
       o[1] = pack2bf(v[2], v[3]);
       *(u32x2_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+      if (p.nrm_xg) {      // uniform (N % 256 == 0: a wave = the 256 columns of one row of the tile); same outputs as the main kernel's epilogue
+        const u32x2_t gg = *(const u32x2_t*)(p.nrm_g + n);
+        const float h0 = bflo(o[0]), h1 = bfhi(o[0]), h2 = bflo(o[1]), h3 = bfhi(o[1]);
+        u32x2_t x;
+        x[0] = pack2bf(h0 * bflo(gg[0]), h1 * bfhi(gg[0]));
+        x[1] = pack2bf(h2 * bflo(gg[1]), h3 * bfhi(gg[1]));
+        *(u32x2_t*)(p.nrm_xg + (size_t)m * p.ldc + n) = x;
+        const float q = wave_sum((h0 * h0 + h1 * h1) + (h2 * h2 + h3 * h3));
+        if ((threadIdx.x & 63) == 0) p.nrm_ss[(size_t)m * num_n + pid_n] = q;
+      }
     }
   } else {
     for (int r = 0; r < 4 && n + r < p.N; ++r) {
@@ -1241,7 +1301,7 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
   } else {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+    hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 1024);
     attr_set = true;
   }
   const int num_m = (p.M + 255) / 256, num_n = (p.N + 255) / 256;
@@ -1251,14 +1311,14 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
   if (kloop_mode() && (p.K % 128) == 0 && fast && persistent_grid <= 0) {
     if (p.sk_split > 1) {
       const int tail = num_m * num_n - p.sk_full;
-      launch_asm<0>(p, dim3(p.sk_full + tail * p.sk_split), 2 * BUF, stream);
+      launch_asm<0>(p, dim3(p.sk_full + tail * p.sk_split), 2 * BUF + 1024, stream);
       hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
     } else if (p.sw_gu) {
       launch_asm<2>(p, dim3(num_m * num_n), 2 * BUF + 32768, stream);
     } else if (p.sf_I) {
-      launch_asm<1>(p, dim3(num_m * num_n), 2 * BUF, stream);
+      launch_asm<1>(p, dim3(num_m * num_n), 2 * BUF + 1024, stream);       // + 1 KiB: row scales of a folded RMSNorm (rs_*)
     } else {
-      launch_asm<0>(p, dim3(num_m * num_n), 2 * BUF, stream);
+      launch_asm<0>(p, dim3(num_m * num_n), 2 * BUF + 1024, stream);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1280,7 +1340,7 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
 #endif
   if (p.sk_split > 1) {
     const int tail = num_m * num_n - p.sk_full;
-    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(p.sk_full + tail * p.sk_split), dim3(512), 2 * BUF, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(p.sk_full + tail * p.sk_split), dim3(512), 2 * BUF + 1024, stream, p);
     hipLaunchKernelGGL(gemm256_fixup_kernel, dim3(tail * 64), dim3(256), 0, stream, p);
   } else if (p.sw_gu) {
     static bool attr_sw = false;      // the fused SwiGLU-backward epilogue stages a second transposed strip in 32 KiB beyond the ring
@@ -1292,12 +1352,12 @@ int launch256(const GemmArgs& p, hipStream_t stream, int persistent_grid) {
   } else if (p.sf_I) {
     static bool attr_sf = false;
     if (!attr_sf) {
-      hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF);
+      hipFuncSetAttribute((const void*)gemm256_kernel<AM, BM_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 1024);
       attr_sf = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<AM, BM_, 1>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_, 1>), dim3(num_m * num_n), dim3(512), 2 * BUF + 1024, stream, p);
   } else {
-    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF, stream, p);
+    hipLaunchKernelGGL((gemm256_kernel<AM, BM_>), dim3(num_m * num_n), dim3(512), 2 * BUF + 1024, stream, p);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1371,6 +1431,72 @@ extern "C" int mla_gemm_dact_swiglu_bwd(const void* dy, const void* wT, const vo
   return mla_gemm256_dispatch(&p, 0, 0, 0, stream);     // no split-K tail (its fix-up pass has no SwiGLU epilogue)
 }
 
+// ---- RMSNorm folded into the projections (round 6; the kernel north_star names: fused RMSNorm + RoPE + QKV). LlamaRMSNorm
+// (modeling_llama.py:76-90) computes y = g * bf16(x * rstd) and the projection (:351-353, :240) y W^T. The row scale commutes with the
+// product: y W^T = rstd (.) ((x * g) W^T). So the GEMM that PRODUCES x (o_proj / down_proj + residual) also leaves x * g and the
+// per-tile partials of sum(x^2) (mla_gemm_res_norm), and the projection that CONSUMES them multiplies its fp32 accumulator rows by rstd
+// before the single rounding to bf16 that the fused RoPE / SwiGLU epilogues start from (the _rs forms below). The stand-alone norm pass
+// (read x, write y: 2 x 2 B per element) disappears; what is added is the x * g store (2 B per element) in the producer's epilogue.
+// Rounding points: x * g is rounded once (the reference rounds x * rstd and then g * that), the projection is rounded once after the
+// fp32 row scale (the reference: once) -- one rounding fewer on the way, none more.
+extern "C" int mla_gemm_res_norm(const void* A, const void* B, void* C, const void* R, const void* g, void* xg, float* ss, int M, int N,
+                                 int K, int lda, int ldb, int ldc, int ldr, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+  MLA_CHECK_ARG(A && B && C && R && g && xg && ss, "mla_gemm_res_norm: null pointer");
+  MLA_CHECK_ARG(M >= 256 && N >= 256 && N % 256 == 0 && K > 0 && K % 64 == 0, "mla_gemm_res_norm: needs M >= 256, N %% 256 == 0, K %% 64 == 0");
+  MLA_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && ldr >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0,
+                "mla_gemm_res_norm: leading dimensions must be multiples of 8");
+  MLA_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)R) | ((uintptr_t)g) | ((uintptr_t)xg) | ((uintptr_t)ss) |
+                  ((uintptr_t)workspace)) & 15) == 0, "mla_gemm_res_norm: 16-B alignment required");
+  GemmArgs p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.R = (const bf16_t*)R; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.alpha = 1.f;
+  p.sk_ws = workspace;
+  p.nrm_g = (const bf16_t*)g; p.nrm_xg = (bf16_t*)xg; p.nrm_ss = ss;      // xg has C's leading dimension; ss is [M, N / 256]
+  return mla_gemm256_dispatch(&p, 0, 0, workspace ? workspace_bytes : 0, stream);
+}
+
+static int rs_args(GemmArgs& p, const float* ss, int parts, float eps, float* rstd, const char* who) {
+  MLA_CHECK_ARG(rstd != nullptr && (ss == nullptr || parts > 0), "%s: null rstd / bad partial count", who);
+  p.rs_ss = ss; p.rs_parts = parts; p.rs_eps = eps; p.rs_rstd = rstd;
+  return 0;
+}
+
+// mla_gemm_qkv_rope on A = x * g with the row scale of the folded RMSNorm: ss [M, parts] partials of sum(x^2) (rstd is computed here and
+// stored to rstd [M]) or ss == NULL (rstd [M] is read). Fused RMSNorm + QKV + RoPE in one launch.
+extern "C" int mla_gemm_qkv_rope_rs(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                    const float* rope_cos, const float* rope_sin, int S, int rope_cols, const float* ss, int parts,
+                                    float eps, float* rstd, hipStream_t stream) {
+  MLA_CHECK_ARG(A && B && C && rope_cos && rope_sin, "mla_gemm_qkv_rope_rs: null pointer");
+  MLA_CHECK_ARG(M >= 256 && N >= 256 && K > 0 && K % 64 == 0 && N % 8 == 0, "mla_gemm_qkv_rope_rs: needs M, N >= 256, K %% 64 == 0, N %% 8 == 0");
+  MLA_CHECK_ARG(S > 0 && rope_cols > 0 && rope_cols % 256 == 0 && rope_cols <= N, "mla_gemm_qkv_rope_rs: rope_cols must be a multiple of 256 (two heads of 128) and <= N");
+  MLA_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "mla_gemm_qkv_rope_rs: leading dimensions must be multiples of 8");
+  MLA_CHECK_ARG(((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15) == 0,
+                "mla_gemm_qkv_rope_rs: 16-B alignment required");
+  GemmArgs p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.alpha = 1.f;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_S = S; p.rope_cols = rope_cols;
+  if (int rc = rs_args(p, ss, parts, eps, rstd, "mla_gemm_qkv_rope_rs")) return rc;
+  return mla_gemm256_dispatch(&p, 0, 0, 0, stream);
+}
+
+// mla_gemm_gateup_swiglu on A = x * g with the row scale of the folded RMSNorm (see mla_gemm_qkv_rope_rs).
+extern "C" int mla_gemm_gateup_swiglu_rs(const void* x, const void* wgu, void* gu, void* act, void* actT, int M, int I, int K, int lda,
+                                         int ldb, long long ldt, const float* ss, int parts, float eps, float* rstd, hipStream_t stream) {
+  MLA_CHECK_ARG(x && wgu && gu && act, "mla_gemm_gateup_swiglu_rs: null pointer");
+  MLA_CHECK_ARG(M >= 256 && I >= 128 && I % 128 == 0 && K > 0 && K % 64 == 0, "mla_gemm_gateup_swiglu_rs: needs M >= 256, I %% 128 == 0, K %% 64 == 0");
+  MLA_CHECK_ARG(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0, "mla_gemm_gateup_swiglu_rs: leading dimensions must be multiples of 8");
+  MLA_CHECK_ARG(actT == nullptr || (M % 8 == 0 && ldt >= M && ldt % 8 == 0), "mla_gemm_gateup_swiglu_rs: transposed output needs M %% 8 == 0, ldt >= M, ldt %% 8 == 0");
+  MLA_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wgu) | ((uintptr_t)gu) | ((uintptr_t)act) | ((uintptr_t)actT)) & 15) == 0,
+                "mla_gemm_gateup_swiglu_rs: 16-B alignment required");
+  GemmArgs p{};
+  p.A = (const bf16_t*)x; p.B = (const bf16_t*)wgu; p.C = gu; p.M = M; p.N = 2 * I; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = 2 * I;
+  p.alpha = 1.f;
+  p.sf_I = I; p.sf_act = (bf16_t*)act; p.sf_actT = (bf16_t*)actT; p.sf_ldt = ldt;
+  if (int rc = rs_args(p, ss, parts, eps, rstd, "mla_gemm_gateup_swiglu_rs")) return rc;
+  return mla_gemm256_dispatch(&p, 0, 0, 0, stream);
+}
+
 // called by mla_gemm_bf16 (gemm.hip) for k-contiguous operands with M, N >= 256 and K % 64 == 0. Only the <0,0>
 // instantiation is built: the reduction-major (ds_read_b64_tr_b16) variants of this schedule are slower than gemm128's.
 // number of sum-of-squares partials a k-contiguous fp32-output launch of this shape writes (whole tiles + 64 per split tile): lets the
@@ -1409,6 +1535,16 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   }
   p.sk_split = 1;
   p.sk_full = 0;
+  if (p.nrm_xg || p.rs_rstd) {     // folded RMSNorm: whole-row epilogues of the k-contiguous kernel only (the entry points check the shapes)
+    const bool fast = (p.N & 7) == 0 && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0 &&
+                      (p.R == nullptr || ((p.ldr & 7) == 0 && (((uintptr_t)p.R) & 15) == 0)) && p.bias == nullptr && !p.out_fp32;
+    const bool ok = fast && a_mode == 0 && b_mode == 0 && p.alpha == 1.f &&
+                    (p.nrm_xg ? (p.R != nullptr && p.N % 256 == 0 && !p.rs_rstd && !p.sf_I && !p.sw_gu && !p.rope_cos) : (p.R == nullptr && !p.sw_gu));
+    if (!ok) {
+      mla_set_error("gemm256: the folded-RMSNorm forms need bf16 k-contiguous operands, alpha 1 and the whole-row epilogue");
+      return -1;
+    }
+  }
   static int ncu = 0, persist = -1;
   if (!ncu) {
     int dev = 0;
@@ -1455,7 +1591,7 @@ int mla_gemm256_dispatch(const void* args, int a_mode, int b_mode, size_t ws_byt
   persist = 0;
 #endif
   const bool use_p = (persist || (p.debug & 0x100)) && (p.debug & 0x80) == 0 && tiles > grid && bytesA < 0x7fffffffULL && bytesB < 0x7fffffffULL &&
-                     p.sf_I == 0 && p.sw_gu == nullptr && p.rope_cos == nullptr && p.sq_out == nullptr;     // the persistent walk has the plain epilogue only
+                     p.sf_I == 0 && p.sw_gu == nullptr && p.rope_cos == nullptr && p.sq_out == nullptr && p.nrm_xg == nullptr && p.rs_rstd == nullptr;     // the persistent walk has the plain epilogue only
   if (sq_slots) *sq_slots = p.sk_split > 1 ? p.sk_full + (tiles - p.sk_full) * 64 : tiles;
   // reduction-major operands ([K, rows] storage, fragments gathered with ds_read_b64_tr_b16): plain epilogue, split-K tail allowed
   if (a_mode == 0 && b_mode == 1) return launch256<0, 1>(p, stream, 0);

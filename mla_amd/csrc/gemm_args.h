@@ -50,4 +50,19 @@ struct GemmArgs {
   // starts `stagger_ticks` (10 ns units) late, so that the HBM-bound epilogue bursts of one half of the chip fall into the other
   // half's main loops instead of all 256 CUs storing at once. mode 1: odd XCDs late, mode 2: every other workgroup of each XCD late.
   int stagger_mode, stagger_ticks;
+  // ---- RMSNorm folded into the projections (round 6; LlamaRMSNorm modeling_llama.py:76-90 feeding :351-353 / :240).
+  // y = g * (x * rstd) followed by y W^T equals rstd (.) ((x * g) W^T): the row scale commutes with the product, the column scale does not.
+  // PRODUCER side (gemm256 bf16 + residual whole-row epilogue and its split-K fix-up; N % 256 == 0): besides C = the new residual-stream
+  // rows h, the launch leaves nrm_xg [M, ldc] = bf16(h * nrm_g) (h = the ROUNDED output, as the stand-alone norm would read it) and
+  // nrm_ss [M, N / 256] = one fp32 partial of sum(h^2) per row and column tile (fixed lane order: deterministic).
+  const bf16_t* nrm_g;
+  bf16_t* nrm_xg;
+  float* nrm_ss;
+  // CONSUMER side (fused QKV + RoPE and fused gate|up + SwiGLU launches): output row m is multiplied by rstd[m] in fp32 before its single
+  // rounding to bf16 (the tile image the fused epilogues read). rs_ss != null: rstd[m] = 1 / sqrt(sum_j rs_ss[m, j] / K + rs_eps) over
+  // rs_parts partials, and the workgroups of column tile 0 store it to rs_rstd [M] (the backward needs it); rs_ss == null: rs_rstd is read.
+  const float* rs_ss;
+  float* rs_rstd;
+  int rs_parts;
+  float rs_eps;
 };

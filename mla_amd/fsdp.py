@@ -495,6 +495,8 @@ class ShardedModel:
                 mod = getattr(u, "module", None)
                 if mod is not None:
                     mod.register_forward_pre_hook(lambda m, inp, uu=u: self.wait_unit(uu))
+                    if hasattr(mod, "_gather_wait"):      # the previous decoder layer reads this one's input_layernorm weight (ops.NormFoldIO)
+                        mod._gather_wait = (lambda uu=u: self.wait_unit(uu))
                 else:
                     owned = {id(p) for _, p, _ in u.params}
                     for m in model.modules():

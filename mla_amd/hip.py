@@ -53,6 +53,13 @@ _SIGNATURES = {
     "mla_gemm_dact_swiglu_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
                                  c_void_p],
     "mla_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "mla_rmsnorm_prep": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "mla_gemm_res_norm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_void_p, c_size_t, c_void_p],
+    "mla_gemm_qkv_rope_rs": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                             c_void_p, c_int, c_float, c_void_p, c_void_p],
+    "mla_gemm_gateup_swiglu_rs": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_longlong,
+                                  c_void_p, c_int, c_float, c_void_p, c_void_p],
     "mla_rmsnorm_bwd_blocks": [c_int],
     "mla_timm_rmsnorm_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "mla_timm_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
@@ -308,16 +315,49 @@ def sum_partials(partials: torch.Tensor, n: int, out1: torch.Tensor, accumulate:
     call("mla_sum_partials", _p(partials), int(n), _p(out1), 1 if accumulate else 0)
 
 
-def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols):
-    """out[T, N] = x2d @ wqkv^T with RoPE applied to columns [0, rope_cols) in the GEMM epilogue (bit-identical to gemm + rope_inplace).
-    Returns False when the shape is outside the fused kernel's contract (the caller then runs the two separate launches)."""
+def _rs_args(norm, rows, device):
+    """(ss, parts, eps, rstd) of a folded RMSNorm for the _rs entry points. norm = (ss [rows, parts] fp32 or None, rstd [rows] fp32 or
+    None, eps): partials given -> rstd is computed by the launch and returned; else the given rstd is read."""
+    ss, rstd, eps = norm
+    if ss is not None:
+        assert ss.dtype == torch.float32 and ss.is_contiguous() and ss.shape[0] == rows
+        rstd = torch.empty(rows, dtype=torch.float32, device=device)
+        return ss, int(ss.shape[1]), float(eps), rstd
+    assert rstd is not None and rstd.dtype == torch.float32 and rstd.is_contiguous() and rstd.numel() == rows
+    return None, 0, float(eps), rstd
+
+
+def qkv_rope_ok(x2d, wqkv, out, cos, sin, S, rope_cols) -> bool:
     T, K = x2d.shape
     N = wqkv.shape[0]
-    ok = (T >= 256 and N >= 256 and K % 64 == 0 and N % 8 == 0 and rope_cols % 256 == 0 and x2d.stride(0) % 8 == 0 and
-          wqkv.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and cos.dtype == torch.float32 and cos.is_contiguous() and
-          sin.is_contiguous() and cos.shape == (S, 64) and all(t.data_ptr() % 16 == 0 for t in (x2d, wqkv, out, cos, sin)))
+    return (T >= 256 and N >= 256 and K % 64 == 0 and N % 8 == 0 and rope_cols % 256 == 0 and x2d.stride(0) % 8 == 0 and
+            wqkv.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and cos.dtype == torch.float32 and cos.is_contiguous() and
+            sin.is_contiguous() and cos.shape == (S, 64) and all(t.data_ptr() % 16 == 0 for t in (x2d, wqkv, out, cos, sin)))
+
+
+def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols, norm=None):
+    """out[T, N] = x2d @ wqkv^T with RoPE applied to columns [0, rope_cols) in the GEMM epilogue (bit-identical to gemm + rope_inplace).
+    Returns False when the shape is outside the fused kernel's contract (the caller then runs the two separate launches).
+    norm = (ss, rstd, eps): x2d is x * g of a folded RMSNorm (mla_gemm_qkv_rope_rs: fused RMSNorm + QKV + RoPE); returns rstd [T]."""
+    T, K = x2d.shape
+    N = wqkv.shape[0]
+    ok = qkv_rope_ok(x2d, wqkv, out, cos, sin, S, rope_cols)
     if not ok:
         return False
+    if norm is not None:
+        _req(x2d, torch.bfloat16, "gemm_qkv_rope x")
+        _req(wqkv, torch.bfloat16, "gemm_qkv_rope w")
+        ss, parts, eps, rstd = _rs_args(norm, T, x2d.device)
+        prof = GEMM_PROFILE
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        call("mla_gemm_qkv_rope_rs", _p(x2d), _p(wqkv), _p(out), T, N, K, x2d.stride(0), wqkv.stride(0), out.stride(0), _p(cos), _p(sin),
+             int(S), int(rope_cols), _p(ss), parts, eps, _p(rstd))
+        if prof is not None:
+            ev1.record()
+            prof.append((ev0, ev1, 2.0 * T * N * K, (0, 0, T, N, K, "rope_epilogue")))
+        return rstd
     _req(x2d, torch.bfloat16, "gemm_qkv_rope x")
     _req(wqkv, torch.bfloat16, "gemm_qkv_rope w")
     prof = GEMM_PROFILE
@@ -332,13 +372,20 @@ def gemm_qkv_rope(x2d, wqkv, out, cos, sin, S, rope_cols):
     return True
 
 
-def gemm_gateup_swiglu(x2d, wgu, want_t):
-    """(gu [T, 2I], act [T, I], actT [I, T] or None) from ONE launch: the SwiGLU product is formed in the gate|up GEMM's epilogue.
-    None when the shape is outside the fused kernel's contract (the caller then runs gemm + swiglu_fwd[_dual])."""
+def gateup_swiglu_ok(x2d, wgu, want_t) -> bool:
     T, K = x2d.shape
     I = wgu.shape[0] // 2
-    ok = (T >= 256 and I % 128 == 0 and K % 64 == 0 and wgu.shape[0] == 2 * I and x2d.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0 and
-          (not want_t or T % 8 == 0) and all(t.data_ptr() % 16 == 0 for t in (x2d, wgu)))
+    return (T >= 256 and I % 128 == 0 and K % 64 == 0 and wgu.shape[0] == 2 * I and x2d.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0 and
+            (not want_t or T % 8 == 0) and all(t.data_ptr() % 16 == 0 for t in (x2d, wgu)))
+
+
+def gemm_gateup_swiglu(x2d, wgu, want_t, norm=None):
+    """(gu [T, 2I], act [T, I], actT [I, T] or None) from ONE launch: the SwiGLU product is formed in the gate|up GEMM's epilogue.
+    None when the shape is outside the fused kernel's contract (the caller then runs gemm + swiglu_fwd[_dual]).
+    norm = (ss, rstd, eps): x2d is x * g of a folded RMSNorm (mla_gemm_gateup_swiglu_rs); rstd [T] is appended to the result."""
+    T, K = x2d.shape
+    I = wgu.shape[0] // 2
+    ok = gateup_swiglu_ok(x2d, wgu, want_t)
     if not ok:
         return None
     _req(x2d, torch.bfloat16, "gemm_gateup_swiglu x")
@@ -350,11 +397,17 @@ def gemm_gateup_swiglu(x2d, wgu, want_t):
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    call("mla_gemm_gateup_swiglu", _p(x2d), _p(wgu), _p(gu), _p(act), _p(actT), T, I, K, x2d.stride(0), wgu.stride(0), T)
+    rstd = None
+    if norm is not None:
+        ss, parts, eps, rstd = _rs_args(norm, T, x2d.device)
+        call("mla_gemm_gateup_swiglu_rs", _p(x2d), _p(wgu), _p(gu), _p(act), _p(actT), T, I, K, x2d.stride(0), wgu.stride(0), T,
+             _p(ss), parts, eps, _p(rstd))
+    else:
+        call("mla_gemm_gateup_swiglu", _p(x2d), _p(wgu), _p(gu), _p(act), _p(actT), T, I, K, x2d.stride(0), wgu.stride(0), T)
     if prof is not None:
         ev1.record()
         prof.append((ev0, ev1, 2.0 * T * 2 * I * K, (0, 0, T, 2 * I, K, "swiglu_fwd_epilogue")))
-    return gu, act, actT
+    return (gu, act, actT) if norm is None else (gu, act, actT, rstd)
 
 
 def gemm_dact_swiglu_bwd(dy2d, wT, gu2d):
@@ -390,6 +443,51 @@ def rmsnorm_fwd(x2d, w, eps):
     rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
     call("mla_rmsnorm_fwd", _p(x2d), _p(w), _p(y), _p(rstd), rows, H, float(eps))
     return y, rstd
+
+
+def rmsnorm_prep(x2d, w, eps, want_rstd=True):
+    """(xg = bf16(x * w), rstd [rows] or None): the two halves of a folded RMSNorm for rows that do not come out of a GEMM epilogue."""
+    _req(x2d, torch.bfloat16, "rmsnorm_prep x")
+    _req(w, torch.bfloat16, "rmsnorm_prep w")
+    rows, H = x2d.shape
+    xg = torch.empty_like(x2d)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device) if want_rstd else None
+    call("mla_rmsnorm_prep", _p(x2d), _p(w), _p(xg), _p(rstd), rows, H, float(eps))
+    return xg, rstd
+
+
+def res_norm_ok(a, b, residual) -> bool:
+    M, K = a.shape
+    N = b.shape[0]
+    return (M >= 256 and N >= 256 and N % 256 == 0 and K % 64 == 0 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and
+            residual.stride(0) % 8 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and residual.stride(1) == 1 and
+            all(t.data_ptr() % 16 == 0 for t in (a, b, residual)))
+
+
+def gemm_res_norm(a, b, residual, g):
+    """(h, xg, ss): h = a @ b^T + residual (the new residual-stream rows), xg = bf16(h * g) and ss [M, N / 256] = per-tile partials of
+    sum(h^2) per row -- the producer half of a folded RMSNorm (mla_gemm_res_norm), one GEMM launch."""
+    _req(a, torch.bfloat16, "gemm_res_norm a")
+    _req(b, torch.bfloat16, "gemm_res_norm b")
+    _req(residual, torch.bfloat16, "gemm_res_norm residual")
+    _req(g, torch.bfloat16, "gemm_res_norm g")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and residual.shape == (M, N) and g.numel() == N and g.data_ptr() % 16 == 0
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    xg = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    ss = torch.empty((M, N // 256), dtype=torch.float32, device=a.device)
+    ws = workspace(SPLITK_WS_BYTES, a.device) if SPLITK else None
+    prof = GEMM_PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    call("mla_gemm_res_norm", _p(a), _p(b), _p(h), _p(residual), _p(g), _p(xg), _p(ss), M, N, K, a.stride(0), b.stride(0), N,
+         residual.stride(0), _p(ws), SPLITK_WS_BYTES if ws is not None else 0)
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, 2.0 * M * N * K, (0, 0, M, N, K)))
+    return h, xg, ss
 
 
 def rmsnorm_bwd(dy, x2d, w, rstd, dres=None, dw_out=None, dw_accumulate=False):

@@ -154,6 +154,8 @@ class LlamaDecoderLayer(nn.Module):
         self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self._grad_hook = None  # set by mla_amd.fsdp: fires when this layer's backward has been enqueued
+        self._gather_wait = None  # set by mla_amd.fsdp (world > 1): makes the current stream wait for this layer's all-gather
+        self._fold_out = None   # ops.NormFoldIO.out of the last forward (x * g and sum(x^2) partials for the NEXT layer's input norm)
 
     def _weights(self):
         a, m = self.self_attn, self.mlp
@@ -161,7 +163,9 @@ class LlamaDecoderLayer(nn.Module):
                 self.post_attention_layernorm.weight, m.gate_proj.weight, m.up_proj.weight, m.down_proj.weight)
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
-                use_cache=False, cache_position=None, seqlens: Optional[torch.Tensor] = None, rope_tables=None, **kwargs):
+                use_cache=False, cache_position=None, seqlens: Optional[torch.Tensor] = None, rope_tables=None, norm_fold=None, **kwargs):
+        """norm_fold = (what the previous layer's down projection made for this layer's input norm or None, the next LlamaDecoderLayer
+        or None): the RMSNorms are folded into the projections (ops.NormFoldIO); None = the separate rmsnorm launches."""
         if past_key_value is not None or use_cache or output_attentions:
             raise NotImplementedError("KV cache / attention-weight output are inference features (SURVEY 8f rank 2)")
         B, S, _ = hidden_states.shape
@@ -169,8 +173,18 @@ class LlamaDecoderLayer(nn.Module):
             seqlens = attention_mask.reshape(B, -1).sum(-1).to(torch.int32)
         cos, sin = rope_tables if rope_tables is not None else self.self_attn.rotary_emb.tables(S, hidden_states.device)
         h = ops.unit_boundary(hidden_states, self._grad_hook)
+        io = None
+        if norm_fold is not None:
+            carry, nxt = norm_fold
+            next_ln = None
+            if nxt is not None:
+                if nxt._gather_wait is not None:
+                    nxt._gather_wait()           # this layer's down projection reads the NEXT layer's input_layernorm weight
+                next_ln = nxt.input_layernorm.weight
+            io = ops.NormFoldIO(pre=carry, next_ln=next_ln)
         out = ops.decoder_layer(h, seqlens, cos, sin, self.config.num_attention_heads, self.config.rms_norm_eps,
-                                self.config.layer_save_level(self.layer_idx), self._weights())
+                                self.config.layer_save_level(self.layer_idx), self._weights(), fold_io=io)
+        self._fold_out = io.out if io is not None else None
         return (out,)
 
 
@@ -215,10 +229,16 @@ class LlamaModel(nn.Module):
             rope_tables = self.layers[0].self_attn.rotary_emb.tables_for_positions(position_ids.reshape(-1))
             assert rope_tables[0].shape[0] in (S, B * S)
         with ops.attn_groups(attn_groups):
-            for layer in self.layers:
+            fold, carry, n_layers = ops.norm_fold_enabled(), None, len(self.layers)
+            for i, layer in enumerate(self.layers):
                 if output_hidden_states:
                     all_hidden += (hidden_states,)
-                hidden_states = layer(hidden_states, seqlens=seqlens, rope_tables=rope_tables)[0]
+                if fold:       # RMSNorms folded into the projections: layer i's down projection prepares layer i + 1's input norm
+                    nxt = self.layers[i + 1] if i + 1 < n_layers else None
+                    hidden_states = layer(hidden_states, seqlens=seqlens, rope_tables=rope_tables, norm_fold=(carry, nxt))[0]
+                    carry, layer._fold_out = layer._fold_out, None
+                else:
+                    hidden_states = layer(hidden_states, seqlens=seqlens, rope_tables=rope_tables)[0]
         hidden_states = self.norm(hidden_states)
         if output_hidden_states:
             all_hidden += (hidden_states,)

@@ -535,6 +535,34 @@ _ATTN_BWD_T = os.environ.get("MLA_ATTN_BWD_T", "1") != "0"           # dqkv^T / 
 _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (tools): 0 = recompute act^T in the backward
 
 
+# RMSNorm folded into the projections (round 6, mla_hip.h: mla_gemm_res_norm / _qkv_rope_rs / _gateup_swiglu_rs): the stand-alone norm passes
+# of the decoder layer's FORWARD disappear -- the GEMM that produces the residual-stream rows leaves x * g and the partials of sum(x^2), the
+# projection applies rstd to its accumulator rows. MLA_NORM_FOLD=0 restores the separate rmsnorm_fwd launches (A/B switch).
+_NORM_FOLD = os.environ.get("MLA_NORM_FOLD", "1") != "0"
+
+
+def norm_fold_enabled() -> bool:
+    return _NORM_FOLD
+
+
+def set_norm_fold(on: bool) -> bool:
+    """A/B switch for tests and tools; returns the previous setting."""
+    global _NORM_FOLD
+    prev, _NORM_FOLD = _NORM_FOLD, bool(on)
+    return prev
+
+
+class NormFoldIO:
+    """What one decoder layer hands to the next when the RMSNorms are folded into the projections: `pre` = (rows' data_ptr, norm weight,
+    xg = bf16(h * g), ss partials) made by the PREVIOUS layer's down projection for THIS layer's input_layernorm (None: first layer, or
+    the previous layer could not make it -> mla_rmsnorm_prep); `next_ln` = the next layer's input_layernorm weight (None: last layer);
+    `out` = what this layer's down projection made for the next one."""
+    __slots__ = ("pre", "next_ln", "out")
+
+    def __init__(self, pre=None, next_ln=None):
+        self.pre, self.next_ln, self.out = pre, next_ln, None
+
+
 # Suffix groups of shared-prefix sequences (round 6, mla_hip.h: mla_attn_fwd_g): (first suffix row, rows per group) or None. Set by the
 # caller of the decoder stack for the duration of its forward (LlamaModel.forward(attn_groups=...)); every DecoderLayerFn.forward
 # records the value it saw in its ctx, so backward and checkpoint recomputation use the same grouping whatever is current then.
@@ -574,10 +602,63 @@ class DecoderLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False, groups=None):
+    def _fold_ok(h2, cos, sin, Sr, nheads, w, save_t) -> bool:
+        """The folded-RMSNorm forward needs all four GEMMs of the layer inside the 256x256 kernel's fused-epilogue contracts."""
+        ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
+        T, H = h2.shape
+        wqkv, wgu = cat_view((wq, wk, wv)), cat_view((wg, wu))
+        if wqkv is None or wgu is None or H // nheads != 128 or not (_ROPE_EPILOGUE and _SWIGLU_FWD_EPILOGUE):
+            return False
+        if T < 256 or H % 256 != 0 or any(t.data_ptr() % 16 for t in (ln1, ln2, wo, wd)) or wo.stride(0) % 8 or wd.stride(0) % 8:
+            return False
+        qkv_like = torch.empty((0, 3 * H), dtype=BF16, device=h2.device)
+        return (hip.qkv_rope_ok(h2, wqkv, qkv_like, cos, sin, Sr, 2 * H) and hip.gateup_swiglu_ok(h2, wgu, save_t and T % 8 == 0) and
+                wd.shape[1] % 64 == 0)
+
+    @staticmethod
+    def _fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold):
+        """_fwd with both RMSNorms folded into the projections (mla_hip.h "RMSNorm folded into the projections"): no stand-alone norm
+        pass; rstd1 / rstd2 come out of the QKV and gate|up launches. fold = NormFoldIO, or a saved rstd1 tensor (recomputation of a
+        checkpointed layer: the same row scale as in the forward, whatever produced it there)."""
+        ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
+        T, H = h2.shape
+        D = H // nheads
+        Sr = cos.shape[0]
+        wqkv, wgu = cat_view((wq, wk, wv)), cat_view((wg, wu))
+        io = fold if isinstance(fold, NormFoldIO) else None
+        pre = io.pre if io is not None else None
+        if pre is not None and not (pre[0] == h2.data_ptr() and pre[1].data_ptr() == ln1.data_ptr() and pre[2].shape == h2.shape):
+            pre = None                                   # made for other rows / another weight: ignore it
+        if pre is not None:
+            xg1, norm1 = pre[2], (pre[3], None, eps)
+        elif io is None and fold is not None:
+            xg1, norm1 = hip.rmsnorm_prep(h2, ln1, eps, want_rstd=False)[0], (None, fold, eps)
+        else:
+            xg1, r1 = hip.rmsnorm_prep(h2, ln1, eps)
+            norm1 = (None, r1, eps)
+        qkv = torch.empty((T, 3 * H), dtype=BF16, device=h2.device)
+        rstd1 = hip.gemm_qkv_rope(xg1, wqkv, qkv, cos, sin, Sr, 2 * H, norm=norm1)      # fused RMSNorm + QKV + RoPE
+        assert rstd1 is not False
+        del xg1
+        o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
+                              rows=T, groups=groups)
+        h1, xg2, ss2 = hip.gemm_res_norm(o, wo, h2, ln2)
+        gu, act_, actT, rstd2 = hip.gemm_gateup_swiglu(xg2, wgu, save_t and T % 8 == 0, norm=(ss2, None, eps))
+        del xg2, ss2
+        if io is not None and io.next_ln is not None and io.next_ln.data_ptr() % 16 == 0:
+            out, xgn, ssn = hip.gemm_res_norm(act_, wd, h1, io.next_ln)
+            io.out = (out.data_ptr(), io.next_ln, xgn, ssn)
+        else:
+            out = hip.gemm(act_, wd, residual=h1)
+        return out, (None, rstd1, qkv, o, lse, h1, None, rstd2, gu, act_, actT)
+
+    @staticmethod
+    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False, groups=None, fold=None):
         ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
         H = h2.shape[1]
         D = H // nheads
+        if fold is not None:
+            return DecoderLayerFn._fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold)
         xn1, rstd1 = hip.rmsnorm_fwd(h2, ln1, eps)
         qkv = torch.empty((h2.shape[0], 3 * H), dtype=BF16, device=h2.device)
         wqkv = cat_view((wq, wk, wv))
@@ -622,7 +703,7 @@ class DecoderLayerFn(torch.autograd.Function):
         return out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT)
 
     @staticmethod
-    def forward(ctx, h, seqlens, cos, sin, nheads, eps, save_level, *w):
+    def forward(ctx, h, seqlens, cos, sin, nheads, eps, save_level, fold_io, *w):
         _check_bf16_cuda(h, *w)
         B, S, H = h.shape
         h2 = h.reshape(B * S, H)
@@ -634,12 +715,18 @@ class DecoderLayerFn(torch.autograd.Function):
             # an odd padded length) runs on zero rows appended here; they stay zero through every row-wise op, contribute zero to
             # every weight gradient, and are cut off again below
             h2 = torch.cat([h2, h2.new_zeros(Tp - T, H)], 0)
-        keep_t = save_level == 1 and ctx.needs_input_grad[7 + 8] and _SWIGLU_DUAL   # down_proj trainable: its wgrad wants act^T
+        keep_t = save_level == 1 and ctx.needs_input_grad[8 + 8] and _SWIGLU_DUAL   # down_proj trainable: its wgrad wants act^T
         if save_level == 3:
             save_level = 1                         # "1-lean": same saved set as level 1 minus act^T
         ctx.groups = current_attn_groups()
+        # RMSNorms folded into the projections: when the caller hands a NormFoldIO and every GEMM of the layer is inside the fused kernels'
+        # contracts. The padded rows of a handed-over x * g belong to the previous layer's padded output: same zero rows.
+        fold = fold_io if (fold_io is not None and DecoderLayerFn._fold_ok(h2, cos, sin, cos.shape[0], nheads, w, keep_t)) else None
+        if fold is not None and fold.pre is not None and Tp != T and fold.pre[0] == h.data_ptr() and fold.pre[2].shape[0] == Tp:
+            fold.pre = (h2.data_ptr(),) + tuple(fold.pre[1:])
+        ctx.folded = fold is not None
         out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w,
-                                                                                             save_t=keep_t, groups=ctx.groups)
+                                                                                             save_t=keep_t, groups=ctx.groups, fold=fold)
         out = out[:T]
         ctx.w, ctx.dims, ctx.save_level = w, (B, S, H, nheads, eps), save_level
         ctx.aux = (seqlens, cos, sin)
@@ -650,6 +737,8 @@ class DecoderLayerFn(torch.autograd.Function):
             # level 1 = recompute the two normalised inputs in the backward (one HBM-bound pass each, written straight into the
             # transposed layout) and KEEP the SwiGLU product, already transposed (+0.39 GB per layer at 7B; 288 GB of HBM)
             ctx.save_for_backward(*((h2, rstd1, qkv, o, lse, h1, rstd2, gu) + ((actT,) if actT is not None else ())))
+        elif ctx.folded:
+            ctx.save_for_backward(h2, rstd1)       # the recomputation scales the QKV rows by the SAME rstd the forward used
         else:
             ctx.save_for_backward(h2)
         return out.view(B, S, H)
@@ -675,10 +764,13 @@ class DecoderLayerFn(torch.autograd.Function):
             else:
                 h2, rstd1, qkv, o, lse, h1, rstd2, gu = ctx.saved_tensors
         else:
-            (h2,) = ctx.saved_tensors
+            if ctx.folded:
+                h2, rstd1_f = ctx.saved_tensors
+            else:
+                (h2,), rstd1_f = ctx.saved_tensors, None
             _, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, _) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w,
-                                                                                            groups=ctx.groups)
-        need = ctx.needs_input_grad[7:]
+                                                                                            groups=ctx.groups, fold=rstd1_f)
+        need = ctx.needs_input_grad[8:]
         d2 = dout.reshape(T, H)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
@@ -771,11 +863,11 @@ class DecoderLayerFn(torch.autograd.Function):
         else:
             ln1_run(None, False)
         dh = holder["dh"][:Tr].view(B, S, H) if ctx.needs_input_grad[0] else None
-        return (dh, None, None, None, None, None, None, *grads)
+        return (dh, None, None, None, None, None, None, None, *grads)
 
 
-def decoder_layer(h, seqlens, cos, sin, nheads, eps, save_level, weights):
-    return DecoderLayerFn.apply(h, seqlens, cos, sin, nheads, eps, save_level, *weights)
+def decoder_layer(h, seqlens, cos, sin, nheads, eps, save_level, weights, fold_io=None):
+    return DecoderLayerFn.apply(h, seqlens, cos, sin, nheads, eps, save_level, fold_io, *weights)
 
 
 class GatherRowsFn(torch.autograd.Function):

@@ -1,0 +1,323 @@
+"""GPU: RMSNorm folded into the projections (include/mla_hip.h "RMSNorm folded into the projections"; round 6, the kernel north_star
+names: fused RMSNorm + RoPE + QKV). LlamaRMSNorm (modeling_llama.py:76-90) feeds only projections (:351-353, :240) and
+g * (x * rstd) W^T == rstd (.) ((x * g) W^T): the producer GEMM's epilogue leaves x * g and the partials of sum(x^2), the consumer GEMM
+scales its fp32 accumulator rows by rstd before the single bf16 rounding its fused RoPE / SwiGLU epilogue starts from.
+
+Every launch is checked bit for bit against the same arithmetic spelled out with the plain kernels (fp32-output GEMM, torch's fp32
+multiply and round-to-nearest-even cast, mla_rope_inplace / mla_swiglu_fwd_dual), and the whole decoder layer against the fp32 oracle
+under the SURVEY 8c(ii) yardstick at the benchmark's true dimensions."""
+import os
+
+import pytest
+import torch
+
+from conftest import fro_rel
+from oracle import recipe
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+NAMES = ["input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+         "self_attn.o_proj.weight", "post_attention_layernorm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+         "mlp.down_proj.weight"]
+
+
+def bfr(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def rstd_of(ss, K, eps):
+    """rstd exactly as the consumer launch forms it: partials added in index order in fp32, 1 / sqrt(sum / K + eps)."""
+    t = torch.zeros_like(ss[:, 0])
+    for j in range(ss.shape[1]):
+        t = t + ss[:, j]
+    return 1.0 / torch.sqrt(t / K + eps)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 512), (4352, 512, 256), (2344, 1024, 1024), (300, 256, 64)])
+def test_res_norm_producer_epilogue(dev, M, N, K):
+    """mla_gemm_res_norm: h bit-identical to mla_gemm_bf16_ws with the residual epilogue (whole tiles through the main kernel, the split-K
+    tail through the fix-up pass: 256 / 34 / 40 / 2 tiles), xg == bf16(h * g) exactly, ss = per-tile partials of sum(h^2)."""
+    from mla_amd import hip
+    a = bfr(M, K, seed=1).to(dev)
+    b = bfr(N, K, seed=2, scale=0.1).to(dev)
+    r = bfr(M, N, seed=3).to(dev)
+    g = (1.0 + 0.2 * torch.randn(N, generator=torch.Generator().manual_seed(4))).to(BF).to(dev)
+    assert hip.res_norm_ok(a, b, r)
+    ref = hip.gemm(a, b, residual=r)
+    h, xg, ss = hip.gemm_res_norm(a, b, r, g)
+    assert torch.equal(h, ref)
+    assert torch.equal(xg, (h.float() * g.float()[None]).to(BF))
+    assert ss.shape == (M, N // 256)
+    want = (h.float() ** 2).view(M, N // 256, 256).double().sum(-1)
+    assert float(((ss.double() - want).abs() / want).max()) < 1e-5
+    # run to run: bit-identical partials (fixed lane order)
+    h2, xg2, ss2 = hip.gemm_res_norm(a, b, r, g)
+    assert torch.equal(ss, ss2) and torch.equal(xg, xg2) and torch.equal(h, h2)
+
+
+@pytest.mark.parametrize("T,S,nh,K", [(548 * 2, 548, 4, 512), (300, 100, 2, 256), (2048, 2048, 2, 256)])
+@pytest.mark.parametrize("kloop", [1, 0])
+def test_fused_rmsnorm_qkv_rope_is_the_plain_kernels(dev, T, S, nh, K, kloop):
+    """mla_gemm_qkv_rope_rs (fused RMSNorm + QKV + RoPE) == fp32-output GEMM of x * g, rows times rstd in fp32, ONE rounding to bf16,
+    mla_rope_inplace -- bit for bit; rstd from the partials (stored for the backward) and rstd handed in; assembly and compiler loops."""
+    from mla_amd import hip
+    D, H = 128, nh * 128
+    eps = 1e-5
+    x = bfr(T, K, seed=31).to(dev)
+    g = (1.0 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(5))).to(BF).to(dev)
+    w = bfr(3 * H, K, seed=32, scale=0.2).to(dev)
+    cos, sin = O.rope_tables(S, D)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    xg, rstd_prep = hip.rmsnorm_prep(x, g, eps)
+    assert torch.equal(xg, (x.float() * g.float()[None]).to(BF))
+    want_rstd = 1.0 / torch.sqrt((x.float() ** 2).double().sum(-1) / K + eps)
+    assert float(((rstd_prep.double() - want_rstd).abs() / want_rstd).max()) < 1e-6
+    parts = 4
+    ss = ((x.float() ** 2).view(T, parts, K // parts).sum(-1)).contiguous()     # any partition of sum(x^2) into partials
+    prev = hip.gemm_kloop(-1)
+    hip.gemm_kloop(kloop)
+    try:
+        out = torch.full((T, 3 * H), float("nan"), dtype=BF, device=dev)
+        rstd = hip.gemm_qkv_rope(xg, w, out, cos, sin, S, 2 * H, norm=(ss, None, eps))
+        assert rstd is not False and rstd.shape == (T,)
+        want = rstd_of(ss, K, eps)
+        assert float(((rstd - want).abs() / want).max()) < 1e-6
+        acc = hip.gemm(xg, w, out_dtype=torch.float32)
+        ref = (acc * rstd[:, None]).to(BF)
+        hip.rope_inplace(ref, cos, sin, S, nh, D, 0, H)
+        assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+        out2 = torch.full((T, 3 * H), float("nan"), dtype=BF, device=dev)
+        r2 = hip.gemm_qkv_rope(xg, w, out2, cos, sin, S, 2 * H, norm=(None, rstd, eps))
+        assert r2 is rstd and torch.equal(out2, out)
+    finally:
+        hip.gemm_kloop(prev)
+    # against the reference's arithmetic: RMSNorm -> projection -> RoPE in fp32 (loose: bf16 outputs)
+    xn = x.float() * want_rstd.float()[:, None] * g.float()[None]
+    qk = (xn @ w.float().t()).cpu()
+    B = T // S
+    q = qk[:B * S, :H].view(B, S, nh, D).transpose(1, 2)
+    k = qk[:B * S, H:2 * H].view(B, S, nh, D).transpose(1, 2)
+    qr, _ = O.apply_rope(q, k, cos.cpu(), sin.cpu())
+    got = out[:B * S, :H].float().cpu().view(B, S, nh, D).transpose(1, 2)
+    assert fro_rel(got, qr) < 6e-3
+
+
+@pytest.mark.parametrize("T,I,K", [(512, 512, 256), (1096, 640, 128), (264, 128, 256)])
+def test_fused_rmsnorm_gateup_swiglu_is_the_plain_kernels(dev, T, I, K):
+    """mla_gemm_gateup_swiglu_rs == fp32-output GEMM of x * g, rows times rstd, one rounding, mla_swiglu_fwd_dual -- bit for bit."""
+    from mla_amd import hip
+    eps = 1e-5
+    x = bfr(T, K, seed=61).to(dev)
+    g = (1.0 + 0.2 * torch.randn(K, generator=torch.Generator().manual_seed(6))).to(BF).to(dev)
+    w = bfr(2 * I, K, seed=62, scale=0.2).to(dev)
+    xg, _ = hip.rmsnorm_prep(x, g, eps)
+    ss = ((x.float() ** 2).view(T, 2, K // 2).sum(-1)).contiguous()
+    gu, act, actT, rstd = hip.gemm_gateup_swiglu(xg, w, True, norm=(ss, None, eps))
+    acc = hip.gemm(xg, w, out_dtype=torch.float32)
+    ref_gu = (acc * rstd[:, None]).to(BF)
+    ref_act, ref_actT = hip.swiglu_fwd_dual(ref_gu)
+    assert torch.equal(gu, ref_gu) and torch.equal(act, ref_act) and torch.equal(actT, ref_actT)
+    gu2, act2, none, rstd2 = hip.gemm_gateup_swiglu(xg, w, False, norm=(None, rstd, eps))
+    assert none is None and rstd2 is rstd and torch.equal(gu2, ref_gu) and torch.equal(act2, ref_act)
+
+
+def _packed(p32, dev, requires_grad=True):
+    """The nine weights of a layer as views of one flat bf16 buffer (the FlatUnit layout: q|k|v and gate|up back to back, which is what
+    the fused kernels take). Returns (list of views in NAMES order, the flat leaf, {name: (offset, shape)})."""
+    offs, n = {}, 0
+    for name in NAMES:
+        offs[name] = (n, tuple(p32[name].shape))
+        n += p32[name].numel()
+    flat = torch.empty(n, dtype=BF, device=dev)
+    for name in NAMES:
+        o, shp = offs[name]
+        flat[o:o + p32[name].numel()] = p32[name].to(BF).to(dev).reshape(-1)
+    flat.requires_grad_(requires_grad)
+    views = [flat[offs[name][0]:offs[name][0] + p32[name].numel()].view(offs[name][1]) for name in NAMES]
+    return views, flat, offs
+
+
+def _grad_of(flat, offs, name):
+    o, shp = offs[name]
+    n = 1
+    for d in shp:
+        n *= d
+    return flat.grad[o:o + n].view(shp)
+
+
+def _layer_params(H, I, seed_scale=None):
+    shapes = [(H,), (H, H), (H, H), (H, H), (H, H), (H,), (I, H), (I, H), (H, I)]
+    if seed_scale is None:
+        return {n: recipe.det_weight("layer." + n, s).to(BF).float() for n, s in zip(NAMES, shapes)}
+    g = torch.Generator().manual_seed(seed_scale)
+    return {n: ((torch.ones(s) + 0.1 * torch.randn(s, generator=g)) if len(s) == 1 else 0.02 * torch.randn(s, generator=g)).to(BF).float()
+            for n, s in zip(NAMES, shapes)}
+
+
+@pytest.mark.parametrize("lens", [None, [100, 37, 64], "pad"])
+def test_folded_decoder_layer_against_the_oracle_and_across_save_levels(dev, lens):
+    """One decoder layer with both norms folded (T = 300 rows: inside the fused kernels' contracts; "pad": 321 rows -> zero rows appended
+    to 384) vs the fp32 oracle within the bounds of test_decoder_layer_fwd_bwd, and bit-identical outputs / gradients across save levels
+    2, 1, 3 and 0 (the checkpointed layer recomputes with the row scale its forward used)."""
+    from mla_amd import ops
+    H, I, nh, B, S = 256, 512, 2, 3, 100
+    if lens == "pad":
+        B, S, lens = 3, 107, None
+    p32 = _layer_params(H, I)
+    x = recipe.det_randn("x", (B, S, H), 1.0).to(BF)
+    dy = recipe.det_randn("dy", (B, S, H), 1.0).to(BF)
+    seqlens = torch.tensor(lens) if lens else None
+    cos, sin = O.rope_tables(S, H // nh)
+    xr = x.float().requires_grad_(True)
+    pr = {n: v.clone().requires_grad_(True) for n, v in p32.items()}
+    ref = O.decoder_layer(xr, pr, cos, sin, nh, 1e-5, seqlens)
+    ref.backward(dy.float())
+    valid = torch.ones(B, S, dtype=torch.bool) if seqlens is None else torch.arange(S)[None] < seqlens[:, None]
+    sl = seqlens.to(dev).int() if seqlens is not None else None
+    results = {}
+    for lvl in (2, 1, 3, 0):
+        xd = x.to(dev).requires_grad_(True)
+        wd, flat, offs = _packed(p32, dev)
+        io = ops.NormFoldIO()
+        out = ops.decoder_layer(xd, sl, cos.to(dev), sin.to(dev), nh, 1e-5, lvl, wd, fold_io=io)
+        assert out.grad_fn.folded, "the folded path did not run"
+        out.backward(dy.to(dev))
+        results[lvl] = (out.detach(), xd.grad, flat.grad)
+        assert fro_rel(out[valid.to(dev)], ref[valid]) < 1e-2
+        assert fro_rel(xd.grad[valid.to(dev)], xr.grad[valid]) < 2e-2
+        for n in NAMES:
+            assert fro_rel(_grad_of(flat, offs, n), pr[n].grad) < 2e-2, n
+    for lvl in (1, 3, 0):
+        assert torch.equal(results[lvl][0], results[2][0]) and torch.equal(results[lvl][1], results[2][1]), lvl
+        assert torch.equal(results[lvl][2], results[2][2]), lvl
+    # and next to the separate-launch layer: same mathematics, roundings in other places
+    xd = x.to(dev).requires_grad_(True)
+    wd, flat, offs = _packed(p32, dev)
+    plain = ops.decoder_layer(xd, sl, cos.to(dev), sin.to(dev), nh, 1e-5, 1, wd)
+    assert not plain.grad_fn.folded
+    assert fro_rel(results[1][0][valid.to(dev)], plain[valid.to(dev)]) < 8e-3
+
+
+def test_hand_over_between_layers(dev):
+    """Layer i's down projection prepares layer i + 1's input norm (x * g and the partials of sum(x^2) leave with the rows): what the
+    next layer receives equals what mla_rmsnorm_prep makes from the rows, and a two-layer stack with the hand-over agrees with the same
+    stack where every layer prepares its own input (rstd differs in the last bit: other summation order)."""
+    from mla_amd import hip, ops
+    H, I, nh, B, S = 256, 512, 2, 3, 128
+    p1, p2 = _layer_params(H, I), _layer_params(H, I, seed_scale=11)
+    x = recipe.det_randn("x", (B, S, H), 1.0).to(BF).to(dev)
+    cos, sin = O.rope_tables(S, H // nh)
+    cos, sin = cos.to(dev), sin.to(dev)
+    w1 = _packed(p1, dev, requires_grad=False)[0]
+    w2 = _packed(p2, dev, requires_grad=False)[0]
+    with torch.no_grad():
+        io1 = ops.NormFoldIO(next_ln=w2[0])
+        h1 = ops.decoder_layer(x, None, cos, sin, nh, 1e-5, 1, w1, fold_io=io1)
+        assert io1.out is not None and io1.out[0] == h1.data_ptr() and io1.out[1] is w2[0]
+        xg, ss = io1.out[2], io1.out[3]
+        xg_ref, rstd_ref = hip.rmsnorm_prep(h1.view(-1, H), w2[0], 1e-5)
+        assert torch.equal(xg, xg_ref)
+        assert float(((rstd_of(ss, H, 1e-5) - rstd_ref).abs() / rstd_ref).max()) < 1e-6
+        io2 = ops.NormFoldIO(pre=io1.out)
+        a = ops.decoder_layer(h1, None, cos, sin, nh, 1e-5, 1, w2, fold_io=io2)
+        b = ops.decoder_layer(h1, None, cos, sin, nh, 1e-5, 1, w2, fold_io=ops.NormFoldIO())
+        assert fro_rel(a, b) < 1e-3
+        # a hand-over made for other rows or another weight is ignored, not trusted
+        stale = ops.NormFoldIO(pre=(h1.data_ptr() + 16, w2[0], xg, ss))
+        c = ops.decoder_layer(h1, None, cos, sin, nh, 1e-5, 1, w2, fold_io=stale)
+        assert torch.equal(c, b)
+
+
+def test_llama_stack_folds_by_default_and_matches_the_separate_norms(dev):
+    """LlamaModel.forward hands each layer's output to the next with the folded norm prepared (default on; MLA_NORM_FOLD=0 / set_norm_fold
+    restore the separate rmsnorm launches): same loss and gradients within bf16 noise, run-to-run bit-identical."""
+    from mla_amd import ops
+    from mla_amd.llama import LlamaConfig, LlamaModel
+    cfg = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=2,
+                      rms_norm_eps=1e-5, activation_save_level=1)
+    torch.manual_seed(3)
+    m = LlamaModel(cfg).to(dev).to(BF)
+    for layer in m.layers:        # the FlatUnit layout: the layer's parameters as views of one flat buffer, q|k|v and gate|up back to back
+        ps = list(layer._weights())
+        flat = torch.empty(sum(p.numel() for p in ps), dtype=BF, device=dev)
+        o = 0
+        for p in ps:
+            flat[o:o + p.numel()] = p.data.reshape(-1)
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+    emb = recipe.det_randn("emb", (3, 128, 256), 1.0).to(BF).to(dev)
+    mask = torch.ones(3, 128, dtype=torch.int64, device=dev)
+    mask[1, 90:] = 0
+    dy = recipe.det_randn("dy", (3, 128, 256), 1.0).to(dev)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        x = emb.clone().requires_grad_(True)
+        out, _ = m(inputs_embeds=x, attention_mask=mask)
+        (out.float() * mask[..., None] * dy).sum().backward()     # (a sum of squares of normalised rows would have a vanishing gradient)
+        return out.detach(), x.grad
+
+    assert ops.norm_fold_enabled()
+    a = run()
+    a2 = run()
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+    prev = ops.set_norm_fold(False)
+    try:
+        b = run()
+    finally:
+        ops.set_norm_fold(prev)
+    v = mask.bool()
+    assert fro_rel(a[0][v], b[0][v]) < 1.5e-2 and fro_rel(a[1][v], b[1][v]) < 3e-2
+
+
+def test_folded_decoder_layer_at_7b_dimensions(dev):
+    """The folded layer at the benchmark's true dimensions under the SURVEY 8c(ii) yardstick ALONE: err(hip, fp32 oracle) <= 2 x
+    err(reference-style bf16 autocast, fp32 oracle) on the output, the input gradient and every weight gradient -- the bound the
+    separate-launch layer is held to (test_model_gpu.py: test_decoder_layer_at_7b_dimensions); the hand-over for the next layer is made
+    by the down projection (K = 11008, split-K tail) and checked against mla_rmsnorm_prep."""
+    from mla_amd import hip, ops
+    H, I, nh, B, S = 4096, 11008, 32, 2, 548
+    p32 = _layer_params(H, I, seed_scale=7)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, S, H, generator=g).to(BF)
+    dy = torch.randn(B, S, H, generator=g).to(BF)
+    seqlens = torch.tensor([S, 500])
+    cos, sin = O.rope_tables(S, H // nh)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    xr = x.float().requires_grad_(True)
+    pr = {n: v.clone().requires_grad_(True) for n, v in p32.items()}
+    ref = O.decoder_layer(xr, pr, cos, sin, nh, 1e-5, seqlens)
+    ref.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    wd, flat, offs = _packed(p32, dev)
+    next_ln = (1.0 + 0.1 * torch.randn(H, generator=g)).to(BF).to(dev)
+    io = ops.NormFoldIO(next_ln=next_ln)
+    out = ops.decoder_layer(xd, seqlens.to(dev).int(), cos.to(dev), sin.to(dev), nh, 1e-5, 1, wd, fold_io=io)
+    assert out.grad_fn.folded and io.out is not None
+    out.backward(dy.to(dev))
+    xg_ref, rstd_ref = hip.rmsnorm_prep(out.detach().view(-1, H), next_ln, 1e-5)
+    # rows are padded to a multiple of 64 inside the layer: the hand-over covers the padded rows too
+    assert torch.equal(io.out[2][:B * S], xg_ref)
+    assert float(((rstd_of(io.out[3][:B * S], H, 1e-5) - rstd_ref).abs() / rstd_ref).max()) < 1e-6
+    valid = torch.arange(S)[None] < seqlens[:, None]
+    xc = x.clone().requires_grad_(True)
+    pc = {n: v.to(BF).requires_grad_(True) for n, v in p32.items()}
+    with torch.autocast("cpu", dtype=BF):
+        refc = O.decoder_layer(xc, pc, cos, sin, nh, 1e-5, seqlens)
+    refc.backward(dy)
+    errs = {"out": fro_rel(out[valid.to(dev)], ref[valid]), "dx": fro_rel(xd.grad[valid.to(dev)], xr.grad[valid])}
+    errc = {"out": fro_rel(refc[valid], ref[valid]), "dx": fro_rel(xc.grad[valid], xr.grad[valid])}
+    for n in NAMES:
+        errs[n] = fro_rel(_grad_of(flat, offs, n), pr[n].grad)
+        errc[n] = fro_rel(pc[n].grad, pr[n].grad)
+    line = ("FOLDED decoder layer @7B dims, Frobenius-relative error vs the fp32 oracle, hip | reference-style bf16 autocast (mode C): " +
+            ", ".join(f"{k} {errs[k]:.2e} | {errc[k]:.2e}" for k in errs))
+    print(line)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_folded_layer_7b.txt", "w") as f:
+        f.write(line + "\n")
+    for k in errs:
+        assert errs[k] <= 2.0 * errc[k], (k, errs[k], errc[k])

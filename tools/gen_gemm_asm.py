@@ -562,8 +562,16 @@ class CfgK64(Cfg):
     # right here: emode 0 = bf16 image [256][256] (row pitch 512 B, 16-B chunk ^ (row & 31)), emode 1 = fp32 image of accumulator rows
     # ri = 0..3 ([128][256], row pitch 1 KiB, chunk ^ (row & 63)); the second half (ri = 4..7) is written by the separate statement
     # image_f32(1) after the C++ side has consumed the first. %[vImg] = the lane's address of fragment (0, 0) in the image of the mode.
-    def image_bf16(self):
-        ln = ["; ---- bf16 tile image", "v_mov_b32 v0, %[vImg]", "v_xor_b32 v1, 32, v0", "v_add_u32 v2, 0x10000, v0", "v_add_u32 v3, 0x10000, v1"]
+    def image_bf16(self, rowscale=False):
+        ln = ["; ---- bf16 tile image" + (" with a per-row scale" if rowscale else ""), "v_mov_b32 v0, %[vImg]", "v_xor_b32 v1, 32, v0",
+              "v_add_u32 v2, 0x10000, v0", "v_add_u32 v3, 0x10000, v1"]
+        if rowscale:
+            # emode 2 (RMSNorm folded into the projection, gemm_args.h rs_*): the kernel left rstd of the tile's 256 rows as floats at LDS
+            # byte 0x20000 (behind the operand ring) before the loop; this lane's accumulator row ri is tile row
+            # (ri >> 2) * 128 + (ri & 3) * 16 + (wr * 64 + li), and wr * 64 + li = vImg >> 9 in the bf16 image's addressing
+            ln += ["v_lshrrev_b32 v20, 9, v0", "v_lshlrev_b32 v20, 2, v20", "v_add_u32 v20, 0x20000, v20"]
+            ln += [f"ds_read_b32 v{21 + ri}, v20 offset:{((ri >> 2) * 128 + (ri & 3) * 16) * 4}" for ri in range(self.FI)]
+            ln += ["s_waitcnt lgkmcnt(0)"]
         k = 0
         for ri in range(self.FI):
             for ci in range(self.FJ):
@@ -573,7 +581,8 @@ class CfgK64(Cfg):
                 base = (ci & 1) + 2 * (ri >> 2)
                 off = (ri & 3) * 16 * 512 + (((ci >> 1) ^ (ri & 1)) << 8)
                 ln += [f"v_accvgpr_read_b32 v{t + r}, a{a + r}" for r in range(4)]
-                ln += [f"v_mul_f32 v{t + r}, %[alpha], v{t + r}" for r in range(4)]
+                scale = f"v{21 + ri}" if rowscale else "%[alpha]"
+                ln += [f"v_mul_f32 v{t + r}, {scale}, v{t + r}" for r in range(4)]
                 ln += [f"v_cvt_pk_bf16_f32 v{t}, v{t}, v{t + 1}", f"v_cvt_pk_bf16_f32 v{t + 1}, v{t + 2}, v{t + 3}",
                        f"ds_write_b64 v{base}, v[{t}:{t + 1}] offset:{off}"]
         return ln
@@ -598,7 +607,8 @@ class CfgK64(Cfg):
         assert (self.FI, self.FJ) == (8, 4)
         return (["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_barrier", "v_readfirstlane_b32 s53, %[emode]", "s_cmp_eq_u32 s53, 0",
                  "s_cbranch_scc0 2f"]
-                + self.image_bf16() + ["s_branch 3f", "2:"] + self.image_f32(0) + ["3:", "s_waitcnt lgkmcnt(0)"])
+                + self.image_bf16() + ["s_branch 3f", "2:", "s_cmp_eq_u32 s53, 1", "s_cbranch_scc0 4f"] + self.image_f32(0)
+                + ["s_branch 3f", "4:"] + self.image_bf16(rowscale=True) + ["3:", "s_waitcnt lgkmcnt(0)"])
 
     def emit_lines(self, fname, lines):
         with open(os.path.join(CSRC, fname), "w") as f:
