@@ -37,10 +37,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// sum over the 32 lanes of this lane's half of the wave (lanes 0..31 / 32..63), fixed butterfly order
-__device__ __forceinline__ float half_wave_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// sum over the 32 lanes of this lane's half of the wave (lanes 0..31 / 32..63) on the VALU's DPP path (no LDS crossbar round trips:
+// five dependent ds_bpermute per row cost the GEMM epilogue ~4 us per tile). The total is valid in the LAST lane of the half only
+// (lane 31 / 63); fixed order -> deterministic. row_shr:n = 0x110 + n, row_bcast:15 = 0x142 (rows 1 and 3 take lane 15 of rows 0 and 2).
+__device__ __forceinline__ float half_wave_sum_last(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, true));
+#endif
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {

@@ -781,8 +781,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { q += hv[j] * hv[j]; xg[j] = hv[j] * ngv[j]; }
                 MLA_ST16(p.nrm_xg + (size_t)m * p.ldc + n, pack8(xg));
-                q = half_wave_sum(q);            // the 32 lanes of this row (N % 256 == 0: all of them are inside the matrix)
-                if (ch == 0) p.nrm_ss[(size_t)m * num_n + pid_n] = q;
+                q = half_wave_sum_last(q);       // the 32 lanes of this row (N % 256 == 0: all of them are inside the matrix)
+                if (ch == 31) p.nrm_ss[(size_t)m * num_n + pid_n] = q;
               }
             }
           }

@@ -537,8 +537,13 @@ _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (t
 
 # RMSNorm folded into the projections (round 6, mla_hip.h: mla_gemm_res_norm / _qkv_rope_rs / _gateup_swiglu_rs): the stand-alone norm passes
 # of the decoder layer's FORWARD disappear -- the GEMM that produces the residual-stream rows leaves x * g and the partials of sum(x^2), the
-# projection applies rstd to its accumulator rows. MLA_NORM_FOLD=0 restores the separate rmsnorm_fwd launches (A/B switch).
-_NORM_FOLD = os.environ.get("MLA_NORM_FOLD", "1") != "0"
+# projection applies rstd to its accumulator rows. Opt-in: MLA_NORM_FOLD=1 (or set_norm_fold(True)).
+# Built, bit-exact against the plain kernels, closer to fp32 than the separate norm (7B layer: 0.63-0.71 x the reference's own bf16 error) --
+# and OFF by default: six alternating same-box pairs of the configs[1] step measured +2.4 ms (95 % CI [+1.2, +3.6]) WITH it
+# (profiles/r6_norm_fold_ab.txt). Per launch at T = 17 536: the norm pass it removes is 48.5 us (reads and writes at 5.9 TB/s); what it adds
+# is the x * g store inside the producers' epilogue bursts (+39 / +47 us, all 256 CUs storing at once) and the partials -> rstd prologue of
+# every consumer tile (+25 / +59 us); history/round_6.md section 9.
+_NORM_FOLD = os.environ.get("MLA_NORM_FOLD", "0") != "0"
 
 
 def norm_fold_enabled() -> bool:

@@ -230,9 +230,11 @@ def test_hand_over_between_layers(dev):
         assert torch.equal(c, b)
 
 
-def test_llama_stack_folds_by_default_and_matches_the_separate_norms(dev):
-    """LlamaModel.forward hands each layer's output to the next with the folded norm prepared (default on; MLA_NORM_FOLD=0 / set_norm_fold
-    restore the separate rmsnorm launches): same loss and gradients within bf16 noise, run-to-run bit-identical."""
+def test_llama_stack_with_folded_norms_matches_the_separate_norms(dev):
+    """LlamaModel.forward hands each layer's output to the next with the folded norm prepared (opt-in: MLA_NORM_FOLD=1 / set_norm_fold;
+    measured slower than the separate rmsnorm launches, profiles/r6_norm_fold_ab.txt): same loss and gradients within bf16 noise,
+    run-to-run bit-identical."""
+    from mla_amd import hip as hip_mod
     from mla_amd import ops
     from mla_amd.llama import LlamaConfig, LlamaModel
     cfg = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=2,
@@ -260,12 +262,17 @@ def test_llama_stack_folds_by_default_and_matches_the_separate_norms(dev):
         (out.float() * mask[..., None] * dy).sum().backward()     # (a sum of squares of normalised rows would have a vanishing gradient)
         return out.detach(), x.grad
 
-    assert ops.norm_fold_enabled()
-    a = run()
-    a2 = run()
-    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
-    prev = ops.set_norm_fold(False)
+    prev = ops.set_norm_fold(True)
     try:
+        calls = []
+        orig = hip_mod.gemm_res_norm
+        hip_mod.gemm_res_norm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        a = run()
+        hip_mod.gemm_res_norm = orig
+        assert len(calls) == 2 * 4 - 1                 # o_proj of every layer + down_proj of every layer but the last
+        a2 = run()
+        assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+        ops.set_norm_fold(False)
         b = run()
     finally:
         ops.set_norm_fold(prev)
@@ -321,3 +328,49 @@ def test_folded_decoder_layer_at_7b_dimensions(dev):
         f.write(line + "\n")
     for k in errs:
         assert errs[k] <= 2.0 * errc[k], (k, errs[k], errc[k])
+
+
+def test_tiny_mla_step_with_folded_norms_against_the_reference_golden(dev):
+    """The whole tiny-MLA training step with the folded norms switched on (decoder-layer parameters in the FlatUnit layout) against the
+    reference golden: losses and the strict per-parameter yardstick err(hip, A) <= 2 x err(C, A) on all 116 gradients -- the bounds of
+    test_mla_e2e_against_reference_golden."""
+    import numpy as np
+    import test_model_gpu as tm
+    from mla_amd import hip as hip_mod
+    from mla_amd import ops
+    from parity_util import grad_sample_rows, strict_violations
+    e2e = np.load(os.path.join(tm.G, "mla_tiny_e2e.npz"), allow_pickle=True)
+    orig_build = tm.build_tiny_mla
+
+    def build_packed(dev_, save_level=2):
+        m = orig_build(dev_, save_level)
+        for layer in m.vlm.llm_backbone.llm.model.layers:
+            ps = list(layer._weights())
+            flat = torch.empty(sum(p.numel() for p in ps), dtype=BF, device=dev_)
+            o = 0
+            for p in ps:
+                flat[o:o + p.numel()] = p.data.reshape(-1)
+                p.data = flat[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+        return m
+
+    calls = []
+    orig = hip_mod.gemm_res_norm
+    prev = ops.set_norm_fold(True)
+    tm.build_tiny_mla = build_packed
+    hip_mod.gemm_res_norm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        m, ld, out = tm._run_hip_e2e(dev)
+    finally:
+        hip_mod.gemm_res_norm = orig
+        tm.build_tiny_mla = orig_build
+        ops.set_norm_fold(prev)
+    assert len(calls) == 2 * 9 - 1, len(calls)          # the folded path ran in all nine layers
+    for got, a, c in ((ld["total_loss"], "A_total_loss", "C_total_loss"), (ld["img_pc_contrastive_loss"], "A_contrastive", "C_contrastive"),
+                      (out.loss, "A_llm_loss", "C_llm_loss")):
+        A, C = float(e2e[a]), float(e2e[c])
+        assert abs(float(got) - A) <= 2 * abs(C - A), (a, float(got), A, C)
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    rows = grad_sample_rows(grads, e2e)
+    assert len(rows) == 116
+    assert not strict_violations(rows), strict_violations(rows)
