@@ -45,49 +45,76 @@ __global__ __launch_bounds__(256) void project_points_kernel(const float* __rest
 
 // ------------------------------------------------------------------------------------------------ FPS
 constexpr int FPS_MAXP = 8;  // points per thread (N <= 2048)
+// Farthest-point sampling (Point_PN.py:10-21 index arithmetic; the start index is drawn by the caller): one workgroup per cloud, the whole
+// loop on chip. A step is a latency chain -- new centre -> distance update -> arg-max over the cloud -> next centre -- so what counts is
+// the length of that chain, not throughput (32 workgroups on 256 CUs). Round 6: the lane's points live in registers (no LDS reads in the
+// update), the (distance, index) pair is ONE 64-bit key (distance bits << 32 | ~index: larger distance wins, then the LOWER index, exactly
+// the old two-field comparison), reduced inside a wave on the VALU's DPP path (row_shr 1/2/4/8, row_bcast 15/31: ~10 short-latency
+// moves instead of twelve dependent ds_bpermute round trips) and across the four waves through double-buffered LDS slots with ONE
+// barrier per step (two before). Same comparisons on the same values: indices identical to the previous kernel and to the reference.
+__device__ __forceinline__ unsigned long long fps_dpp_max(unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FPS_STEP(CTRL, ROWMASK)                                                                                          \
+  {                                                                                                                      \
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROWMASK, 0xf, true);            \
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROWMASK, 0xf, true);    \
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;                                                    \
+    v = o > v ? o : v;                                                                                                   \
+  }
+  FPS_STEP(0x111, 0xf) FPS_STEP(0x112, 0xf) FPS_STEP(0x114, 0xf) FPS_STEP(0x118, 0xf)      // row_shr 1, 2, 4, 8: lane 15 of a row = its max
+  FPS_STEP(0x142, 0xa)                                                                    // row_bcast:15 -> lanes 31 / 63
+  FPS_STEP(0x143, 0xc)                                                                    // row_bcast:31 -> lane 63 = the wave's max
+#undef FPS_STEP
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+#else
+  return v;
+#endif
+}
+
 __global__ __launch_bounds__(256) void fps_kernel(const float* __restrict__ xyz, const long long* __restrict__ start,
                                                   long long* __restrict__ out, int N, int npoint) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* pts = (float*)smem;                 // [N][3]
-  float* rv = pts + N * 3;                   // [4] per-wave best value
-  int* ri = (int*)(rv + 4);                  // [4] per-wave best index
+  float* pts = (float*)smem;                                            // [N][3]: the centre of a step is fetched from here
+  unsigned long long* slot = (unsigned long long*)(pts + ((N * 3 + 3) & ~3));   // [2][4]: per-wave best key, double-buffered
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* src = xyz + (size_t)b * N * 3;
   for (int e = tid; e < N * 3; e += 256) pts[e] = src[e];
-  float dist[FPS_MAXP];
-#pragma unroll
-  for (int i = 0; i < FPS_MAXP; ++i) dist[i] = 1e10f;
+  float dist[FPS_MAXP], px[FPS_MAXP], py[FPS_MAXP], pz[FPS_MAXP];
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < FPS_MAXP; ++i) {
+    const int p = tid + i * 256;
+    dist[i] = 1e10f;
+    px[i] = py[i] = pz[i] = 0.f;
+    if (p < N) { px[i] = pts[p * 3]; py[i] = pts[p * 3 + 1]; pz[i] = pts[p * 3 + 2]; }
+  }
   int far = (int)start[b];
   for (int it = 0; it < npoint; ++it) {
     if (tid == 0) out[(size_t)b * npoint + it] = far;
     const float cx = pts[far * 3], cy = pts[far * 3 + 1], cz = pts[far * 3 + 2];
-    float bv = -1.f;
-    int bi = 0x7fffffff;
+    unsigned long long key = 0ull;               // below every real key (distances are >= 0, ~index < 2^32 - 1 only for index > 0 ... and
+                                                 // a real key with distance 0 and index 0 is 0x00000000ffffffff > 0)
 #pragma unroll
     for (int i = 0; i < FPS_MAXP; ++i) {
       const int p = tid + i * 256;
       if (p < N) {
-        const float dx = __fsub_rn(pts[p * 3], cx), dy = __fsub_rn(pts[p * 3 + 1], cy), dz = __fsub_rn(pts[p * 3 + 2], cz);
+        const float dx = __fsub_rn(px[i], cx), dy = __fsub_rn(py[i], cy), dz = __fsub_rn(pz[i], cz);
         const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
         if (d < dist[i]) dist[i] = d;
-        if (dist[i] > bv) { bv = dist[i]; bi = p; }  // ascending p: first (lowest) index wins ties
+        // non-negative floats order like their bit patterns; ~p makes the LOWER index the larger key among equal distances
+        const unsigned long long k = ((unsigned long long)__float_as_uint(dist[i]) << 32) | (unsigned)(~(unsigned)p);
+        key = k > key ? k : key;
       }
     }
+    key = fps_dpp_max(key);
+    if (lane == 0) slot[(it & 1) * 4 + wid] = key;
+    __syncthreads();      // one barrier per step: the other buffer is rewritten only after everybody has passed THIS barrier
+    const unsigned long long* sl = slot + (it & 1) * 4;
+    unsigned long long best = sl[0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    __syncthreads();  // previous iteration's rv/ri fully consumed
-    if (lane == 0) { rv[wid] = bv; ri[wid] = bi; }
-    __syncthreads();
-    bv = rv[0]; bi = ri[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-      if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
-    far = bi;
+    for (int w = 1; w < 4; ++w) best = sl[w] > best ? sl[w] : best;
+    far = (int)(~(unsigned)best);
   }
 }
 
@@ -349,7 +376,20 @@ __global__ __launch_bounds__(256) void colstats_partial_vec_kernel(const bf16_t*
   float a[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) a[j] = q[j] = 0.f;
-  for (long long r = r0 + rl; r < r1; r += RL) {
+  long long r = r0 + rl;
+  for (; r + 3LL * RL < r1; r += 4LL * RL) {         // four rows in flight per lane (round 6: one was latency-bound); same order of adds
+    u32x4_t w4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w4[u] = *(const u32x4_t*)(x + (r + (long long)u * RL) * ld + cg * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+      unpack8(w4[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a[j] += v[j]; q[j] += v[j] * v[j]; }
+    }
+  }
+  for (; r < r1; r += RL) {
     float v[8];
     unpack8(*(const u32x4_t*)(x + r * ld + cg * 8), v);
 #pragma unroll
@@ -395,10 +435,55 @@ __global__ __launch_bounds__(256) void colstats_final_kernel(const float* __rest
   }
 }
 // y = (x - mean) * rsqrt(var + eps) * w + b (+ residual) (relu)
+// Round 6: lane = (row lane, 8-channel chunk) with blockDim = RL * C/8 like colstats_partial_vec_kernel, so a lane keeps ITS eight
+// columns' mean / 1/sqrt(var + eps) / w / b in registers for all its rows (the flat grid-stride form recomputed a divide and a square root
+// and issued four scalar loads per ELEMENT: 185 us per launch at 2.2 TB/s); two rows in flight per lane. Same expression per element.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ var, const bf16_t* __restrict__ w,
                                                        const bf16_t* __restrict__ b, const bf16_t* __restrict__ res,
                                                        bf16_t* __restrict__ y, long long rows, int C, float eps, int relu) {
+  const int cpr = C >> 3, RL = blockDim.x / cpr;
+  const int cg = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  const int c0 = cg * 8;
+  float mu[8], rs[8], wv[8], bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = mean[c0 + j];
+    rs[j] = 1.0f / sqrtf(var[c0 + j] + eps);
+    wv[j] = bf2f(w[c0 + j]);
+    bv[j] = bf2f(b[c0 + j]);
+  }
+  auto one = [&](long long r, const u32x4_t xv, const u32x4_t rv) {
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t wd = xv[j >> 1], rd = rv[j >> 1];
+      const float v = (j & 1) ? bfhi(wd) : bflo(wd);
+      const float rr = (j & 1) ? bfhi(rd) : bflo(rd);
+      float t = (v - mu[j]) * rs[j] * wv[j] + bv[j] + rr;
+      if (relu) t = t > 0.f ? t : 0.f;
+      o[j] = t;
+    }
+    u32x4_t ov;
+    ov[0] = pack2bf(o[0], o[1]); ov[1] = pack2bf(o[2], o[3]); ov[2] = pack2bf(o[4], o[5]); ov[3] = pack2bf(o[6], o[7]);
+    *(u32x4_t*)(y + r * C + c0) = ov;
+  };
+  const long long step = (long long)gridDim.x * RL;
+  long long r = (long long)blockIdx.x * RL + rl;
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+  for (; r + step < rows; r += 2 * step) {
+    const u32x4_t x0 = *(const u32x4_t*)(x + r * C + c0), x1 = *(const u32x4_t*)(x + (r + step) * C + c0);
+    const u32x4_t r0 = res ? *(const u32x4_t*)(res + r * C + c0) : z, r1 = res ? *(const u32x4_t*)(res + (r + step) * C + c0) : z;
+    one(r, x0, r0);
+    one(r + step, x1, r1);
+  }
+  if (r < rows) one(r, *(const u32x4_t*)(x + r * C + c0), res ? *(const u32x4_t*)(res + r * C + c0) : z);
+}
+// generic form (C / 8 > 256): flat grid-stride over 8-channel pieces
+__global__ __launch_bounds__(256) void bn_apply_flat_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b, const bf16_t* __restrict__ res,
+                                                            bf16_t* __restrict__ y, long long rows, int C, float eps, int relu) {
   const int cpr = C >> 3;
   const long long total = rows * cpr;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -435,6 +520,41 @@ __global__ __launch_bounds__(256) void maxpool_k_kernel(const bf16_t* __restrict
     out[idx] = f2bf(m);
   }
 }
+// same, 8 channels per lane from 16-B loads with four neighbours in flight (round 6: the scalar form moved 2 B per lane per load,
+// 250 us per launch); max is exact in any order, so the result is the same bf16 value. C % 8 == 0, 16-B aligned.
+__global__ __launch_bounds__(256) void maxpool_k_vec_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long long groups,
+                                                            int K, int C) {
+  const int cpr = C >> 3;
+  const long long total = groups * cpr;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long g = idx / cpr;
+    const int c0 = (int)(idx % cpr) * 8;
+    const bf16_t* base = x + g * K * C + c0;
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    int k = 0;
+    for (; k + 3 < K; k += 4) {
+      u32x4_t w4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w4[u] = *(const u32x4_t*)(base + (size_t)(k + u) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack8(w4[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+      }
+    }
+    for (; k < K; ++k) {
+      float v[8];
+      unpack8(*(const u32x4_t*)(base + (size_t)k * C), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+    }
+    *(u32x4_t*)(out + g * C + c0) = pack8(m);
+  }
+}
 // gather rows: out[i][:] = src[idx[i]][:] (fp32, 3 wide or any width)
 __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, const long long* __restrict__ idx,
                                                               float* __restrict__ out, int B, int N, int G, int W) {
@@ -464,7 +584,7 @@ extern "C" int mla_project_points(const float* xyz, const float* consts21, long 
 
 extern "C" int mla_fps(const float* xyz, const long long* start, long long* out, int B, int N, int npoint, hipStream_t stream) {
   MLA_CHECK_ARG(xyz && start && out && B > 0 && N > 0 && N <= 2048 && npoint > 0 && npoint <= N, "mla_fps: need N <= 2048");
-  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(256), N * 3 * sizeof(float) + 64, stream, xyz, start, out, N, npoint);
+  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(256), ((N * 3 + 3) & ~3) * sizeof(float) + 64, stream, xyz, start, out, N, npoint);
   MLA_LAUNCH_CHECK();
 }
 
@@ -515,14 +635,26 @@ extern "C" int mla_colstats_bf16(const void* x, float* mean, float* var, long lo
 extern "C" int mla_bn_apply(const void* x, const float* mean, const float* var, const void* w, const void* b, const void* res,
                             void* y, long long rows, int C, float eps, int relu, hipStream_t stream) {
   MLA_CHECK_ARG(x && mean && var && w && b && y && C % 8 == 0, "mla_bn_apply: bad args (C %% 8)");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(gridn(rows * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, mean, var,
-                     (const bf16_t*)w, (const bf16_t*)b, (const bf16_t*)res, (bf16_t*)y, rows, C, eps, relu);
+  const int cpr = C / 8;
+  if (cpr <= 256 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) == 0) {
+    const int RL = 256 / cpr;
+    long long nb = (rows + RL - 1) / RL;
+    if (nb > 4096) nb = 4096;          // 16 workgroups per CU's worth of row walkers; every lane keeps its columns' constants
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((int)nb), dim3(RL * cpr), 0, stream, (const bf16_t*)x, mean, var, (const bf16_t*)w,
+                       (const bf16_t*)b, (const bf16_t*)res, (bf16_t*)y, rows, C, eps, relu);
+  } else {
+    hipLaunchKernelGGL(bn_apply_flat_kernel, dim3(gridn(rows * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, mean, var,
+                       (const bf16_t*)w, (const bf16_t*)b, (const bf16_t*)res, (bf16_t*)y, rows, C, eps, relu);
+  }
   MLA_LAUNCH_CHECK();
 }
 
 extern "C" int mla_maxpool_k(const void* x, void* out, long long groups, int K, int C, hipStream_t stream) {
   MLA_CHECK_ARG(x && out, "mla_maxpool_k: null pointer");
-  hipLaunchKernelGGL(maxpool_k_kernel, dim3(gridn(groups * C)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, groups, K, C);
+  if (C % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0)
+    hipLaunchKernelGGL(maxpool_k_vec_kernel, dim3(gridn(groups * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, groups, K, C);
+  else
+    hipLaunchKernelGGL(maxpool_k_kernel, dim3(gridn(groups * C)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, groups, K, C);
   MLA_LAUNCH_CHECK();
 }
 
