@@ -53,7 +53,19 @@ batch, draws = recipe.make_batch(R=2)
 m.vlm.vision_tower_3d.fps_starts_override = [draws["fps_start0"], draws["fps_start1"]]
 orig = m.forward
 m.forward = lambda **kw: orig(**kw, noise=draws["noise"].to(dev), timestep=draws["timestep"].to(dev))
-calls = dict(rs=0, ag=0, ar=0)
+calls = dict(rs=0, ag=0, ar=0, res_norm=0, gather_wait=0)
+from mla_amd import hip as _hip
+_orig_res_norm = _hip.gemm_res_norm
+def _spy_res_norm(*a, **k):
+    calls["res_norm"] += 1
+    return _orig_res_norm(*a, **k)
+_hip.gemm_res_norm = _spy_res_norm
+for _layer in m.vlm.llm_backbone.llm.model.layers:
+    if _layer._gather_wait is not None:
+        def _gw(_inner=_layer._gather_wait):
+            calls["gather_wait"] += 1
+            return _inner()
+        _layer._gather_wait = _gw
 if use_pg:
     for name, key in (("reduce_scatter_tensor", "rs"), ("all_gather_into_tensor", "ag"), ("all_reduce", "ar")):
         inner = getattr(dist, name)
@@ -110,6 +122,25 @@ def test_rccl_world1_forced_collectives_match_collective_free_path_bit_for_bit(d
             bad = [k for k in plain[kind] if not torch.equal(got[kind][k], plain[kind][k])]
             assert not bad, (tag, kind, bad)
         print(f"{tag}: {n_units} trainable units, calls {got['calls']}, losses {got['losses']}, norms {got['norms']}")
+
+
+def test_folded_norms_through_the_sharded_path_match_the_collective_free_path(dev, tmp_path):
+    """MLA_NORM_FOLD=1 (RMSNorm folded into the projections, opt-in) through FSDPStrategy: in the sharded path layer i's down projection
+    reads layer i + 1's input_layernorm weight, so that unit's all-gather is waited for one layer early (`_gather_wait`). Masters, AdamW
+    moments and bf16 copies after two steps: bit-identical between the collective-free path and the forced-collectives RCCL path, the
+    folded GEMMs counted (o_proj of 9 layers + down_proj of 8, forward only, two steps), losses next to the separate-norm run's."""
+    fold = {"MLA_NORM_FOLD": "1"}
+    sep = _child({}, tmp_path / "sep.pt")
+    plain = _child(fold, tmp_path / "plain.pt")
+    got = _child(dict(fold, USE_PG="1", MLA_FORCE_COLLECTIVES="1"), tmp_path / "coll.pt")
+    assert sep["calls"]["res_norm"] == 0 and plain["calls"]["res_norm"] == 2 * 17 == got["calls"]["res_norm"], (sep["calls"], plain["calls"], got["calls"])
+    assert got["coll"] and got["backend"] == "nccl" and got["calls"]["gather_wait"] == 2 * 8, got["calls"]
+    assert got["losses"] == plain["losses"]
+    for a, b in zip(plain["losses"], sep["losses"]):
+        assert abs(a - b) <= 2e-2 * abs(b), (plain["losses"], sep["losses"])          # same mathematics, roundings in other places
+    for kind in ("master", "exp_avg", "exp_avg_sq", "flat16"):
+        bad = [k for k in plain[kind] if not torch.equal(got[kind][k], plain[kind][k])]
+        assert not bad, (kind, bad)
 
 
 RS = r"""
