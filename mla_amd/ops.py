@@ -533,6 +533,7 @@ _SWIGLU_FWD_EPILOGUE = os.environ.get("MLA_SWIGLU_FWD_EPILOGUE", "1") != "0"   #
 _SWIGLU_BWD_EPILOGUE = os.environ.get("MLA_SWIGLU_BWD_EPILOGUE", "1") != "0"   # A/B switch: 0 = d(act) GEMM + separate SwiGLU backward
 _ATTN_BWD_T = os.environ.get("MLA_ATTN_BWD_T", "1") != "0"           # dqkv^T / o^T written by the attention-backward kernels
 _SWIGLU_DUAL = os.environ.get("MLA_SWIGLU_DUAL", "1") != "0"     # A/B switch (tools): 0 = recompute act^T in the backward
+_RECOMPUTE_LEAN = os.environ.get("MLA_RECOMPUTE_LEAN", "1") != "0"   # A/B switch: 0 = a checkpointed layer recomputes its WHOLE forward (incl. the unused down projection)
 
 
 # RMSNorm folded into the projections (round 6, mla_hip.h: mla_gemm_res_norm / _qkv_rope_rs / _gateup_swiglu_rs): the stand-alone norm passes
@@ -621,7 +622,7 @@ class DecoderLayerFn(torch.autograd.Function):
                 wd.shape[1] % 64 == 0)
 
     @staticmethod
-    def _fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold):
+    def _fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold, need_out=True):
         """_fwd with both RMSNorms folded into the projections (mla_hip.h "RMSNorm folded into the projections"): no stand-alone norm
         pass; rstd1 / rstd2 come out of the QKV and gate|up launches. fold = NormFoldIO, or a saved rstd1 tensor (recomputation of a
         checkpointed layer: the same row scale as in the forward, whatever produced it there)."""
@@ -648,9 +649,11 @@ class DecoderLayerFn(torch.autograd.Function):
         o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
                               rows=T, groups=groups)
         h1, xg2, ss2 = hip.gemm_res_norm(o, wo, h2, ln2)
-        gu, act_, actT, rstd2 = hip.gemm_gateup_swiglu(xg2, wgu, save_t and T % 8 == 0, norm=(ss2, None, eps))
+        gu, act_, actT, rstd2 = hip.gemm_gateup_swiglu(xg2, wgu, save_t and T % 8 == 0, norm=(ss2, None, eps), want_act=need_out)
         del xg2, ss2
-        if io is not None and io.next_ln is not None and io.next_ln.data_ptr() % 16 == 0:
+        if not need_out:
+            out = None
+        elif io is not None and io.next_ln is not None and io.next_ln.data_ptr() % 16 == 0:
             out, xgn, ssn = hip.gemm_res_norm(act_, wd, h1, io.next_ln)
             io.out = (out.data_ptr(), io.next_ln, xgn, ssn)
         else:
@@ -658,12 +661,15 @@ class DecoderLayerFn(torch.autograd.Function):
         return out, (None, rstd1, qkv, o, lse, h1, None, rstd2, gu, act_, actT)
 
     @staticmethod
-    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False, groups=None, fold=None):
+    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False, groups=None, fold=None, need_out=True):
+        """need_out=False: the recomputation of a checkpointed layer inside its backward -- everything up to the SwiGLU product, NOT the
+        down projection (its output is the layer output, which the backward never reads; torch.utils.checkpoint, the reference's
+        fsdp.py:211-223, recomputes it anyway: 22 % of a layer's forward FLOPs)."""
         ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
         H = h2.shape[1]
         D = H // nheads
         if fold is not None:
-            return DecoderLayerFn._fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold)
+            return DecoderLayerFn._fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold, need_out)
         xn1, rstd1 = hip.rmsnorm_fwd(h2, ln1, eps)
         qkv = torch.empty((h2.shape[0], 3 * H), dtype=BF16, device=h2.device)
         wqkv = cat_view((wq, wk, wv))
@@ -688,7 +694,8 @@ class DecoderLayerFn(torch.autograd.Function):
         wgu = cat_view((wg, wu))
         # fused gate|up projection + SwiGLU: the product (and, with save_t, its transposed copy for the backward's wgrad) is formed in the
         # GEMM epilogue -- gu is written once and not read again in the forward pass
-        fused = hip.gemm_gateup_swiglu(xn2, wgu, save_t and h2.shape[0] % 8 == 0) if (wgu is not None and _SWIGLU_FWD_EPILOGUE) else None
+        fused = (hip.gemm_gateup_swiglu(xn2, wgu, save_t and h2.shape[0] % 8 == 0, want_act=need_out)
+                 if (wgu is not None and _SWIGLU_FWD_EPILOGUE) else None)
         if fused is not None:
             gu, act_, actT = fused
         else:
@@ -704,7 +711,7 @@ class DecoderLayerFn(torch.autograd.Function):
                 act_, actT = hip.swiglu_fwd_dual(gu)
             else:
                 act_, actT = hip.swiglu_fwd(gu), None
-        out = hip.gemm(act_, wd, residual=h1)
+        out = hip.gemm(act_, wd, residual=h1) if need_out else None
         return out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT)
 
     @staticmethod
@@ -773,8 +780,11 @@ class DecoderLayerFn(torch.autograd.Function):
                 h2, rstd1_f = ctx.saved_tensors
             else:
                 (h2,), rstd1_f = ctx.saved_tensors, None
-            _, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, _) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w,
-                                                                                            groups=ctx.groups, fold=rstd1_f)
+            # the recomputation stops in front of the down projection and asks the gate|up epilogue for the SwiGLU product in the
+            # layout the down-projection wgrad wants (round 6: was a full forward + a transpose pass over act)
+            want_t = ctx.needs_input_grad[8 + 8] and _SWIGLU_DUAL and _RECOMPUTE_LEAN
+            _, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT_saved) = DecoderLayerFn._fwd(
+                h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=want_t, groups=ctx.groups, fold=rstd1_f, need_out=not _RECOMPUTE_LEAN)
         need = ctx.needs_input_grad[8:]
         d2 = dout.reshape(T, H)
         if not d2.is_contiguous():
