@@ -86,7 +86,8 @@ int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, int N, int K
 /* fused gate|up projection + SwiGLU (LlamaMLP.forward modeling_llama.py:240): gu[M, 2I] = x[M, K] wgu[2I, K]^T (wgu = gate rows then up
  * rows), act[M, I] = silu(gate) * up and, if actT != NULL, actT[I, ldt] = act^T, all from one GEMM launch; bit-identical to
  * mla_gemm_bf16 followed by mla_swiglu_fwd_dual. M >= 256, I % 128 == 0, K % 64 == 0. act may be NULL when actT is given (the
- * recomputation of a checkpointed layer needs the product in the wgrad layout only). */
+ * recomputation of a checkpointed layer needs the product in the wgrad layout only), gu may be NULL when act is given (the forward of a
+ * checkpointed layer keeps nothing but its input). */
 int mla_gemm_gateup_swiglu(const void* x, const void* wgu, void* gu, void* act, void* actT, int M, int I, int K, int lda, int ldb,
                            long long ldt, mla_stream_t stream);
 /* fused down-projection dgrad + SwiGLU backward (autograd of LlamaMLP.forward modeling_llama.py:240): d(act) = dy[M, K] wT[I, K]^T is

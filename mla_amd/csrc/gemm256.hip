@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             const int idx = tid + 512 * k4;
             const int rl = idx >> 5, ch = idx & 31;
             const int row = s4 * 64 + rl, m = m0 + row;
-            if (m < p.M)
+            if (p.C && m < p.M)      // (null: the forward of a checkpointed layer keeps nothing but its input; gate|up is recomputed later)
               MLA_ST16((bf16_t*)p.C + (size_t)m * ld2 + (ch < 16 ? cbase + ch * 8 : I + cbase + (ch - 16) * 8), *(const u32x4_t*)(smem + row * 512 + ((ch ^ (row & 31)) << 4)));
           }
 #pragma unroll
@@ -1400,7 +1400,7 @@ extern "C" int mla_gemm_qkv_rope(const void* A, const void* B, void* C, int M, i
 // (optional) its transpose [I, ldt]. Replaces hip.gemm + mla_swiglu_fwd_dual (LlamaMLP.forward modeling_llama.py:240); bit-identical.
 extern "C" int mla_gemm_gateup_swiglu(const void* x, const void* wgu, void* gu, void* act, void* actT, int M, int I, int K, int lda,
                                       int ldb, long long ldt, hipStream_t stream) {
-  MLA_CHECK_ARG(x && wgu && gu && (act || actT), "mla_gemm_gateup_swiglu: null pointer (act may be NULL only when actT is given)");
+  MLA_CHECK_ARG(x && wgu && (act || actT) && (gu || act), "mla_gemm_gateup_swiglu: null pointer (act may be NULL only when actT is given, gu only when act is)");
   MLA_CHECK_ARG(M >= 256 && I >= 128 && I % 128 == 0 && K > 0 && K % 64 == 0, "mla_gemm_gateup_swiglu: needs M >= 256, I %% 128 == 0, K %% 64 == 0");
   MLA_CHECK_ARG(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0, "mla_gemm_gateup_swiglu: leading dimensions must be multiples of 8");
   MLA_CHECK_ARG(actT == nullptr || (M % 8 == 0 && ldt >= M && ldt % 8 == 0), "mla_gemm_gateup_swiglu: transposed output needs M %% 8 == 0, ldt >= M, ldt %% 8 == 0");
@@ -1483,7 +1483,7 @@ extern "C" int mla_gemm_qkv_rope_rs(const void* A, const void* B, void* C, int M
 // mla_gemm_gateup_swiglu on A = x * g with the row scale of the folded RMSNorm (see mla_gemm_qkv_rope_rs).
 extern "C" int mla_gemm_gateup_swiglu_rs(const void* x, const void* wgu, void* gu, void* act, void* actT, int M, int I, int K, int lda,
                                          int ldb, long long ldt, const float* ss, int parts, float eps, float* rstd, hipStream_t stream) {
-  MLA_CHECK_ARG(x && wgu && gu && (act || actT), "mla_gemm_gateup_swiglu_rs: null pointer (act may be NULL only when actT is given)");
+  MLA_CHECK_ARG(x && wgu && (act || actT) && (gu || act), "mla_gemm_gateup_swiglu_rs: null pointer (act may be NULL only when actT is given, gu only when act is)");
   MLA_CHECK_ARG(M >= 256 && I >= 128 && I % 128 == 0 && K > 0 && K % 64 == 0, "mla_gemm_gateup_swiglu_rs: needs M >= 256, I %% 128 == 0, K %% 64 == 0");
   MLA_CHECK_ARG(lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0, "mla_gemm_gateup_swiglu_rs: leading dimensions must be multiples of 8");
   MLA_CHECK_ARG(actT == nullptr || (M % 8 == 0 && ldt >= M && ldt % 8 == 0), "mla_gemm_gateup_swiglu_rs: transposed output needs M %% 8 == 0, ldt >= M, ldt %% 8 == 0");

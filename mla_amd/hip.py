@@ -379,7 +379,7 @@ def gateup_swiglu_ok(x2d, wgu, want_t) -> bool:
             (not want_t or T % 8 == 0) and all(t.data_ptr() % 16 == 0 for t in (x2d, wgu)))
 
 
-def gemm_gateup_swiglu(x2d, wgu, want_t, norm=None, want_act=True):
+def gemm_gateup_swiglu(x2d, wgu, want_t, norm=None, want_act=True, want_gu=True):
     """(gu [T, 2I], act [T, I], actT [I, T] or None) from ONE launch: the SwiGLU product is formed in the gate|up GEMM's epilogue.
     None when the shape is outside the fused kernel's contract (the caller then runs gemm + swiglu_fwd[_dual]).
     norm = (ss, rstd, eps): x2d is x * g of a folded RMSNorm (mla_gemm_gateup_swiglu_rs); rstd [T] is appended to the result."""
@@ -390,8 +390,8 @@ def gemm_gateup_swiglu(x2d, wgu, want_t, norm=None, want_act=True):
         return None
     _req(x2d, torch.bfloat16, "gemm_gateup_swiglu x")
     _req(wgu, torch.bfloat16, "gemm_gateup_swiglu w")
-    gu = torch.empty((T, 2 * I), dtype=torch.bfloat16, device=x2d.device)
     act = torch.empty((T, I), dtype=torch.bfloat16, device=x2d.device) if (want_act or not want_t) else None   # want_act=False: act^T only
+    gu = torch.empty((T, 2 * I), dtype=torch.bfloat16, device=x2d.device) if (want_gu or act is None) else None  # want_gu=False: the product only
     actT = torch.empty((I, T), dtype=torch.bfloat16, device=x2d.device) if want_t else None
     prof = GEMM_PROFILE
     if prof is not None:

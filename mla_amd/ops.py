@@ -622,7 +622,7 @@ class DecoderLayerFn(torch.autograd.Function):
                 wd.shape[1] % 64 == 0)
 
     @staticmethod
-    def _fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold, need_out=True):
+    def _fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold, need_out=True, need_gu=True):
         """_fwd with both RMSNorms folded into the projections (mla_hip.h "RMSNorm folded into the projections"): no stand-alone norm
         pass; rstd1 / rstd2 come out of the QKV and gate|up launches. fold = NormFoldIO, or a saved rstd1 tensor (recomputation of a
         checkpointed layer: the same row scale as in the forward, whatever produced it there)."""
@@ -649,7 +649,7 @@ class DecoderLayerFn(torch.autograd.Function):
         o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
                               rows=T, groups=groups)
         h1, xg2, ss2 = hip.gemm_res_norm(o, wo, h2, ln2)
-        gu, act_, actT, rstd2 = hip.gemm_gateup_swiglu(xg2, wgu, save_t and T % 8 == 0, norm=(ss2, None, eps), want_act=need_out)
+        gu, act_, actT, rstd2 = hip.gemm_gateup_swiglu(xg2, wgu, save_t and T % 8 == 0, norm=(ss2, None, eps), want_act=need_out, want_gu=need_gu)
         del xg2, ss2
         if not need_out:
             out = None
@@ -661,15 +661,16 @@ class DecoderLayerFn(torch.autograd.Function):
         return out, (None, rstd1, qkv, o, lse, h1, None, rstd2, gu, act_, actT)
 
     @staticmethod
-    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False, groups=None, fold=None, need_out=True):
+    def _fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=False, groups=None, fold=None, need_out=True, need_gu=True):
         """need_out=False: the recomputation of a checkpointed layer inside its backward -- everything up to the SwiGLU product, NOT the
         down projection (its output is the layer output, which the backward never reads; torch.utils.checkpoint, the reference's
-        fsdp.py:211-223, recomputes it anyway: 22 % of a layer's forward FLOPs)."""
+        fsdp.py:211-223, recomputes it anyway: 22 % of a layer's forward FLOPs). need_gu=False: the FORWARD of a checkpointed layer --
+        gate|up never leaves the chip (only the SwiGLU product does; nothing but the layer input is kept)."""
         ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
         H = h2.shape[1]
         D = H // nheads
         if fold is not None:
-            return DecoderLayerFn._fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold, need_out)
+            return DecoderLayerFn._fwd_folded(h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t, groups, fold, need_out, need_gu)
         xn1, rstd1 = hip.rmsnorm_fwd(h2, ln1, eps)
         qkv = torch.empty((h2.shape[0], 3 * H), dtype=BF16, device=h2.device)
         wqkv = cat_view((wq, wk, wv))
@@ -694,7 +695,7 @@ class DecoderLayerFn(torch.autograd.Function):
         wgu = cat_view((wg, wu))
         # fused gate|up projection + SwiGLU: the product (and, with save_t, its transposed copy for the backward's wgrad) is formed in the
         # GEMM epilogue -- gu is written once and not read again in the forward pass
-        fused = (hip.gemm_gateup_swiglu(xn2, wgu, save_t and h2.shape[0] % 8 == 0, want_act=need_out)
+        fused = (hip.gemm_gateup_swiglu(xn2, wgu, save_t and h2.shape[0] % 8 == 0, want_act=need_out, want_gu=need_gu)
                  if (wgu is not None and _SWIGLU_FWD_EPILOGUE) else None)
         if fused is not None:
             gu, act_, actT = fused
@@ -737,8 +738,9 @@ class DecoderLayerFn(torch.autograd.Function):
         if fold is not None and fold.pre is not None and Tp != T and fold.pre[0] == h.data_ptr() and fold.pre[2].shape[0] == Tp:
             fold.pre = (h2.data_ptr(),) + tuple(fold.pre[1:])
         ctx.folded = fold is not None
-        out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT) = DecoderLayerFn._fwd(h2, seqlens, cos, sin, B, S, nheads, eps, w,
-                                                                                             save_t=keep_t, groups=ctx.groups, fold=fold)
+        out, (xn1, rstd1, qkv, o, lse, h1, xn2, rstd2, gu, act_, actT) = DecoderLayerFn._fwd(
+            h2, seqlens, cos, sin, B, S, nheads, eps, w, save_t=keep_t, groups=ctx.groups, fold=fold,
+            need_gu=not (save_level == 0 and _RECOMPUTE_LEAN))
         out = out[:T]
         ctx.w, ctx.dims, ctx.save_level = w, (B, S, H, nheads, eps), save_level
         ctx.aux = (seqlens, cos, sin)
