@@ -632,7 +632,7 @@ def main():
                                       + (" [TINY SMOKE MODEL - not the benchmark]" if args.tiny else ""),
                           "model": "mla-llama2-7b" if not args.tiny else "tiny", "global_batch": B_PER_GPU * world, "seq_len": S,
                           "parallelism": f"fsdp-rccl x{world}" if world > 1 else "single-gpu", "activation_save_level": args.save_level,
-                          **({"activation_policy": ("every decoder layer checkpointed (the reference's policy, fsdp.py:211-223)" if keep_layers == 0 else
+                          **({"activation_policy": ("every decoder layer checkpointed (the reference's policy, fsdp.py:211-223); a layer's recomputation stops in front of its down projection, whose output the backward never reads" if keep_layers == 0 else
                                                     f"MIXED (opt-in, not the reference's policy): last {keep_layers} of 32 decoder layers keep "
                                                     f"activations (level {args.keep_level}), {32 - keep_layers} checkpointed (level 0)")}
                              if args.config == 4 and not args.tiny else {}),
