@@ -263,14 +263,14 @@ def secondary_configs(steps=3, warmup=1, timeout_s=420):
     A child that fails is reported as {"error": ...}; it never takes the headline line down."""
     import subprocess
     res = {}
-    for cfg, extra in ((3, []), (4, ["--keep-layers", "0"]), (4, ["--keep-layers", "0", "--share-prefix"])):
+    for cfg, extra in ((3, []), (4, ["--keep-layers", "0"]), (4, ["--keep-layers", "0", "--share-prefix"]), (1, ["--readout-rows"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(cfg), "--steps", str(steps), "--warmup", str(warmup),
                "--no-cpu-baseline", "--no-secondary", "--no-box"] + extra
         t0 = time.time()
         try:
             cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
             line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
-            key = f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "")
+            key = f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "") + ("_readout_rows" if "--readout-rows" in extra else "")
             if cp.returncode != 0 or not line:
                 res[key] = {"error": f"rc {cp.returncode}", "stderr_tail": cp.stderr[-400:]}
                 continue
@@ -278,6 +278,7 @@ def secondary_configs(steps=3, warmup=1, timeout_s=420):
             r = j.get("roofline") or {}
             res[key] = {
                 **({"share_prefix": j["share_prefix"]} if "share_prefix" in j else {}),
+                **({"readout_rows": j["readout_rows"]} if "readout_rows" in j else {}),
                 "workload": j["config"]["workload"], "steps": j["steps"], "warmup": j["warmup"], "ms_per_step": j["ms_per_step"],
                 "value": j["value"], "unit": j["unit"], "seq_len": j["config"]["seq_len"],
                 **({"activation_policy": j["config"]["activation_policy"]} if "activation_policy" in j["config"] else {}),
@@ -286,9 +287,9 @@ def secondary_configs(steps=3, warmup=1, timeout_s=420):
                                                    "launches_per_step", "avg_launch_ms", "gemm_ms_per_step", "traffic")} if r else None,
                 "loss": j["loss"], "wall_s_incl_model_build": round(time.time() - t0, 1)}
         except subprocess.TimeoutExpired:
-            res[f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "")] = {"error": f"timeout after {timeout_s} s"}
+            res[f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "") + ("_readout_rows" if "--readout-rows" in extra else "")] = {"error": f"timeout after {timeout_s} s"}
         except Exception as e:   # noqa: BLE001 -- the headline line must survive anything the secondary runs do
-            res[f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "")] = {"error": repr(e)}
+            res[f"config{cfg}" + ("_shared_prefix" if "--share-prefix" in extra else "") + ("_readout_rows" if "--readout-rows" in extra else "")] = {"error": repr(e)}
     # latency of MLA.predict_action_diff (8-step DDIM, batch 1, 7B) -- with the prefix computed once per action chunk
     # (round 6, mla_amd/infer.py) and with the reference's control flow (a whole forward per DDIM step)
     for tag, extra in (("inference_predict_action_diff", []), ("inference_whole_forward_per_step", ["--no-reuse-prefix"])):
@@ -329,6 +330,9 @@ def main():
     ap.add_argument("--eager-lm-head", action="store_true",
                     help="compute lm_head + cross entropy inside every forward like the reference (modeling_llama.py:1255-1269) instead of on "
                          "first access of output.logits / output.loss (the default since round 6: the trainer discards `output`, SURVEY App. A #7)")
+    ap.add_argument("--readout-rows", action="store_true",
+                    help="opt-in (round 6, configs 1 / 4): MLA.readout_rows_only -- the last decoder layer runs its row-wise half (o_proj, MLP) on the "
+                         "action read-out rows only, the one thing the diffusion objective reads of the final hidden state")
     ap.add_argument("--no-box", action="store_true", help="skip the `box` block (sclk / power sampler + the two 300 ms MFMA calibrations)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (configs[3] and configs[4] at 3 timed steps each) the default 1-GPU configs[1] run appends")
@@ -394,6 +398,10 @@ def main():
     stage = "post-training" if gen_on else ("pretrain" if args.config == 4 else "finetune")   # config 4: the vision tokenizer trains too
     mla = build(device, args.save_level, args.tiny, use_pointcloud=pc_on, generation=gen_on, stage=stage)
     mla.vlm.llm_backbone.llm.config.lazy_lm_head = not args.eager_lm_head
+    if args.readout_rows:
+        if args.config == 3:
+            raise SystemExit("--readout-rows: the generation heads of config 3 read the whole final hidden state")
+        mla.readout_rows_only = True
     if args.share_prefix:
         if args.config != 4:
             raise SystemExit("--share-prefix applies to config 4 (use_pointcloud=False): with a point cloud the FPS start indices differ per copy")
@@ -530,6 +538,13 @@ def main():
         if not args.eager_lm_head:
             tot_fl = dec_fl                    # lazy lm_head: the 2 H V flops per token are not executed in a training step, so not counted
         ref_layout_fl = tot_fl
+        readout_fl = None
+        if args.readout_rows and not args.share_prefix:
+            # executed work: the last layer's o_proj + MLP (2 H^2 + 6 H I of its 8 H^2 + 6 H I per token, x 3 for forward + backward)
+            # run on the B' x T read-out rows instead of B' x S
+            H_, I_ = 4096, 11008
+            readout_fl = 3 * (2 * H_ * H_ + 6 * H_ * I_) * (S - 1) * R_DIFF
+            tot_fl -= readout_fl
         if args.share_prefix:
             # MFU figures are about EXECUTED work: one (S - 3) + 4 x 3 row sequence per sample (its causal attention priced as fully causal)
             tot_fl = model_flops_per_sample((S - 3) + (R_DIFF + 1) * 3, R=1)[0]      # (+ one dummy group: 2 060 rows, a multiple of 4)
@@ -651,6 +666,12 @@ def main():
                                             "the 2 060-row sequence (2 045 prefix + 4 suffix groups + 1 dummy group of 3 rows) priced as fully causal), so the speed-up over config4 is an algorithmic saving, "
                                             "not a kernel rate"}}
                   if args.share_prefix else {}),
+               **({"readout_rows": {"executed_tflop_per_sample": round(tot_fl / 1e12, 2), "dense_layout_tflop_per_sample": round(ref_layout_fl / 1e12, 2),
+                                    "note": "opt-in (MLA.readout_rows_only): the diffusion objective reads only the action read-out rows of the final hidden state "
+                                            "(models/vlm/prismatic.py:1115-1126; lm_head + CE are unused and lazy, `output` is discarded by the trainer), so the "
+                                            "last decoder layer runs o_proj + MLP, forward and backward, on those B' x T rows instead of B' x S. Same losses and "
+                                            "gradients to rounding; the dense final hidden state / logits are produced on first access. model_tflop_per_sample / "
+                                            "mfu in THIS line are the EXECUTED work"}} if readout_fl is not None else {}),
                **({"heads_encoders_tflop_per_sample_from_gemm_launches": round(heads_fl / 1e12, 2)} if heads_fl else {}),
                "model_tflops_per_gpu": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12, 1),
                "mfu_vs_2.5PF": round(tot_fl * B_PER_GPU / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -187,6 +187,15 @@ class LlamaDecoderLayer(nn.Module):
         self._fold_out = io.out if io is not None else None
         return (out,)
 
+    def forward_readout(self, hidden_states, rows, seqlens: Optional[torch.Tensor] = None, rope_tables=None):
+        """Rows `rows` (flat indices into B * S) of this layer's output [n, H]: the row-wise half of the layer (o_proj, MLP) runs on
+        those rows only (ops.ReadoutLayerFn). For the LAST decoder layer when nothing else of its output is read."""
+        B, S, _ = hidden_states.shape
+        cos, sin = rope_tables if rope_tables is not None else self.self_attn.rotary_emb.tables(S, hidden_states.device)
+        h = ops.unit_boundary(hidden_states, self._grad_hook)
+        return ops.decoder_layer_readout(h, seqlens, cos, sin, self.config.num_attention_heads, self.config.rms_norm_eps, rows,
+                                         self._weights())
+
 
 class LlamaModel(nn.Module):
     def __init__(self, config: LlamaConfig):
@@ -206,8 +215,11 @@ class LlamaModel(nn.Module):
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, cache_position=None,
-                attn_groups=None):
-        """attn_groups = (first suffix row, rows per group) with position_ids [S] (round 6, opt-in): one sequence per sample laid out
+                attn_groups=None, readout_rows=None):
+        """readout_rows (int64 [n], flat indices into B * S; round 6, opt-in): only these rows of the final hidden state are wanted --
+        the last decoder layer runs its row-wise half on them alone (ops.ReadoutLayerFn) and the call returns
+        (norm(rows) [n, H], hidden states of the layers in front, a callable that produces the dense final hidden state on demand).
+        attn_groups = (first suffix row, rows per group) with position_ids [S] (round 6, opt-in): one sequence per sample laid out
         as [prefix | R suffix groups]; every suffix row attends to the prefix and, causally, to its own group, and carries the position
         it has in the reference's R separate sequences (models/mla/model_mla.py:148-180 tiles the whole sample R times)."""
         if (input_ids is None) == (inputs_embeds is None):
@@ -233,8 +245,16 @@ class LlamaModel(nn.Module):
             for i, layer in enumerate(self.layers):
                 if output_hidden_states:
                     all_hidden += (hidden_states,)
+                if readout_rows is not None and i == n_layers - 1:
+                    last_in = hidden_states
+                    picked = self.norm(layer.forward_readout(last_in, readout_rows, seqlens=seqlens, rope_tables=rope_tables))
+
+                    def dense_last(layer=layer, last_in=last_in):
+                        with ops.attn_groups(attn_groups):
+                            return self.norm(layer(last_in, seqlens=seqlens, rope_tables=rope_tables)[0])
+                    return picked, all_hidden, dense_last
                 if fold:       # RMSNorms folded into the projections: layer i's down projection prepares layer i + 1's input norm
-                    nxt = self.layers[i + 1] if i + 1 < n_layers else None
+                    nxt = self.layers[i + 1] if (i + 1 < n_layers and not (readout_rows is not None and i + 1 == n_layers - 1)) else None
                     hidden_states = layer(hidden_states, seqlens=seqlens, rope_tables=rope_tables, norm_fold=(carry, nxt))[0]
                     carry, layer._fold_out = layer._fold_out, None
                 else:
@@ -317,17 +337,41 @@ class LlamaForCausalLM(nn.Module):
                 cache_position=None, pc_token_indices=None, img_token_indices=None, tac_token_indices=None,
                 patch_correspondence_indices=None, correspondence_valid_mask=None, positive_pc_indices_for_tac=None,
                 linear_positive_img_indices_for_tac=None, compute_token_contrastive_loss: bool = False,
-                compute_tactile_contrastive_loss: bool = False, attn_groups=None):
+                compute_tactile_contrastive_loss: bool = False, attn_groups=None, readout_rows=None):
+        """readout_rows (round 6, opt-in): the caller reads only these rows of the final hidden state (the action read-out of the
+        diffusion branch). Honoured in training with the lazy lm_head: `output.readout_hidden` [n, H] holds them, the dense final hidden
+        state / logits / loss are produced on first access of `output.hidden_states` / `.logits` / `.loss`. Otherwise the forward is
+        the dense one and `readout_hidden` is a gather of its rows."""
         output_hidden_states = (output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states)
         need_tap = self.training and (compute_token_contrastive_loss or compute_tactile_contrastive_loss)
-        hidden_states, all_hidden = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
-                                               past_key_values=past_key_values, use_cache=use_cache,
-                                               output_hidden_states=bool(output_hidden_states or need_tap),
-                                               position_ids=position_ids if attn_groups is not None else None, attn_groups=attn_groups)
-        B, S, H = hidden_states.shape
+        use_readout = readout_rows is not None and self.training and self.config.lazy_lm_head and attn_groups is None
+        model_out = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
+                               past_key_values=past_key_values, use_cache=use_cache,
+                               output_hidden_states=bool(output_hidden_states or need_tap),
+                               position_ids=position_ids if attn_groups is not None else None, attn_groups=attn_groups,
+                               readout_rows=readout_rows if use_readout else None)
+        readout_hidden, lazy_last = None, None
+        if use_readout:
+            readout_hidden, all_hidden, dense_last = model_out
+            cell = {}
+
+            def lazy_last():
+                if "v" not in cell:
+                    cell["v"] = dense_last()
+                return cell["v"]
+            ref = inputs_embeds if inputs_embeds is not None else input_ids
+            B, S, H = ref.shape[0], ref.shape[1], self.config.hidden_size
+            hidden_states = None
+        else:
+            hidden_states, all_hidden = model_out
+            B, S, H = hidden_states.shape
+            if readout_rows is not None:
+                readout_hidden = ops.gather_rows(hidden_states.reshape(B * S, H), readout_rows)
         logits, loss, lazy_lm = None, None, None
         if self.config.compute_lm_logits or labels is not None:
             def lm_and_ce(hidden_states=hidden_states, labels=labels):
+                if hidden_states is None:
+                    hidden_states = lazy_last()              # read-out forward: the dense last layer runs now, with autograd
                 h2 = hidden_states.reshape(B * S, H)
                 lg = LMHeadFn.apply(h2, self.lm_head.weight).view(B, S, -1)  # fp32, = lm_head(h).float()  (:1254-1255)
                 ce = None
@@ -369,7 +413,8 @@ class LlamaForCausalLM(nn.Module):
                 loss = loss + tactile_contrastive_loss
         return CausalLMOutputWithPast(loss=loss, logits=logits, img_pc_contrastive_loss=img_pc_contrastive_loss,
                                       tactile_contrastive_loss=tactile_contrastive_loss, past_key_values=None,
-                                      hidden_states=all_hidden if output_hidden_states else None, attentions=None, lazy_lm=lazy_lm)
+                                      hidden_states=all_hidden if output_hidden_states else None, attentions=None, lazy_lm=lazy_lm,
+                                      readout_hidden=readout_hidden, lazy_last=lazy_last if (use_readout and output_hidden_states) else None)
 
 
 class LMHeadFn(torch.autograd.Function):

@@ -42,6 +42,9 @@ class MLA(nn.Module):
             # round 6, opt-in: run the R diffusion copies of a sample as ONE [prefix | R suffix groups] sequence where the prefix does not depend
             # on the copy (PrismaticVLM.shared_prefix_ok(): the scripts/pretrain.sh configuration); see _forward_shared_prefix
             self.share_prefix = False
+            # opt-in (round 6): in the diffusion branch only the action read-out rows of the final hidden state are read; with this
+            # flag the last decoder layer computes its row-wise half (o_proj, MLP) on those rows alone (ops.ReadoutLayerFn)
+            self.readout_rows_only = False
             self.diffusion_steps = 100
             self.diffusion = create_diffusion(timestep_respacing="", noise_schedule="squaredcos_cap_v2", diffusion_steps=100,
                                               sigma_small=True, learn_sigma=False)
@@ -135,6 +138,7 @@ class MLA(nn.Module):
         rep = lambda v: v.repeat(R, *([1] * (v.ndimension() - 1)))  # noqa: E731
         if getattr(self, "share_prefix", False) and R > 1 and self.training and self.vlm.shared_prefix_ok():
             return self._forward_shared_prefix(input_ids, attention_mask, images, camera_name, labels, actions, proprio, R, noise, timestep)
+        self.vlm.readout_rows_only = bool(getattr(self, "readout_rows_only", False))
         proprio = rep(proprio)
         actions = rep(actions)
         actions_future = actions[:, -(self.future_action_window_size + 1):, :]

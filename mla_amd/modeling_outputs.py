@@ -18,13 +18,18 @@ class CausalLMOutputWithPast:
                  img_pc_contrastive_loss: Optional[torch.Tensor] = None, tactile_contrastive_loss: Optional[torch.Tensor] = None,
                  all_logits_for_action: Optional[torch.Tensor] = None, past_key_values: Optional[Tuple] = None,
                  hidden_states: Optional[Tuple[torch.Tensor, ...]] = None, attentions: Optional[Tuple[torch.Tensor, ...]] = None,
-                 lazy_lm: Optional[Callable[[], Tuple[torch.Tensor, Optional[torch.Tensor]]]] = None):
+                 lazy_lm: Optional[Callable[[], Tuple[torch.Tensor, Optional[torch.Tensor]]]] = None,
+                 readout_hidden: Optional[torch.Tensor] = None, lazy_last: Optional[Callable[[], torch.Tensor]] = None):
         self._loss, self._logits, self._lazy_lm = loss, logits, lazy_lm
+        # read-out mode (round 6, opt-in: MLA.readout_rows_only): `readout_hidden` [n, H] = the rows of the final hidden state the
+        # caller asked for; the DENSE final hidden state is produced by `lazy_last` on the first access of `hidden_states` (or of
+        # logits / loss, whose closure calls it) -- the trainer never does (base_strategy_mla.py:307,334)
+        self.readout_hidden, self._lazy_last = readout_hidden, lazy_last
         self.img_pc_contrastive_loss = img_pc_contrastive_loss
         self.tactile_contrastive_loss = tactile_contrastive_loss
         self.all_logits_for_action = all_logits_for_action
         self.past_key_values = past_key_values
-        self.hidden_states = hidden_states
+        self._hidden_states = hidden_states
         self.attentions = attentions
 
     def _materialise(self):
@@ -37,6 +42,22 @@ class CausalLMOutputWithPast:
                     if extra is not None:
                         loss = loss + extra
             self._loss = loss
+
+    @property
+    def hidden_states(self):
+        if self._lazy_last is not None and self._hidden_states is not None:
+            fn, self._lazy_last = self._lazy_last, None
+            self._hidden_states = tuple(self._hidden_states) + (fn(),)
+        return self._hidden_states
+
+    @hidden_states.setter
+    def hidden_states(self, v):
+        self._hidden_states, self._lazy_last = v, None
+
+    @property
+    def last_hidden_pending(self) -> bool:
+        """True while the dense final hidden state of a read-out forward has not been asked for."""
+        return self._lazy_last is not None
 
     @property
     def lm_head_pending(self) -> bool:

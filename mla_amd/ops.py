@@ -883,6 +883,158 @@ class DecoderLayerFn(torch.autograd.Function):
         return (dh, None, None, None, None, None, None, None, *grads)
 
 
+class ReadoutLayerFn(torch.autograd.Function):
+    """The LAST LlamaDecoderLayer when only a few rows of its output are read (round 6, opt-in: MLA.readout_rows_only).
+
+    In the diffusion branch the only consumer of the last hidden state is the action read-out (models/vlm/prismatic.py:1115-1126:
+    rows k + 2 .. k + 2 + T of every sequence -> FinalLayer); lm_head + CE are computed-but-unused and `output`
+    is discarded by the trainer. A decoder layer is row-wise everywhere except in the attention core, so for the last layer:
+      all rows : RMSNorm -> q|k|v projection (+RoPE) -> causal attention            (keys / values of every row are attended to)
+      read rows: o_proj + residual -> RMSNorm -> gate|up -> SwiGLU -> down + residual   (n rows instead of B * S)
+    and in the backward the gradient of the output is non-zero on the read rows only: MLP and o_proj backward run on n rows, the
+    attention backward and the q|k|v backward stay dense (d(out) of the attention is a zero matrix with n rows filled in).
+    Same mathematics as DecoderLayerFn followed by a row gather -- every loss and every gradient agrees with it to rounding (the small
+    GEMMs run on the 128-tile kernel: another accumulation order) -- at 9 of 12 units of the layer's forward GEMM work and 18 of 24 of
+    its backward's saved (one unit = rows x H x H): 2.3 % of the step's GEMM FLOPs at 32 layers.
+    forward(h [B, S, H], seqlens, cos, sin, nheads, eps, rows int64 [n] (flat indices into B * S), *w) -> [n, H]."""
+
+    @staticmethod
+    def forward(ctx, h, seqlens, cos, sin, nheads, eps, rows, *w):
+        _check_bf16_cuda(h, *w)
+        ln1, wq, wk, wv, wo, ln2, wg, wu, wd = w
+        B, S, H = h.shape
+        D = H // nheads
+        h2 = h.reshape(B * S, H)
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        T, Tp = B * S, _pad_tokens(B * S)
+        if Tp != T:
+            h2 = torch.cat([h2, h2.new_zeros(Tp - T, H)], 0)
+        groups = current_attn_groups()
+        # ---- dense half (DecoderLayerFn._fwd up to the attention output)
+        xn1, rstd1 = hip.rmsnorm_fwd(h2, ln1, eps)
+        qkv = torch.empty((Tp, 3 * H), dtype=BF16, device=h2.device)
+        wqkv = cat_view((wq, wk, wv))
+        Sr = cos.shape[0]
+        if not (wqkv is not None and D == 128 and _ROPE_EPILOGUE and hip.gemm_qkv_rope(xn1, wqkv, qkv, cos, sin, Sr, 2 * H)):
+            if wqkv is not None:
+                hip.gemm(xn1, wqkv, out=qkv)
+            else:
+                for i, wi in enumerate((wq, wk, wv)):
+                    hip.gemm(xn1, wi, out=qkv[:, i * H:(i + 1) * H])
+            hip.rope_inplace(qkv, cos, sin, Sr, nheads, D, 0, H)
+        del xn1
+        o, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, nheads, D, 3 * H, seqlens, 1.0 / math.sqrt(D),
+                              rows=Tp, groups=groups)
+        # ---- read rows only: zero rows pad n to a multiple of 64 (they stay zero through every row-wise op and add nothing to any
+        # weight gradient), so every small GEMM has MFMA-friendly row / reduction counts
+        n = rows.numel()
+        npad = (n + 63) // 64 * 64
+        o_r = hip.gather_rows(o, rows, out_rows=npad)
+        h_r = hip.gather_rows(h2, rows, out_rows=npad)
+        h1_r = hip.gemm(o_r, wo, residual=h_r)
+        xn2_r, rstd2_r = hip.rmsnorm_fwd(h1_r, ln2, eps)
+        wgu = cat_view((wg, wu))
+        if wgu is not None:
+            gu_r = hip.gemm(xn2_r, wgu)
+        else:
+            I = wg.shape[0]
+            gu_r = torch.empty((npad, 2 * I), dtype=BF16, device=h2.device)
+            hip.gemm(xn2_r, wg, out=gu_r[:, :I])
+            hip.gemm(xn2_r, wu, out=gu_r[:, I:])
+        act_r = hip.swiglu_fwd(gu_r)
+        out_r = hip.gemm(act_r, wd, residual=h1_r)
+        ctx.w, ctx.dims, ctx.aux, ctx.groups, ctx.n = w, (B, S, H, nheads, eps), (seqlens, cos, sin), groups, n
+        ctx.save_for_backward(h2, rstd1, qkv, o, lse, rows, o_r, h1_r, rstd2_r, gu_r, act_r)
+        return out_r[:n]
+
+    @staticmethod
+    def backward(ctx, dout_r):
+        ln1, wq, wk, wv, wo, ln2, wg, wu, wd = ctx.w
+        B, S, H, nheads, eps = ctx.dims
+        seqlens, cos, sin = ctx.aux
+        D = H // nheads
+        h2, rstd1, qkv, o, lse, rows, o_r, h1_r, rstd2_r, gu_r, act_r = ctx.saved_tensors
+        need = ctx.needs_input_grad[7:]
+        n, npad, T = ctx.n, o_r.shape[0], h2.shape[0]
+        Tr = B * S
+        d_r = dout_r.reshape(n, H)
+        if npad != n or not d_r.is_contiguous():
+            d_r = torch.cat([d_r, d_r.new_zeros(npad - n, H)], 0) if npad != n else d_r.contiguous()
+        grads: List[Optional[torch.Tensor]] = [None] * 9
+        # ---- MLP on the read rows (dgrad with the weights as they are stored: reduction-major B operand, npad rows make it cheap)
+        dact_r = hip.gemm(d_r, wd, b_mode=1)                                     # [npad, I]
+        if need[8]:
+            grads[8] = deliver_wgrad((wd,), d_r, act_r, need[8:9])[0]
+        dgu_r, _ = hip.swiglu_bwd(dact_r, gu_r)
+        wgu = cat_view((wg, wu))
+        if wgu is not None:
+            dxn2_r = hip.gemm(dgu_r, wgu, b_mode=1)                              # [npad, H]
+        else:
+            I = wg.shape[0]
+            dxn2_r = hip.gemm(dgu_r[:, :I].contiguous(), wg, b_mode=1)
+            dxn2_r = hip.gemm(dgu_r[:, I:].contiguous(), wu, b_mode=1, residual=dxn2_r)
+        if need[6] or need[7]:
+            xn2_r, _ = hip.rmsnorm_fwd(h1_r, ln2, eps)
+            grads[6], grads[7] = deliver_wgrad((wg, wu), dgu_r, xn2_r, need[6:8])
+        holder = {}
+
+        def ln2_run(dw_out, acc):
+            holder["dh1"] = hip.rmsnorm_bwd(dxn2_r, h1_r, ln2, rstd2_r, dres=d_r, dw_out=dw_out, dw_accumulate=acc)
+
+        if need[5]:
+            grads[5] = deliver_vec_grad(ln2, ln2_run)
+        else:
+            ln2_run(None, False)
+        dh1_r = holder["dh1"]                                                    # [npad, H]: gradient of the residual stream on the read rows
+        # ---- attention output projection on the read rows; its input gradient goes back into a dense zero matrix
+        do_r = hip.gemm(dh1_r, wo, b_mode=1)
+        if need[4]:
+            grads[4] = deliver_wgrad((wo,), dh1_r, o_r, need[4:5])[0]
+        do = hip.gather_rows(do_r[:n], rows, out_rows=T, scatter=True)
+        dres = hip.gather_rows(dh1_r[:n], rows, out_rows=T, scatter=True)        # residual path into the layer input
+        # ---- dense half: attention backward, q|k|v backward, input norm backward (DecoderLayerFn.backward)
+        dqkv = torch.empty_like(qkv)
+        if T != Tr:
+            dqkv[Tr:].zero_()
+        fuse_rope = cos.shape[0] in (S, B * S) and cos.is_contiguous() and sin.is_contiguous() and cos.dtype == torch.float32
+        want_qkv_w = need[1] or need[2] or need[3]
+        tr = None
+        if _ATTN_BWD_T and fuse_rope and S % 4 == 0 and want_qkv_w:
+            tr = (torch.empty((3 * H, T), dtype=BF16, device=qkv.device), torch.empty((H, T), dtype=BF16, device=qkv.device))
+            if T != Tr:
+                tr[0][:, Tr:].zero_()
+                tr[1][:, Tr:].zero_()
+        hip.attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], o, do, lse, seqlens, dqkv[:, :H], dqkv[:, H:2 * H],
+                     dqkv[:, 2 * H:], B, S, nheads, D, 3 * H, 1.0 / math.sqrt(D), rope_cos=cos if fuse_rope else None,
+                     rope_sin=sin if fuse_rope else None, transposed=tr, groups=ctx.groups)
+        del do
+        if not fuse_rope:
+            hip.rope_inplace(dqkv, cos, sin, cos.shape[0], nheads, D, 0, H, backward=True)
+        wqkv = cat_view((wq, wk, wv))
+        dxn1 = hip.gemm(dqkv, hip.transpose(wqkv if wqkv is not None else torch.cat([wq, wk, wv], 0)))
+        if want_qkv_w:
+            xn1T = hip.rmsnorm_apply_t(h2, ln1, rstd1)
+            grads[1], grads[2], grads[3] = deliver_wgrad_nt((wq, wk, wv), tr[0] if tr is not None else hip.transpose(dqkv), xn1T, need[1:4])
+            del xn1T
+        del dqkv, tr
+
+        def ln1_run(dw_out, acc):
+            holder["dh"] = hip.rmsnorm_bwd(dxn1, h2, ln1, rstd1, dres=dres, dw_out=dw_out, dw_accumulate=acc)
+
+        if need[0]:
+            grads[0] = deliver_vec_grad(ln1, ln1_run)
+        else:
+            ln1_run(None, False)
+        dh = holder["dh"][:Tr].view(B, S, H) if ctx.needs_input_grad[0] else None
+        return (dh, None, None, None, None, None, None, *grads)
+
+
+def decoder_layer_readout(h, seqlens, cos, sin, nheads, eps, rows, weights):
+    """Rows `rows` (flat indices into B * S) of LlamaDecoderLayer(h): see ReadoutLayerFn."""
+    return ReadoutLayerFn.apply(h, seqlens, cos, sin, nheads, eps, rows, *weights)
+
+
 def decoder_layer(h, seqlens, cos, sin, nheads, eps, save_level, weights, fold_io=None):
     return DecoderLayerFn.apply(h, seqlens, cos, sin, nheads, eps, save_level, fold_io, *weights)
 

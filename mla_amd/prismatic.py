@@ -521,6 +521,12 @@ class PrismaticVLM(nn.Module):
             raise IndexError(f"input_ids row without the splice tag {tag_0}: the reference indexes the last occurrence "
                              "(models/vlm/prismatic.py:983) and fails the same way")
 
+        # ---- action read-out rows (:1115-1126): rows k+2 .. k+2+T of the last hidden state -> FinalLayer
+        rows = (torch.arange(B, device=dev)[:, None] * S + k + 2 + torch.arange(T, device=dev)[None]).reshape(-1)
+        gen_active = self.use_generation and (self.gen_image or self.gen_pointcloud or self.gen_tactile) and self.training
+        # opt-in (round 6, MLA.readout_rows_only): nothing but these rows of the final hidden state is read in the diffusion branch
+        # (the generation heads read all of it), so the last decoder layer runs its row-wise half on them alone
+        readout = rows if (getattr(self, "readout_rows_only", False) and self.training and not gen_active) else None
         output: CausalLMOutputWithPast = self.llm_backbone(
             input_ids=None, attention_mask=fused_attention_mask, position_ids=None, past_key_values=None,
             inputs_embeds=fused_embeddings, labels=fused_labels, use_cache=use_cache, output_attentions=output_attentions,
@@ -528,9 +534,9 @@ class PrismaticVLM(nn.Module):
             tac_token_indices=tac_idx, patch_correspondence_indices=patch_indices, correspondence_valid_mask=valid_mask,
             positive_pc_indices_for_tac=pos_pc_tac, linear_positive_img_indices_for_tac=lin_img_tac,
             compute_token_contrastive_loss=self.use_contrastive,
-            compute_tactile_contrastive_loss=(self.use_contrastive and self.use_tactile))
+            compute_tactile_contrastive_loss=(self.use_contrastive and self.use_tactile), readout_rows=readout)
 
-        last_hidden = output.hidden_states[-1]
+        last_hidden = output.hidden_states[-1] if (gen_active or output.readout_hidden is None) else None
         # ---- generation heads (:1071-1113). current_point_cloud=None is what the reference passes (:1098), so the FPS prior of
         # the point head never runs; the per-step visualisation (:1129-1135, hard-coded path) is deliberately not reproduced.
         generation_outputs: Dict[str, torch.Tensor] = {}
@@ -556,9 +562,8 @@ class PrismaticVLM(nn.Module):
             generation_losses = self.compute_generation_losses(generation_outputs, next_images=next_images,
                                                                next_point_cloud=next_point_cloud, next_tactile=next_tactile)
 
-        # ---- action read-out (:1115-1126): rows k+2 .. k+2+T of the last hidden state -> FinalLayer
-        rows = (torch.arange(B, device=dev)[:, None] * S + k + 2 + torch.arange(T, device=dev)[None]).reshape(-1)
-        picked = ops.gather_rows(last_hidden.reshape(B * S, H), rows)
+        # ---- action read-out (:1115-1126)
+        picked = output.readout_hidden if output.readout_hidden is not None else ops.gather_rows(last_hidden.reshape(B * S, H), rows)
         noise_pred = self.final_layer(picked).view(B, T, -1)
         if self.training:
             return output, noise_pred, generation_outputs, generation_losses
