@@ -1,9 +1,11 @@
 """MLA wrapper (reference: models/mla/model_mla.py:47-309): diffusion branch of forward + wrap policy + freeze."""
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
+
 import torch
 import torch.nn as nn
 
@@ -44,7 +46,7 @@ class MLA(nn.Module):
             self.share_prefix = False
             # opt-in (round 6): in the diffusion branch only the action read-out rows of the final hidden state are read; with this
             # flag the last decoder layer computes its row-wise half (o_proj, MLP) on those rows alone (ops.ReadoutLayerFn)
-            self.readout_rows_only = False
+            self.readout_rows_only = os.environ.get("MLA_READOUT_ROWS", "0") != "0"
             self.diffusion_steps = 100
             self.diffusion = create_diffusion(timestep_respacing="", noise_schedule="squaredcos_cap_v2", diffusion_steps=100,
                                               sigma_small=True, learn_sigma=False)

@@ -143,6 +143,27 @@ def test_folded_norms_through_the_sharded_path_match_the_collective_free_path(de
         assert not bad, (kind, bad)
 
 
+def test_readout_rows_through_the_sharded_path_match_the_collective_free_path(dev, tmp_path):
+    """MLA_READOUT_ROWS=1 (the last decoder layer on its read-out rows, opt-in) through FSDPStrategy: the last layer's weight gradients
+    come from the small GEMMs of ops.ReadoutLayerFn, its unit's reduce-scatter is launched by the same backward hook. Masters, AdamW
+    moments and bf16 copies after two steps are bit-identical between the collective-free path and the forced-collectives RCCL path, and
+    the losses sit next to the dense run's."""
+    ro = {"MLA_READOUT_ROWS": "1"}
+    dense = _child({}, tmp_path / "dense.pt")
+    plain = _child(ro, tmp_path / "plain.pt")
+    got = _child(dict(ro, USE_PG="1", MLA_FORCE_COLLECTIVES="1"), tmp_path / "coll.pt")
+    assert got["coll"] and got["backend"] == "nccl"
+    assert got["losses"] == plain["losses"]
+    for a, b in zip(plain["losses"], dense["losses"]):
+        assert abs(a - b) <= 2e-2 * abs(b), (plain["losses"], dense["losses"])
+    for kind in ("master", "exp_avg", "exp_avg_sq", "flat16"):
+        bad = [k for k in plain[kind] if not torch.equal(got[kind][k], plain[kind][k])]
+        assert not bad, (kind, bad)
+    # the read-out run really took the other path: the last layer's master weights differ from the dense run's in the last bits
+    diff = [k for k in plain["master"] if not torch.equal(plain["master"][k], dense["master"][k])]
+    assert diff, "MLA_READOUT_ROWS=1 did not change anything"
+
+
 RS = r"""
 import os, sys, torch
 import torch.distributed as dist
