@@ -89,5 +89,8 @@ class CausalLMOutputWithPast:
                      if v is not None)[k]
 
     def __repr__(self):
-        return "CausalLMOutputWithPast(" + ", ".join(f"{f}={'<lazy>' if f in ('loss', 'logits') and self.lm_head_pending else type(getattr(self, f)).__name__}"
-                                                     for f in self._FIELDS) + ")"
+        def show(f):
+            if (f in ("loss", "logits") and self.lm_head_pending) or (f == "hidden_states" and self.last_hidden_pending):
+                return "<lazy>"          # (printing an output must not run lm_head or the dense last layer)
+            return type(getattr(self, f)).__name__
+        return "CausalLMOutputWithPast(" + ", ".join(f"{f}={show(f)}" for f in self._FIELDS) + ")"

@@ -555,3 +555,27 @@ def test_lazy_lm_output_materialises_once_and_adds_the_contrastive_terms_in_orde
     assert float(plain.loss) == 1.0 and plain.logits is None and not plain.lm_head_pending
     none = CausalLMOutputWithPast(lazy_lm=lambda: (torch.zeros(1), None), img_pc_contrastive_loss=torch.tensor(1.0))
     assert none.loss is None and none.logits is not None          # no labels -> no CE -> loss stays None (the reference would raise on None + tensor)
+
+
+def test_readout_output_keeps_the_dense_last_hidden_state_lazy():
+    """Read-out mode (round 6, opt-in MLA.readout_rows_only): `readout_hidden` holds the rows the caller asked for; the dense final hidden
+    state is appended to `hidden_states` on FIRST access, once, and neither repr() nor the other fields trigger it; assigning
+    `hidden_states` drops the pending computation."""
+    from mla_amd.modeling_outputs import CausalLMOutputWithPast
+    calls = []
+
+    def last():
+        calls.append(1)
+        return torch.full((1,), 9.0)
+    out = CausalLMOutputWithPast(hidden_states=(torch.zeros(1), torch.ones(1)), lazy_last=last, readout_hidden=torch.full((2, 4), 3.0),
+                                 img_pc_contrastive_loss=torch.tensor(0.5))
+    assert out.last_hidden_pending and not calls and "hidden_states=<lazy>" in repr(out) and not calls
+    assert out.readout_hidden.shape == (2, 4) and float(out.img_pc_contrastive_loss) == 0.5 and not calls
+    hs = out.hidden_states
+    assert len(hs) == 3 and float(hs[-1]) == 9.0 and calls == [1] and not out.last_hidden_pending
+    assert out.hidden_states is hs and calls == [1]
+    other = CausalLMOutputWithPast(hidden_states=(torch.zeros(1),), lazy_last=last)
+    other.hidden_states = None
+    assert other.hidden_states is None and not other.last_hidden_pending and calls == [1]
+    dense = CausalLMOutputWithPast(hidden_states=(torch.zeros(1),))
+    assert not dense.last_hidden_pending and len(dense.hidden_states) == 1 and dense.readout_hidden is None
