@@ -198,3 +198,53 @@ def test_tiny_mla_step_with_readout_rows_against_the_reference_golden(dev):
     A, C = float(e2e["A_llm_loss"]), float(e2e["C_llm_loss"])
     assert abs(float(out.loss) - A) <= 2 * abs(C - A)
     assert not out.lm_head_pending
+
+
+def test_llama_stack_with_readout_rows_and_folded_norms_together(dev):
+    """LlamaModel.forward(readout_rows=...) with MLA_NORM_FOLD on as well (both opt-ins): the layer in front of the last one must NOT
+    prepare a folded input norm for the read-out layer (it runs the plain rmsnorm), the read rows equal the dense stack's rows of the
+    final hidden state to rounding, and so do the input gradient and every parameter gradient."""
+    from mla_amd import ops
+    from mla_amd.llama import LlamaConfig, LlamaModel
+    cfg = LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+                      rms_norm_eps=1e-5, activation_save_level=1)
+    torch.manual_seed(5)
+    m = LlamaModel(cfg).to(dev).to(BF)
+    for layer in m.layers:
+        ps = list(layer._weights())
+        flat = torch.empty(sum(p.numel() for p in ps), dtype=BF, device=dev)
+        o = 0
+        for p in ps:
+            flat[o:o + p.numel()] = p.data.reshape(-1)
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+    B, S, H = 3, 128, 256
+    emb = recipe.det_randn("emb", (B, S, H), 1.0).to(BF).to(dev)
+    rows = torch.tensor([100, S + 90, 2 * S + 127], device=dev)
+    dy = recipe.det_randn("dy", (3, H), 1.0).to(BF).to(dev)
+
+    def run(readout, fold):
+        for p in m.parameters():
+            p.grad = None
+        prev = ops.set_norm_fold(fold)
+        try:
+            x = emb.clone().requires_grad_(True)
+            if readout:
+                picked, hidden, dense_last = m(inputs_embeds=x, output_hidden_states=True, readout_rows=rows)
+                assert len(hidden) == 3 and callable(dense_last)
+            else:
+                last, _ = m(inputs_embeds=x)
+                picked = last.reshape(B * S, H)[rows]
+            picked.backward(dy)
+        finally:
+            ops.set_norm_fold(prev)
+        return picked.detach(), x.grad, {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+
+    a = run(True, True)
+    b = run(False, False)
+    assert fro_rel(a[0], b[0]) < 1e-2 and fro_rel(a[1], b[1]) < 2.5e-2
+    assert a[2].keys() == b[2].keys()
+    for n in a[2]:
+        assert fro_rel(a[2][n], b[2][n]) < 2.5e-2, (n, fro_rel(a[2][n], b[2][n]))
+    a2 = run(True, True)
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
